@@ -1,0 +1,177 @@
+"""Clean-room mini data layer: ``Data`` / ``Batch`` / ``DataLoader`` /
+``from_networkx``.
+
+The reference gets these from PyTorch-Geometric (``train_causal.py:4,13-15``,
+``utils.py:4,55``), which is not vendored.  Only the surface the hot path
+touches is provided (SURVEY.md section 8b "batch protocol"):
+
+* ``data.x`` **or** ``data.feat`` ``[N, F]`` fp32 -- ``data.x`` is ``None`` when
+  absent (``model.py:87``), ``data.edge_index`` ``[2, E]`` int64, ``data.batch``
+  ``[N]`` int64 (sorted), ``data.y``, ``data.num_graphs``, ``data.to(device)``.
+* ``DataLoader(dataset, batch_size, shuffle)`` with ``len(loader.dataset)``
+  (``train_causal.py:194``).
+
+A ``Batch`` additionally carries ``ptr`` ([B+1] node offsets) and lazily caches
+the device ``GraphPlan`` (CSR structures) the HIP kernels consume.
+"""
+from __future__ import annotations
+
+import random as _random
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+
+_NODE_KEYS = ("x", "feat")
+
+
+class Data:
+    def __init__(self, x=None, edge_index=None, y=None, feat=None, **kw):
+        self.x = x
+        self.feat = feat
+        self.edge_index = edge_index
+        self.y = y
+        self.batch = None
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    # -- PyG-style introspection -------------------------------------------
+    @property
+    def num_nodes(self) -> int:
+        for k in _NODE_KEYS:
+            v = getattr(self, k, None)
+            if v is not None:
+                return int(v.size(0))
+        nn = getattr(self, "_num_nodes", None)
+        if nn is not None:
+            return nn
+        return int(self.edge_index.max().item()) + 1 if self.edge_index.numel() else 0
+
+    @num_nodes.setter
+    def num_nodes(self, v):
+        self._num_nodes = int(v)
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.edge_index.size(1))
+
+    @property
+    def num_features(self) -> int:
+        v = self.x if self.x is not None else self.feat
+        return 0 if v is None else int(v.size(1))
+
+    def _tensor_keys(self):
+        return [k for k, v in self.__dict__.items() if torch.is_tensor(v)]
+
+    def to(self, device, non_blocking: bool = False):
+        for k in self._tensor_keys():
+            setattr(self, k, getattr(self, k).to(device, non_blocking=non_blocking))
+        if getattr(self, "_plan", None) is not None and self._plan.device != torch.device(device):
+            self._plan = None
+        return self
+
+    def __repr__(self):
+        parts = [f"{k}={list(getattr(self, k).shape)}" for k in self._tensor_keys()]
+        return f"{self.__class__.__name__}({', '.join(parts)})"
+
+
+class Batch(Data):
+    """Disjoint union of graphs (block-diagonal adjacency)."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ptr = None
+        self.num_graphs = 0
+        self._plan = None
+
+    @staticmethod
+    def from_data_list(data_list: Sequence[Data]) -> "Batch":
+        b = Batch()
+        xs, feats, eis, ys, bvec, ptr = [], [], [], [], [], [0]
+        off = 0
+        for i, d in enumerate(data_list):
+            n = d.num_nodes
+            if d.x is not None:
+                xs.append(d.x)
+            if d.feat is not None:
+                feats.append(d.feat)
+            eis.append(d.edge_index + off)
+            if d.y is not None:
+                ys.append(d.y.view(-1))
+            bvec.append(torch.full((n,), i, dtype=torch.long))
+            off += n
+            ptr.append(off)
+        b.x = torch.cat(xs, 0) if xs else None
+        b.feat = torch.cat(feats, 0) if feats else None
+        b.edge_index = torch.cat(eis, 1) if eis else torch.zeros(2, 0, dtype=torch.long)
+        b.y = torch.cat(ys, 0) if ys else None
+        b.batch = torch.cat(bvec, 0) if bvec else torch.zeros(0, dtype=torch.long)
+        b.ptr = torch.tensor(ptr, dtype=torch.long)
+        b.num_graphs = len(data_list)
+        return b
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.batch.size(0))
+
+
+class DataLoader:
+    """``DataLoader(dataset, batch_size, shuffle)`` (train_causal.py:13-15).
+
+    Shuffling uses ``torch.randperm`` (as ``torch.utils.data.RandomSampler``
+    does); ``rank``/``world_size`` give each data-parallel replica a disjoint
+    strided shard of every epoch's permutation.
+    """
+
+    def __init__(self, dataset, batch_size: int = 1, shuffle: bool = False,
+                 rank: int = 0, world_size: int = 1, drop_last: bool = False,
+                 generator: Optional[torch.Generator] = None):
+        self.dataset = dataset
+        self.batch_size = int(batch_size)
+        self.shuffle = shuffle
+        self.rank, self.world_size = rank, world_size
+        self.drop_last = drop_last
+        self.generator = generator
+
+    def _indices(self) -> List[int]:
+        n = len(self.dataset)
+        idx = (torch.randperm(n, generator=self.generator).tolist()
+               if self.shuffle else list(range(n)))
+        if self.world_size > 1:
+            per = n // self.world_size if self.drop_last else -(-n // self.world_size)
+            idx = idx[self.rank::self.world_size][:per]
+        return idx
+
+    def __len__(self) -> int:
+        n = len(self._indices()) if self.world_size > 1 else len(self.dataset)
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self) -> Iterable[Batch]:
+        idx = self._indices()
+        for s in range(0, len(idx), self.batch_size):
+            chunk = idx[s:s + self.batch_size]
+            if self.drop_last and len(chunk) < self.batch_size:
+                return
+            yield Batch.from_data_list([self.dataset[i] for i in chunk])
+
+
+def from_networkx(G) -> Data:
+    """PyG ``from_networkx`` (call site utils.py:55): relabel to 0..n-1, make
+    directed (both directions of every undirected edge, grouped by source),
+    stack node attributes into ``[N, ...]`` tensors."""
+    import networkx as nx
+    import numpy as np
+
+    G = nx.convert_node_labels_to_integers(G)
+    G = G.to_directed() if not nx.is_directed(G) else G
+    edges = list(G.edges)
+    edge_index = (torch.tensor(edges, dtype=torch.long).t().contiguous()
+                  if edges else torch.zeros(2, 0, dtype=torch.long))
+    data = Data(edge_index=edge_index)
+    keys = set()
+    for _, feat_dict in G.nodes(data=True):
+        keys |= set(feat_dict.keys())
+    for k in keys:
+        vals = [G.nodes[i][k] for i in range(G.number_of_nodes())]
+        setattr(data, str(k), torch.tensor(np.asarray(vals)))
+    data.num_nodes = G.number_of_nodes()
+    return data
