@@ -1,0 +1,92 @@
+"""ctypes binding of libcalhip.so, driven by include/cal_hip.h.
+
+The header is the single source of truth: every ``CAL_API`` declaration is
+parsed into a ctypes prototype.  There is **no fallback**: if the shared
+library is missing ``lib()`` raises, and every compute wrapper in
+``cal_amd.ops`` refuses CPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "cal_hip.h")
+LIB_PATH = os.path.join(HERE, "lib", "libcalhip.so")
+
+_SCALARS = {
+    "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
+    "uint64_t": ctypes.c_uint64, "float": ctypes.c_float, "double": ctypes.c_double,
+}
+
+
+def _ctype(decl: str):
+    decl = decl.replace("const", " ").strip()
+    if "*" in decl:
+        return ctypes.c_char_p if decl.replace(" ", "").startswith("char*") else ctypes.c_void_p
+    return _SCALARS[decl.split()[0]]
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object], List[str]]]:
+    """{name: (restype, [argtypes], [argnames])} for every CAL_API declaration."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"CAL_API\s+([\w\s\*]+?)\s*\b(cal_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        argtypes, argnames = [], []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                argtypes.append(_ctype(mm.group(1)))
+                argnames.append(mm.group(2))
+        protos[name] = (_ctype(ret), argtypes, argnames)
+    return protos
+
+
+class CalError(RuntimeError):
+    pass
+
+
+_LIB = None
+_PROTOS = None
+
+
+def lib():
+    """Load libcalhip.so (building nothing: use ``python -m cal_amd.build``)."""
+    global _LIB, _PROTOS
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise CalError(
+            "libcalhip.so not found at %s -- build it with `python -m cal_amd.build` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    handle = ctypes.CDLL(LIB_PATH)
+    _PROTOS = parse_header()
+    for name, (ret, argtypes, _) in _PROTOS.items():
+        fn = getattr(handle, name)      # AttributeError if the library lacks a declared symbol
+        fn.restype = ret
+        fn.argtypes = argtypes
+    _LIB = handle
+    return _LIB
+
+
+def protos():
+    lib()
+    return _PROTOS
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point; raise CalError with cal_last_error() on failure."""
+    h = lib()
+    rc = getattr(h, name)(*args)
+    if rc != 0:
+        raise CalError("%s failed (%d): %s" % (name, rc, h.cal_last_error().decode()))
+
+
+def query(name: str, *args) -> int:
+    """Call a size-query entry point (returns int64)."""
+    return int(getattr(lib(), name)(*args))

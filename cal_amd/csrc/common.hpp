@@ -1,0 +1,116 @@
+// Shared device/host helpers for libcalhip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CAL_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace cal {
+
+void set_error(const char* fmt, ...);
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // default workgroup: 4 waves, one per SIMD
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// lanes cooperating on one feature row: smallest power of two covering H/vec, <= 64
+inline int group_for(int H, int vec) {
+    int need = (H + vec - 1) / vec;
+    int g = 1;
+    while (g < need && g < 64) g <<= 1;
+    return g;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int G>
+__device__ __forceinline__ double group_sum_d(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int G>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// vector-of-VEC float load/store helpers (VEC = 1 or 4)
+template <int VEC> struct Vec;
+template <> struct Vec<4> {
+    float4 v;
+    __device__ __forceinline__ static Vec ld(const float* p) { Vec r; r.v = *reinterpret_cast<const float4*>(p); return r; }
+    __device__ __forceinline__ void st(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ __forceinline__ static Vec zero() { Vec r; r.v = make_float4(0.f, 0.f, 0.f, 0.f); return r; }
+    __device__ __forceinline__ void fma(float a, const Vec& x) {
+        v.x = fmaf(a, x.v.x, v.x); v.y = fmaf(a, x.v.y, v.y); v.z = fmaf(a, x.v.z, v.z); v.w = fmaf(a, x.v.w, v.w);
+    }
+    __device__ __forceinline__ void add(const Vec& x) { v.x += x.v.x; v.y += x.v.y; v.z += x.v.z; v.w += x.v.w; }
+    __device__ __forceinline__ void scale(float a) { v.x *= a; v.y *= a; v.z *= a; v.w *= a; }
+    __device__ __forceinline__ void relu() { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    __device__ __forceinline__ float dot(const Vec& x) const {
+        return fmaf(v.w, x.v.w, fmaf(v.z, x.v.z, fmaf(v.y, x.v.y, v.x * x.v.x)));
+    }
+    __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+};
+template <> struct Vec<1> {
+    float v;
+    __device__ __forceinline__ static Vec ld(const float* p) { Vec r; r.v = *p; return r; }
+    __device__ __forceinline__ void st(float* p) const { *p = v; }
+    __device__ __forceinline__ static Vec zero() { Vec r; r.v = 0.f; return r; }
+    __device__ __forceinline__ void fma(float a, const Vec& x) { v = fmaf(a, x.v, v); }
+    __device__ __forceinline__ void add(const Vec& x) { v += x.v; }
+    __device__ __forceinline__ void scale(float a) { v *= a; }
+    __device__ __forceinline__ void relu() { v = fmaxf(v, 0.f); }
+    __device__ __forceinline__ float dot(const Vec& x) const { return v * x.v; }
+    __device__ __forceinline__ float get(int) const { return v; }
+};
+
+}  // namespace cal
+
+#define CAL_CHECK_LAUNCH(name)                                               \
+    do {                                                                     \
+        hipError_t e_ = hipGetLastError();                                   \
+        if (e_ != hipSuccess) {                                              \
+            cal::set_error("%s: %s", name, hipGetErrorString(e_));           \
+            return 1;                                                        \
+        }                                                                    \
+    } while (0)
+
+#define CAL_REQUIRE(cond, msg)                                               \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            cal::set_error("%s: %s", __func__, msg);                         \
+            return 2;                                                        \
+        }                                                                    \
+    } while (0)
+
+// Dispatch on (vectorisable?, group width) -> KERNEL<VEC, G>
+#define CAL_DISPATCH_VG(H, vec_ok, BODY)                                     \
+    do {                                                                     \
+        if (vec_ok) {                                                        \
+            constexpr int VEC = 4;                                           \
+            int g_ = cal::group_for((H), 4);                                 \
+            if (g_ <= 8) { constexpr int G = 8; BODY; }                      \
+            else if (g_ == 16) { constexpr int G = 16; BODY; }               \
+            else if (g_ == 32) { constexpr int G = 32; BODY; }               \
+            else { constexpr int G = 64; BODY; }                             \
+        } else {                                                             \
+            constexpr int VEC = 1;                                           \
+            int g_ = cal::group_for((H), 1);                                 \
+            if (g_ <= 8) { constexpr int G = 8; BODY; }                      \
+            else if (g_ == 16) { constexpr int G = 16; BODY; }               \
+            else if (g_ == 32) { constexpr int G = 32; BODY; }               \
+            else { constexpr int G = 64; BODY; }                             \
+        }                                                                    \
+    } while (0)

@@ -1,0 +1,314 @@
+// GATv1 attention layer on the GraphPlan CSR (fp32): what the reference gets from PyG's
+// GATConv(hidden, hidden/heads, heads=heads, dropout=p) at model.py:340,390.
+//
+//   z = x W  (dense, done by the GEMM)                       [N, K*D]
+//   a_dst[i,k] = <z[i,k,:], att[k,:D]>,  a_src[j,k] = <z[j,k,:], att[k,D:]>
+//   e = LeakyReLU_slope(a_dst[i] + a_src[j]);  alpha = softmax over the incoming edges of i
+//   (self loops of the input dropped, one loop per node added), exp(e-max)/(sum+1e-16);
+//   alpha~ = alpha * keep/(1-p) in training;  out[i,k,:] = sum_j alpha~ z[j,k,:] + bias.
+//
+// One G-lane group per destination row; every lane owns VEC consecutive columns of one head and
+// walks the row's slots itself, so the per-head softmax needs no cross-lane traffic in the forward.
+// Only (max, denominator) per (node, head) are kept for the backward; alpha is recomputed.
+// Roofline: HBM-bound gather, same bytes as cal_spmm_fwd plus 3*E'*K*4 for the logits.
+#include "common.hpp"
+
+namespace cal {
+
+__device__ __forceinline__ uint32_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (uint32_t)(x >> 32);
+}
+// Counter-based keep decision for (edge slot id, head): reproducible in the backward.
+__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t id, int k, int K, float p, float inv_keep) {
+    if (p <= 0.f) return 1.f;
+    uint32_t r = mix64(seed ^ (uint64_t)(id * K + k) * 0xD6E8FEB86659FD93ull);
+    return ((float)r * (1.0f / 4294967296.0f)) >= p ? inv_keep : 0.f;
+}
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
+
+// thread per (node, head)
+__global__ void k_gat_scores(const float* __restrict__ z, const float* __restrict__ att,
+                             float* __restrict__ adst, float* __restrict__ asrc, int N, int K, int D) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * K) return;
+    int k = t % K;
+    const float* zp = z + (size_t)t * D;          // [v, k, :] is contiguous at (v*K + k)*D
+    const float* ad = att + (size_t)k * 2 * D;
+    float sd = 0.f, ss = 0.f;
+    for (int d = 0; d < D; ++d) {
+        float zv = zp[d];
+        sd = fmaf(zv, ad[d], sd);
+        ss = fmaf(zv, ad[D + d], ss);
+    }
+    adst[t] = sd;
+    asrc[t] = ss;
+}
+
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_gat_fwd(const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                 const int* __restrict__ eid, const float* __restrict__ z,
+                                                 const float* __restrict__ adst, const float* __restrict__ asrc,
+                                                 const float* __restrict__ bias, int relu, float slope, float p,
+                                                 uint64_t seed, int64_t E, float* __restrict__ out,
+                                                 float* __restrict__ mx, float* __restrict__ den, int N, int K, int D) {
+    constexpr int RPB = 256 / G;
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    const int i = blockIdx.x * RPB + g;
+    if (i >= N) return;
+    const int H = K * D;
+    const int s0 = rowptr[i], s1 = rowptr[i + 1];
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    using V = Vec<VEC>;
+    for (int c = l * VEC; c < H; c += G * VEC) {
+        const int k = c / D;
+        const float ad = adst[(size_t)i * K + k];
+        const float eself = lrelu(ad + asrc[(size_t)i * K + k], slope);
+        float m = eself;
+        for (int s = s0; s < s1; ++s) m = fmaxf(m, lrelu(ad + asrc[(size_t)nbr[s] * K + k], slope));
+        float lsum = 0.f;
+        V acc = V::zero();
+        for (int s = s0; s < s1; ++s) {
+            const int j = nbr[s];
+            float pe = expf(lrelu(ad + asrc[(size_t)j * K + k], slope) - m);
+            lsum += pe;
+            acc.fma(pe * keep_scale(seed, eid[s], k, K, p, inv_keep), V::ld(z + (size_t)j * H + c));
+        }
+        {
+            float pe = expf(eself - m);
+            lsum += pe;
+            acc.fma(pe * keep_scale(seed, E + i, k, K, p, inv_keep), V::ld(z + (size_t)i * H + c));
+        }
+        const float dn = lsum + 1e-16f;
+        acc.scale(1.f / dn);
+        if (bias) acc.add(V::ld(bias + c));
+        if (relu) acc.relu();
+        acc.st(out + (size_t)i * H + c);
+        if (c % D == 0) { mx[(size_t)i * K + k] = m; den[(size_t)i * K + k] = dn; }
+    }
+}
+
+// Backward pass 1+2 over the by-destination CSR.  Lanes of one head (LH = D/VEC of them, a power
+// of two) reduce their partial dots with shuffles.  draw[id*K + k] (id = edge id, or E + i for the
+// loop of node i) receives d(raw logit); dadst[i,k] the row sum.
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_gat_bwd_dst(const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                     const int* __restrict__ eid, const float* __restrict__ z,
+                                                     const float* __restrict__ adst, const float* __restrict__ asrc,
+                                                     const float* __restrict__ mx, const float* __restrict__ den,
+                                                     const float* __restrict__ gout, float slope, float p,
+                                                     uint64_t seed, int64_t E, float* __restrict__ draw,
+                                                     float* __restrict__ dadst, int N, int K, int D) {
+    constexpr int RPB = 256 / G;
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    const int i = blockIdx.x * RPB + g;
+    if (i >= N) return;
+    const int H = K * D;
+    const int LH = D / VEC;
+    const int s0 = rowptr[i], s1 = rowptr[i + 1];
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    using V = Vec<VEC>;
+    for (int c = l * VEC; c < H; c += G * VEC) {
+        const int k = c / D;
+        const bool head_lead = (c % D) == 0;
+        const float ad = adst[(size_t)i * K + k];
+        const float m = mx[(size_t)i * K + k], dn = den[(size_t)i * K + k];
+        const V gi = V::ld(gout + (size_t)i * H + c);
+        float S = 0.f;
+        for (int s = s0; s <= s1; ++s) {
+            const int j = s < s1 ? nbr[s] : i;
+            const int64_t id = s < s1 ? (int64_t)eid[s] : E + i;
+            float dot = gi.dot(V::ld(z + (size_t)j * H + c));
+            for (int o = LH / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+            const float alpha = expf(lrelu(ad + asrc[(size_t)j * K + k], slope) - m) / dn;
+            const float dalpha = dot * keep_scale(seed, id, k, K, p, inv_keep);
+            S = fmaf(alpha, dalpha, S);
+            if (head_lead) draw[id * K + k] = dalpha;
+        }
+        float rowsum = 0.f;
+        for (int s = s0; s <= s1; ++s) {
+            const int j = s < s1 ? nbr[s] : i;
+            const int64_t id = s < s1 ? (int64_t)eid[s] : E + i;
+            const float raw = ad + asrc[(size_t)j * K + k];
+            const float alpha = expf(lrelu(raw, slope) - m) / dn;
+            float dalpha = draw[id * K + k];        // written by this head's lead lane above
+            dalpha = __shfl(dalpha, (threadIdx.x & 63) & ~(LH - 1), 64);
+            const float de = alpha * (dalpha - S);
+            const float dr = de * (raw > 0.f ? 1.f : slope);
+            rowsum += dr;
+            if (head_lead) draw[id * K + k] = dr;
+        }
+        if (head_lead) dadst[(size_t)i * K + k] = rowsum;
+    }
+}
+
+// thread per (node j, head k): dasrc[j,k] = sum over edges leaving j (+ its loop) of draw
+__global__ void k_gat_bwd_dasrc(const int* __restrict__ ptr_src, const int* __restrict__ eid_src,
+                                const float* __restrict__ draw, int64_t E, float* __restrict__ dasrc, int N, int K) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * K) return;
+    int j = t / K, k = t % K;
+    float s = 0.f;
+    for (int q = ptr_src[j]; q < ptr_src[j + 1]; ++q) s += draw[(int64_t)eid_src[q] * K + k];
+    s += draw[(E + j) * K + k];
+    dasrc[t] = s;
+}
+
+// dz[j,k,:] = sum_{s: src = j} alpha~_s g[dst_s,k,:] + alpha~_loop g[j,k,:]
+//           + dadst[j,k] att[k,:D] + dasrc[j,k] att[k,D:]
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_gat_bwd_src(const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                     const int* __restrict__ eid, const float* __restrict__ att,
+                                                     const float* __restrict__ adst, const float* __restrict__ asrc,
+                                                     const float* __restrict__ mx, const float* __restrict__ den,
+                                                     const float* __restrict__ gout, const float* __restrict__ dadst,
+                                                     const float* __restrict__ dasrc, float slope, float p,
+                                                     uint64_t seed, int64_t E, float* __restrict__ dz, int N, int K, int D) {
+    constexpr int RPB = 256 / G;
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    const int j = blockIdx.x * RPB + g;
+    if (j >= N) return;
+    const int H = K * D;
+    const int s0 = rowptr[j], s1 = rowptr[j + 1];
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    using V = Vec<VEC>;
+    for (int c = l * VEC; c < H; c += G * VEC) {
+        const int k = c / D, d = c % D;
+        const float as = asrc[(size_t)j * K + k];
+        V acc = V::zero();
+        for (int s = s0; s <= s1; ++s) {
+            const int i = s < s1 ? nbr[s] : j;
+            const int64_t id = s < s1 ? (int64_t)eid[s] : E + j;
+            const float alpha = expf(lrelu(adst[(size_t)i * K + k] + as, slope) - mx[(size_t)i * K + k]) / den[(size_t)i * K + k];
+            acc.fma(alpha * keep_scale(seed, id, k, K, p, inv_keep), V::ld(gout + (size_t)i * H + c));
+        }
+        acc.fma(dadst[(size_t)j * K + k], V::ld(att + (size_t)k * 2 * D + d));
+        acc.fma(dasrc[(size_t)j * K + k], V::ld(att + (size_t)k * 2 * D + D + d));
+        acc.st(dz + (size_t)j * H + c);
+    }
+}
+
+// partial sums for d att: part[blk, k, 0:D] = sum_v dadst[v,k] z[v,k,:], part[blk, k, D:2D] = sum_v dasrc[v,k] z[v,k,:]
+__global__ void __launch_bounds__(256) k_gat_datt_part(const float* __restrict__ z, const float* __restrict__ dadst,
+                                                       const float* __restrict__ dasrc, float* __restrict__ part,
+                                                       int N, int K, int D, int rows_per_block) {
+    const int H = K * D;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const int k = c / D, d = c % D;
+        float a = 0.f, b = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            float zv = z[(size_t)r * H + c];
+            a = fmaf(dadst[(size_t)r * K + k], zv, a);
+            b = fmaf(dasrc[(size_t)r * K + k], zv, b);
+        }
+        part[(size_t)blockIdx.x * 2 * H + (size_t)k * 2 * D + d] = a;
+        part[(size_t)blockIdx.x * 2 * H + (size_t)k * 2 * D + D + d] = b;
+    }
+}
+
+__global__ void k_gat_datt_finish(const float* __restrict__ part, int nparts, int n, float* __restrict__ datt) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + c];
+    datt[c] = s;
+}
+
+// keep mask (1/0) as floats, [E + N, K]: row e < E for original edge e, row E + i for node i's loop
+__global__ void k_gat_mask(uint64_t seed, int64_t rows, int K, float p, float* __restrict__ mask) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * K) return;
+    mask[t] = keep_scale(seed, t / K, (int)(t % K), K, p, 1.f);
+}
+
+}  // namespace cal
+
+using namespace cal;
+
+static inline bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int gat_rows_per_block(int64_t N) {
+    int64_t rpb = (N + 1023) / 1024;
+    return (int)(rpb < 16 ? 16 : rpb);
+}
+
+// z [N,K*D] (= x W), att [K,2D] (first D: target half, last D: source half), bias [K*D] or null.
+// Outputs: out [N,K*D]; saved for backward: adst, asrc, mx, den, each [N,K].
+// p > 0 applies attention dropout with the counter-based mask of `seed` (cal_gat_dropout_mask
+// materialises the same mask for tests).
+CAL_EXPORT int cal_gat_fwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst, const float* z,
+                           const float* att, const float* bias, int relu, float slope, float p, uint64_t seed,
+                           float* out, float* adst, float* asrc, float* mx, float* den, int64_t N, int64_t E,
+                           int64_t K, int64_t D, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N == 0) return 0;
+    CAL_REQUIRE(K > 0 && D > 0, "bad head shape");
+    CAL_REQUIRE(p >= 0.f && p < 1.f, "dropout p must be in [0,1)");
+    int64_t H = K * D;
+    hipLaunchKernelGGL(k_gat_scores, dim3(cdiv(N * K, 256)), dim3(256), 0, stream, z, att, adst, asrc, (int)N, (int)K, (int)D);
+    CAL_CHECK_LAUNCH("k_gat_scores");
+    bool vec_ok = (D % 4 == 0) && aligned16(z) && aligned16(out) && (!bias || aligned16(bias));
+    CAL_DISPATCH_VG((int)H, vec_ok, {
+        hipLaunchKernelGGL((k_gat_fwd<VEC, G>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst,
+                           z, adst, asrc, bias, relu, slope, p, seed, E, out, mx, den, (int)N, (int)K, (int)D);
+    });
+    CAL_CHECK_LAUNCH("k_gat_fwd");
+    return 0;
+}
+
+CAL_EXPORT int64_t cal_gat_bwd_ws(int64_t N, int64_t E, int64_t K, int64_t D) {
+    int64_t nb = N == 0 ? 1 : cdiv(N, gat_rows_per_block(N));
+    return (E + N) * K + 2 * N * K + nb * 2 * K * D + 16;
+}
+
+// gout [N,K*D]: gradient at the layer output (already masked by the ReLU if one was fused).
+// Outputs dz [N,K*D], datt [K,2D].  ws: cal_gat_bwd_ws floats.
+CAL_EXPORT int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst,
+                           const int32_t* rowptr_src, const int32_t* nbr_src, const int32_t* eid_src, const float* z,
+                           const float* att, const float* adst, const float* asrc, const float* mx, const float* den,
+                           const float* gout, float slope, float p, uint64_t seed, float* dz, float* datt, float* ws,
+                           int64_t N, int64_t E, int64_t K, int64_t D, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t H = K * D;
+    int rpb = gat_rows_per_block(N);
+    int nb = N == 0 ? 0 : cdiv(N, rpb);
+    float* draw = ws;
+    float* dadst = draw + ((E + N) * K + 3) / 4 * 4;
+    float* dasrc = dadst + (N * K + 3) / 4 * 4;
+    float* part = dasrc + (N * K + 3) / 4 * 4;
+    if (N > 0) {
+        bool vec_ok = (D % 4 == 0) && pow2(D / 4) && aligned16(z) && aligned16(gout) && aligned16(dz) && aligned16(att);
+        CAL_REQUIRE(vec_ok || pow2(D), "head dim must be a power of two (or 4 * a power of two)");
+        CAL_DISPATCH_VG((int)H, vec_ok, {
+            hipLaunchKernelGGL((k_gat_bwd_dst<VEC, G>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr_dst, nbr_dst,
+                               eid_dst, z, adst, asrc, mx, den, gout, slope, p, seed, E, draw, dadst, (int)N, (int)K, (int)D);
+        });
+        CAL_CHECK_LAUNCH("k_gat_bwd_dst");
+        hipLaunchKernelGGL(k_gat_bwd_dasrc, dim3(cdiv(N * K, 256)), dim3(256), 0, stream, rowptr_src, eid_src, draw, E, dasrc, (int)N, (int)K);
+        CAL_CHECK_LAUNCH("k_gat_bwd_dasrc");
+        CAL_DISPATCH_VG((int)H, vec_ok, {
+            hipLaunchKernelGGL((k_gat_bwd_src<VEC, G>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr_src, nbr_src,
+                               eid_src, att, adst, asrc, mx, den, gout, dadst, dasrc, slope, p, seed, E, dz, (int)N, (int)K, (int)D);
+        });
+        CAL_CHECK_LAUNCH("k_gat_bwd_src");
+        int threads = (int)(H > 256 ? 256 : ((H + 63) / 64) * 64);
+        hipLaunchKernelGGL(k_gat_datt_part, dim3(nb), dim3(threads), 0, stream, z, dadst, dasrc, part, (int)N, (int)K, (int)D, rpb);
+        CAL_CHECK_LAUNCH("k_gat_datt_part");
+    }
+    hipLaunchKernelGGL(k_gat_datt_finish, dim3(cdiv(2 * H, 256)), dim3(256), 0, stream, part, nb, (int)(2 * H), datt);
+    CAL_CHECK_LAUNCH("k_gat_datt_finish");
+    return 0;
+}
+
+CAL_EXPORT int cal_gat_dropout_mask(uint64_t seed, int64_t E, int64_t N, int64_t K, float p, float* mask, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int64_t n = (E + N) * K;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_gat_mask, dim3(cdiv(n, 256)), dim3(256), 0, stream, seed, E + N, (int)K, p, mask);
+    CAL_CHECK_LAUNCH("k_gat_mask");
+    return 0;
+}

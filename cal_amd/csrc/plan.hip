@@ -1,0 +1,184 @@
+// GraphPlan: COO edge list -> CSR-by-destination + CSR-by-source (int32), both
+// with the original edge id per slot, explicit self loops dropped.
+//
+// Replaces, once per mini-batch, what the reference recomputes in every layer:
+// remove_self_loops + add_self_loops inside GCNConv.norm (gcn_conv.py:56-57)
+// and the implicit scatter index of MessagePassing.propagate (gcn_conv.py:92).
+// The N added self loops are never materialised: every consumer kernel adds the
+// diagonal term itself.  Slots inside a row are sorted by edge id, so every
+// segment reduction downstream runs in a fixed order (run-to-run deterministic,
+// and the same order as a sequential CPU scatter_add).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.hpp"
+
+namespace cal {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// cnt layout: [0, N] in-degree(+1 pad), [N+1, 2N+1] out-degree(+1 pad)
+__global__ void k_plan_count(const int64_t* __restrict__ ei, int64_t E, int N,
+                             int* __restrict__ cnt_dst, int* __restrict__ cnt_src,
+                             int* __restrict__ row32, int* __restrict__ col32,
+                             int* __restrict__ status) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int64_t r = ei[e], c = ei[E + e];
+    if (r < 0 || r >= N || c < 0 || c >= N) {   // reference would raise an index error
+        atomicOr(status, 1);
+        row32[e] = 0; col32[e] = 0;             // treated as a dropped self loop
+        return;
+    }
+    row32[e] = (int)r;
+    col32[e] = (int)c;
+    if (r != c) {
+        atomicAdd(&cnt_dst[c], 1);
+        atomicAdd(&cnt_src[r], 1);
+    }
+}
+
+// Single-workgroup exclusive scan of n counters into n+1 offsets; block y picks the array.
+__global__ void __launch_bounds__(1024) k_plan_scan(const int* __restrict__ cnt_a, int* __restrict__ ptr_a,
+                                                    const int* __restrict__ cnt_b, int* __restrict__ ptr_b,
+                                                    int n) {
+    const int* cnt = blockIdx.x == 0 ? cnt_a : cnt_b;
+    int* ptr = blockIdx.x == 0 ? ptr_a : ptr_b;
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = i < n ? cnt[i] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wave_tot[wid] = x;
+        __syncthreads();
+        int carry = carry_s;
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wave_tot[w];
+        if (i < n) ptr[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ptr[n] = carry_s;
+}
+
+__global__ void k_plan_fill(const int* __restrict__ row32, const int* __restrict__ col32, int64_t E,
+                            const int* __restrict__ ptr_dst, const int* __restrict__ ptr_src,
+                            int* __restrict__ cur_dst, int* __restrict__ cur_src,
+                            int* __restrict__ nbr_d, int* __restrict__ eid_d,
+                            int* __restrict__ nbr_s, int* __restrict__ eid_s) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    int r = row32[e], c = col32[e];
+    if (r == c) return;
+    int p = ptr_dst[c] + atomicAdd(&cur_dst[c], 1);
+    nbr_d[p] = r; eid_d[p] = (int)e;
+    int q = ptr_src[r] + atomicAdd(&cur_src[r], 1);
+    nbr_s[q] = c; eid_s[q] = (int)e;
+}
+
+// One thread per (row, direction): insertion sort of the row's slots by edge id.
+__global__ void k_plan_sort(const int* __restrict__ ptr_dst, int* __restrict__ nbr_d, int* __restrict__ eid_d,
+                            const int* __restrict__ ptr_src, int* __restrict__ nbr_s, int* __restrict__ eid_s,
+                            int N) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * N) return;
+    const int* ptr = t < N ? ptr_dst : ptr_src;
+    int* nbr = t < N ? nbr_d : nbr_s;
+    int* eid = t < N ? eid_d : eid_s;
+    int v = t < N ? t : t - N;
+    int s0 = ptr[v], s1 = ptr[v + 1];
+    for (int i = s0 + 1; i < s1; ++i) {
+        int ke = eid[i], kn = nbr[i];
+        int j = i - 1;
+        while (j >= s0 && eid[j] > ke) {
+            eid[j + 1] = eid[j];
+            nbr[j + 1] = nbr[j];
+            --j;
+        }
+        eid[j + 1] = ke;
+        nbr[j + 1] = kn;
+    }
+}
+
+// gptr[b] = first node index whose graph id is >= b; batch must be sorted.
+__global__ void k_graph_ptr(const int64_t* __restrict__ batch, int N, int B, int* __restrict__ gptr,
+                            int* __restrict__ status) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    int64_t prev = i == 0 ? -1 : batch[i - 1];
+    int64_t cur = i == N ? (int64_t)B : batch[i];
+    if (i < N && (cur < prev || cur >= B || cur < 0)) { atomicOr(status, 2); return; }
+    for (int64_t b = prev + 1; b <= cur && b <= B; ++b) gptr[b] = i;
+}
+
+}  // namespace cal
+
+using namespace cal;
+
+CAL_EXPORT const char* cal_last_error() { return g_err; }
+CAL_EXPORT int cal_version() { return 100; }
+
+// Build both CSR views.  `work` must hold 4*(N+1) ints; `status` one int (bit0: edge index out of
+// range, bit1: batch vector not sorted / out of range) -- zeroed here, read by the caller when it
+// chooses to validate.
+CAL_EXPORT int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
+                              int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
+                              int32_t* rowptr_src, int32_t* nbr_src, int32_t* eid_src,
+                              int32_t* row32, int32_t* col32, int32_t* work, int32_t* status,
+                              void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CAL_REQUIRE(N >= 0 && E >= 0 && N < (1ll << 31) && E < (1ll << 31), "N/E out of int32 range");
+    int n = (int)N;
+    int* cnt_dst = work;
+    int* cnt_src = work + (n + 1);
+    int* cur_dst = work + 2 * (n + 1);
+    int* cur_src = work + 3 * (n + 1);
+    if (hipMemsetAsync(work, 0, sizeof(int) * 4 * (size_t)(n + 1), stream) != hipSuccess ||
+        hipMemsetAsync(status, 0, sizeof(int), stream) != hipSuccess) {
+        set_error("cal_plan_build: memset failed");
+        return 1;
+    }
+    if (E > 0) {
+        hipLaunchKernelGGL(k_plan_count, dim3(cdiv(E, 256)), dim3(256), 0, stream, edge_index, E, n,
+                           cnt_dst, cnt_src, row32, col32, status);
+        CAL_CHECK_LAUNCH("k_plan_count");
+    }
+    hipLaunchKernelGGL(k_plan_scan, dim3(2), dim3(1024), 0, stream, cnt_dst, rowptr_dst, cnt_src, rowptr_src, n);
+    CAL_CHECK_LAUNCH("k_plan_scan");
+    if (E > 0) {
+        hipLaunchKernelGGL(k_plan_fill, dim3(cdiv(E, 256)), dim3(256), 0, stream, row32, col32, E,
+                           rowptr_dst, rowptr_src, cur_dst, cur_src, nbr_dst, eid_dst, nbr_src, eid_src);
+        CAL_CHECK_LAUNCH("k_plan_fill");
+        if (n > 0) {
+            hipLaunchKernelGGL(k_plan_sort, dim3(cdiv(2 * (int64_t)n, 256)), dim3(256), 0, stream,
+                               rowptr_dst, nbr_dst, eid_dst, rowptr_src, nbr_src, eid_src, n);
+            CAL_CHECK_LAUNCH("k_plan_sort");
+        }
+    }
+    return 0;
+}
+
+CAL_EXPORT int cal_graph_ptr(const int64_t* batch, int64_t N, int64_t B, int32_t* gptr, int32_t* status,
+                             void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    CAL_REQUIRE(N >= 0 && B >= 0 && N < (1ll << 31), "bad sizes");
+    hipLaunchKernelGGL(k_graph_ptr, dim3(cdiv(N + 1, 256)), dim3(256), 0, stream, batch, (int)N, (int)B, gptr, status);
+    CAL_CHECK_LAUNCH("k_graph_ptr");
+    return 0;
+}

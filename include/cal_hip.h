@@ -1,0 +1,115 @@
+/* libcalhip -- C ABI of the MI355X (gfx950) kernels behind cal_amd.
+ *
+ * The reference (yongduosui/CAL) has no FFI: its hot path is Python calling
+ * PyTorch-Geometric / torch_scatter operators.  Each entry point below replaces
+ * one such operator call site (cited file:line, paths relative to the reference
+ * root) and is what a binding of that path would bind (INTEGRATION.md shows the
+ * ctypes stub).
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; cal_last_error()
+ *    returns the (thread-local) message of the last failure;
+ *  - all pointers are DEVICE pointers owned by the caller (torch allocations),
+ *    contiguous row-major; float buffers 16-byte aligned for the vector paths
+ *    (unaligned / H % 4 != 0 inputs take a scalar path);
+ *  - features fp32, reference indices int64 (edge_index, batch), plan indices
+ *    int32;
+ *  - `stream` is the hipStream_t to launch on (torch's current stream);
+ *    functions only enqueue work: no allocation, no synchronisation, safe to
+ *    capture in a hipGraph;
+ *  - E = number of edges of the input edge_index (self loops included),
+ *    N = nodes, H = feature width, B = graphs, K = heads, D = head width.
+ */
+#ifndef CAL_HIP_H
+#define CAL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAL_API __attribute__((visibility("default")))
+
+CAL_API const char* cal_last_error(void);
+CAL_API int cal_version(void);
+
+/* ---- GraphPlan ---------------------------------------------------------------
+ * COO -> CSR-by-destination and CSR-by-source with edge ids, explicit self loops
+ * dropped (remove_self_loops, gcn_conv.py:56); the N loops add_self_loops
+ * appends (gcn_conv.py:57-63) stay implicit.  work: 4*(N+1) int32.  status: 1
+ * int32, bit0 = edge index out of range, bit1 = batch not sorted/out of range. */
+CAL_API int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
+                           int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
+                           int32_t* rowptr_src, int32_t* nbr_src, int32_t* eid_src,
+                           int32_t* row32, int32_t* col32, int32_t* work, int32_t* status,
+                           void* stream);
+/* node offsets of each graph from the sorted `batch` vector (train_causal.py:174 batch object) */
+CAL_API int cal_graph_ptr(const int64_t* batch, int64_t N, int64_t B, int32_t* gptr,
+                          int32_t* status, void* stream);
+
+/* ---- GCNConv (gcn_conv.py:44-104) ------------------------------------------ */
+/* GCNConv.norm, gcn_conv.py:44-70 */
+CAL_API int cal_gcn_norm_fwd(const int32_t* rowptr_src, const int32_t* eid_src,
+                             const int32_t* row32, const int32_t* col32, const float* w,
+                             float loop_w, int64_t N, int64_t E, float* dis, float* norm_e,
+                             void* stream);
+/* propagate + message + update (+ fused ReLU of model.py:95), gcn_conv.py:92-104 */
+CAL_API int cal_spmm_fwd(const int32_t* rowptr, const int32_t* nbr, const int32_t* eid,
+                         const float* norm_e, const float* dis, float loop_w, const float* h,
+                         const float* bias, int relu, float* out, int64_t N, int64_t H,
+                         void* stream);
+CAL_API int64_t cal_colsum_parts(int64_t N);
+/* ReLU backward + bias gradient (gcn_conv.py:103, model.py:95) */
+CAL_API int cal_relu_bwd_colsum(const float* dout, const float* y, float* dz, float* dbias,
+                                float* part, int64_t N, int64_t H, void* stream);
+/* autograd of gcn_conv.py:63-70,97 w.r.t. edge_weight */
+CAL_API int cal_gcn_norm_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst,
+                             const int32_t* rowptr_src, const int32_t* nbr_src, const int32_t* eid_src,
+                             const int32_t* row32, const int32_t* col32, const float* w,
+                             const float* dis, float loop_w, const float* h, const float* dz,
+                             float* gn_e, float* gself, float* ddeg, float* dw, int64_t N,
+                             int64_t E, int64_t H, void* stream);
+
+/* ---- causal / trivial soft masks (model.py:97-111) ------------------------- */
+CAL_API int cal_edge_att_fwd(const float* x, const float* W, const float* b, const int32_t* row32,
+                             const int32_t* col32, float* pq, float* att, int64_t N, int64_t E,
+                             int64_t H, void* stream);
+CAL_API int64_t cal_edge_att_bwd_ws(int64_t N, int64_t E, int64_t H);
+CAL_API int cal_edge_att_bwd(const float* x, const float* W, const float* att, const float* datt,
+                             const int32_t* rowptr_src, const int32_t* eid_src,
+                             const int32_t* rowptr_dst, const int32_t* eid_dst, float* dx,
+                             int accumulate, float* dW, float* db, float* ws, int64_t N, int64_t E,
+                             int64_t H, void* stream);
+CAL_API int cal_node_att_split_fwd(const float* x, const float* Wn, const float* bn, float* att_n,
+                                   float* xc, float* xo, int64_t N, int64_t H, void* stream);
+CAL_API int64_t cal_node_att_bwd_ws(int64_t N, int64_t H);
+CAL_API int cal_node_att_split_bwd(const float* x, const float* Wn, const float* att_n,
+                                   const float* dxc, const float* dxo, float* dx, float* dWn,
+                                   float* dbn, float* ws, int64_t N, int64_t H, void* stream);
+
+/* ---- global_add_pool (model.py:115-116, 403-404) --------------------------- */
+CAL_API int cal_add_pool_fwd(const float* x, const int32_t* gptr, float* out, float* part,
+                             int64_t B, int64_t H, int64_t S, void* stream);
+CAL_API int cal_add_pool_bwd(const float* dout, const int64_t* batch, float* dx, int64_t N,
+                             int64_t H, void* stream);
+
+/* ---- GATConv (PyG, call sites model.py:340,390) ----------------------------- */
+CAL_API int cal_gat_fwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst,
+                        const float* z, const float* att, const float* bias, int relu, float slope,
+                        float p, uint64_t seed, float* out, float* adst, float* asrc, float* mx,
+                        float* den, int64_t N, int64_t E, int64_t K, int64_t D, void* stream);
+CAL_API int64_t cal_gat_bwd_ws(int64_t N, int64_t E, int64_t K, int64_t D);
+CAL_API int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst,
+                        const int32_t* rowptr_src, const int32_t* nbr_src, const int32_t* eid_src,
+                        const float* z, const float* att, const float* adst, const float* asrc,
+                        const float* mx, const float* den, const float* gout, float slope, float p,
+                        uint64_t seed, float* dz, float* datt, float* ws, int64_t N, int64_t E,
+                        int64_t K, int64_t D, void* stream);
+CAL_API int cal_gat_dropout_mask(uint64_t seed, int64_t E, int64_t N, int64_t K, float p,
+                                 float* mask, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAL_HIP_H */

@@ -1,0 +1,145 @@
+"""GPU parity of the nn.Module surface (CausalGCN / CausalGAT) against the CPU
+oracle: committed golden fixtures (eval logits, one training step) and seeded
+batches at the BASELINE.json config-2 shape.  Logit tolerance 1e-4 (north_star)."""
+import argparse
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cal_oracle as O
+from tests.helpers import GOLDEN, ref_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+LOGIT_TOL = 1e-4
+
+
+def _args(**kw):
+    d = dict(layers=3, hidden=128, with_random=True, without_node_attention=False,
+             without_edge_attention=False, fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def _build(name, nfeat, ncls, args, sd=None):
+    from cal_amd import model as M
+    m = getattr(M, name)(nfeat, ncls, args)
+    if sd is not None:
+        m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name,fname", [("CausalGCN", "causal_gcn_batch8.npz"),
+                                        ("CausalGAT", "causal_gat_batch8.npz")])
+def test_golden_fixture_eval_and_train_step(name, fname):
+    fx = np.load(os.path.join(GOLDEN, fname))
+    b = ref_batch(list(fx["ids"]))
+    sd = {k[3:]: torch.from_numpy(fx[k]).clone() for k in fx.files if k.startswith("sd.")}
+    perm = torch.from_numpy(fx["perm"])
+    m = _build(name, 10, 4, _args(layers=2, hidden=32), sd)
+    bd = ref_batch(list(fx["ids"])).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        ev = m(bd, eval_random=False, perm=perm)
+    for n, t in zip(("c", "o", "co"), ev):
+        assert np.abs(t.cpu().numpy() - fx[f"eval_logits_{n}"]).max() < LOGIT_TOL, n
+    # one training step (GAT attention dropout off, as in the fixture)
+    m.train()
+    if name == "CausalGAT":
+        for c in m.convs:
+            c.dropout = 0.0
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    opt.zero_grad()
+    logits = m(bd, eval_random=True, perm=perm)
+    for n, t in zip(("c", "o", "co"), logits):
+        assert np.abs(t.detach().cpu().numpy() - fx[f"train_logits_{n}"]).max() < LOGIT_TOL, n
+    loss, lc, lo, lco = O.causal_loss(*logits, bd.y, 4)
+    assert np.allclose([loss.item(), lc.item(), lo.item(), lco.item()], fx["loss"], atol=1e-4)
+    loss.backward()
+    assert m.conv_feat.bias.grad is None
+    for k, p in m.named_parameters():
+        g = fx[f"grad.{k}"]
+        if g.size == 0:
+            continue
+        assert np.allclose(p.grad.cpu().numpy(), g, atol=2e-4, rtol=2e-3), k
+    opt.step()
+    post = m.state_dict()
+    for k in post:
+        if f"post.{k}" in fx.files:
+            assert np.allclose(post[k].cpu().numpy(), fx[f"post.{k}"], atol=2e-4, rtol=1e-3), k
+
+
+@pytest.mark.parametrize("name", ["CausalGCN", "CausalGAT"])
+@pytest.mark.parametrize("cat_or_add", ["add", "cat"])
+def test_config2_shape_logits_within_1e4(name, cat_or_add):
+    """hidden=128, 3 layers, 32 SPMotif graphs (reference-generated fixtures), train + eval mode."""
+    ids = list(range(24)) + [0, 3, 5, 7, 9, 11, 13, 15]
+    b = ref_batch(ids)
+    torch.manual_seed(7)
+    sd = O.init_state(name, 10, 4, hidden=128, layers=3, heads=4, cat_or_add=cat_or_add)
+    args = _args(cat_or_add=cat_or_add)
+    m = _build(name, 10, 4, args, {k: v.clone() for k, v in sd.items()})
+    perm = torch.randperm(len(ids))
+    for training in (True, False):
+        sdc = {k: v.clone() for k, v in sd.items()}
+        ref = O.causal_forward(name, sdc, b.feat, b.edge_index, b.batch, perm=perm, training=training,
+                               cat_or_add=cat_or_add, gat_dropout=0.0)
+        m.load_state_dict(sd)
+        m.train(training)
+        if name == "CausalGAT":
+            for c in m.convs:
+                c.dropout = 0.0
+        with torch.no_grad():
+            out = m(ref_batch(ids).to(DEV), eval_random=True, perm=perm)
+        for r, t in zip(ref, out):
+            assert (r - t.cpu()).abs().max().item() < LOGIT_TOL
+        if training:    # BN running statistics updated like torch's
+            post = m.state_dict()
+            for k in ("bn_feat.running_mean", "bnc.running_var", "fc2_bn_co.running_mean"):
+                assert torch.allclose(post[k].cpu(), sdc[k], atol=1e-5, rtol=1e-4), k
+
+
+def test_gat_training_dropout_matches_oracle_with_same_mask():
+    from cal_amd import ops
+    from cal_amd.plan import plan_of
+    ids = [0, 4, 7, 10]
+    b = ref_batch(ids)
+    torch.manual_seed(3)
+    sd = O.init_state("CausalGAT", 10, 4, hidden=32, layers=2, heads=4)
+    m = _build("CausalGAT", 10, 4, _args(layers=2, hidden=32), {k: v.clone() for k, v in sd.items()})
+    m.train()
+    bd = ref_batch(ids).to(DEV)
+    plan = plan_of(bd)
+    masks = []
+    row, col = b.edge_index
+    keep_e = (row != col).nonzero().view(-1)
+    for i, c in enumerate(m.convs):
+        c.seed = 100 + i
+        full = ops.gat_dropout_mask(c.seed, plan, 4, 0.2).cpu()
+        masks.append(torch.cat([full[keep_e], full[plan.E:]], 0))
+    out = m(bd, eval_random=False)
+    ref = O.causal_forward("CausalGAT", sd, b.feat, b.edge_index, b.batch, training=True, layers=2,
+                           heads=4, gat_dropout=0.2, gat_masks=masks)
+    for r, t in zip(ref, out):
+        assert (r - t.detach().cpu()).abs().max().item() < LOGIT_TOL
+
+
+def test_ablation_flags_and_random_perm_path():
+    b = ref_batch([0, 4, 7, 10, 13])
+    torch.manual_seed(1)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=32, layers=2)
+    args = _args(layers=2, hidden=32, without_node_attention=True, without_edge_attention=True)
+    m = _build("CausalGCN", 10, 4, args, {k: v.clone() for k, v in sd.items()})
+    m.eval()
+    random.seed(5)
+    with torch.no_grad():
+        out = m(ref_batch([0, 4, 7, 10, 13]).to(DEV), eval_random=True)
+    random.seed(5)
+    perm = torch.tensor(O.intervention_perm(5, True, True, "CausalGCN"))
+    ref = O.causal_forward("CausalGCN", sd, b.feat, b.edge_index, b.batch, perm=perm, training=False,
+                           layers=2, without_node_attention=True, without_edge_attention=True)
+    for r, t in zip(ref, out):
+        assert (r - t.cpu()).abs().max().item() < LOGIT_TOL
