@@ -1,0 +1,243 @@
+#!/usr/bin/env python
+"""bench.py -- graphs/sec of the CAL causal train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" = forward (3 heads) + 0.5*KL + 1.0*NLL + 0.5*NLL + backward + Adam
+(train_causal.py:173-192) on one pre-collated, HBM-resident mini-batch of
+synthetic SPMotif graphs (BASELINE.json configs[1]: CausalGCN, b=0.9, 3 layers,
+hidden 128, batch 128, node_num 7 -> ~57 nodes / graph).  Batches shard across
+ranks (independent mini-batches per GPU, weak scaling) with one RCCL all-reduce
+of the flat gradient bucket per step.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (model, node_num, hidden, layers, batch, num_features, num_classes)
+    "spmotif_b0.9_causalgcn_h128_l3_bs128": dict(model="CausalGCN", node_num=7, hidden=128, layers=3, batch=128),
+    "spmotif_b0.9_causalgat_h128_l3_bs128": dict(model="CausalGAT", node_num=7, hidden=128, layers=3, batch=128),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="spmotif_b0.9_causalgcn_h128_l3_bs128", choices=list(WORKLOADS))
+    ap.add_argument("--mode", default="graph", choices=["graph", "eager"])
+    ap.add_argument("--batches", type=int, default=8, help="distinct resident mini-batches per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def model_args(wl):
+    return argparse.Namespace(layers=wl["layers"], hidden=wl["hidden"], with_random=True,
+                              without_node_attention=False, without_edge_attention=False,
+                              fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
+
+
+def make_batches(wl, nb, seed):
+    from cal_amd import spmotif
+    from cal_amd.data import Batch
+    gs = spmotif.train_mix(nb * wl["batch"], bias=0.9, node_num=wl["node_num"], seed=seed)
+    return [Batch.from_data_list(gs[i * wl["batch"]:(i + 1) * wl["batch"]]) for i in range(nb)]
+
+
+def cpu_baseline(wl, batches_cpu, seconds):
+    """Restated reference CPU path (oracle/cal_oracle.py, kind 'port') on this host's cores."""
+    from oracle import cal_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(666)
+    sd = O.init_state(wl["model"], 10, 4, hidden=wl["hidden"], layers=wl["layers"], heads=4)
+    tr = O.CpuTrainer(wl["model"], sd, 4, lr=1e-3, layers=wl["layers"], heads=4)
+    nb = len(batches_cpu)
+
+    def one(i):
+        b = batches_cpu[i % nb]
+        perm = torch.tensor(O.intervention_perm(b.num_graphs, True, True, wl["model"]))
+        tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+        return b.num_graphs
+
+    for i in range(3):
+        one(i)
+    t0 = time.perf_counter()
+    n, steps = 0, 0
+    while time.perf_counter() - t0 < seconds or steps < 5:
+        n += one(steps)
+        steps += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="graphs/s", cores=cores, kind="port",
+                sample="%d train steps of batch %d (same synthetic SPMotif batches, %.1f s) through "
+                       "oracle/cal_oracle.py (unfused restatement of the PyG path), torch %d threads"
+                       % (steps, wl["batch"], dt, torch.get_num_threads()),
+                ms_per_step=1e3 * dt / steps)
+
+
+def spmm_roofline(trainer, batches, wl, iters=20):
+    """Live HIP-event timing of the dominant graph kernel (k_spmm, the CSR aggregation of
+    gcn_conv.py:92-104) as launched inside the step: an eager replica of the step is run with an
+    event pair around every cal_spmm_fwd launch on the launch stream."""
+    from cal_amd import _lib
+    events = []
+    orig = _lib.call
+
+    def timed(name, *a):
+        if name == "cal_spmm_fwd":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(name, *a)
+            e1.record()
+            events.append((e0, e1, a[10], a[11]))      # N, H
+        else:
+            orig(name, *a)
+
+    import cal_amd.ops as ops_mod
+    import cal_amd.plan as plan_mod
+    ops_mod._lib.call = timed
+    try:
+        algo = []
+        for i in range(iters):
+            b = batches[i % len(batches)]
+            perm = torch.arange(b.num_graphs, device="cuda")
+            n_before = len(events)
+            trainer._fwd_bwd(b, perm, trainer.stats)
+            E_nsl = int((b.edge_index[0] != b.edge_index[1]).sum().item())
+            for (_, _, N, H) in events[n_before:]:
+                algo.append(2 * N * H * 4 + (E_nsl + N) * 8 + (N + 1) * 4)
+        torch.cuda.synchronize()
+    finally:
+        ops_mod._lib.call = orig
+    durs = np.array([e0.elapsed_time(e1) * 1e-3 for e0, e1, _, _ in events])   # seconds
+    algo = np.array(algo, dtype=np.float64)
+    # drop the first step's launches (cold instruction cache)
+    k = len(events) // iters
+    durs, algo = durs[k:], algo[k:]
+    avg_dur = float(durs.mean())
+    achieved = float(algo.mean() / avg_dur / 1e9)
+    peak = 8000.0
+    return dict(bound="hbm", kernel="k_spmm (cal_spmm_fwd)", achieved=achieved, peak=peak, unit="GB/s",
+                frac=achieved / peak, traffic=None, avg_launch_us=avg_dur * 1e6,
+                algorithmic_bytes_per_launch=float(algo.mean()), launches_per_step=k,
+                note="event pairs include ~launch gap; working set is cache-resident at this config "
+                     "(launch/latency-bound by construction, SURVEY.md 8d)")
+
+
+def main():
+    a = parse()
+    wl = WORKLOADS[a.workload]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from cal_amd import _lib
+    from cal_amd import model as M
+    from cal_amd.trainer import CausalTrainer
+    _lib.lib()      # fail loudly if the HIP extension is missing
+
+    seed = 666
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed + rank)
+    margs = model_args(wl)
+    model = getattr(M, wl["model"])(10, 4, margs).cuda()
+    if world > 1:   # identical replicas
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+        for bname, buf in model.named_buffers():
+            if buf.dtype.is_floating_point:
+                dist.broadcast(buf, 0)
+    batches_cpu = make_batches(wl, a.batches, seed=seed + 1000 * rank)
+    batches = [b.to("cuda") for b in make_batches(wl, a.batches, seed=seed + 1000 * rank)]
+    mode = a.mode
+    trainer = CausalTrainer(model, margs, lr=1e-3, use_graph=(mode == "graph"), world_size=world)
+    if mode == "graph":
+        try:
+            for b in batches:
+                trainer.prepare(b)
+        except Exception as exc:   # capture unsupported -> measured eagerly, and said so
+            sys.stderr.write("graph capture failed (%r); falling back to eager launches\n" % (exc,))
+            mode = "eager"
+            model = getattr(M, wl["model"])(10, 4, margs).cuda()
+            trainer = CausalTrainer(model, margs, lr=1e-3, use_graph=False, world_size=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    nb = len(batches)
+    for i in range(a.warmup):
+        trainer.step(batches[i % nb])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        stats = trainer.step(batches[i % nb])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final = stats.tolist()
+    graphs = wl["batch"] * a.steps * world
+    nodes = float(np.mean([b.batch.numel() for b in batches]))
+    edges = float(np.mean([b.edge_index.size(1) for b in batches]))
+
+    out = {
+        "metric": "graphs/sec (train step) on SPMotif b=0.9 batch=128",
+        "value": graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": a.workload, "model": wl["model"], "batch_per_gpu": wl["batch"],
+                   "global_batch": wl["batch"] * world, "hidden": wl["hidden"], "layers": wl["layers"],
+                   "node_num": wl["node_num"], "mean_nodes_per_batch": nodes, "mean_edges_per_batch": edges,
+                   "launch": mode, "parallelism": "dp%d" % world, "resident_batches": nb,
+                   "final_loss": final[0]},
+    }
+    if rank == 0 and world == 1:
+        if not a.no_roofline:
+            try:
+                out["roofline"] = spmm_roofline(trainer, batches, wl)
+            except Exception as exc:
+                out["roofline"] = {"error": repr(exc)}
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, batches_cpu, a.cpu_seconds)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,12 @@ __global__ void k_plan_sort(const int* __restrict__ ptr_dst, int* __restrict__ n
     }
 }
 
+__global__ void k_zero_i32(int* __restrict__ a, int64_t n, int* __restrict__ b) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = 0;
+    if (i == 0 && b) *b = 0;
+}
+
 // gptr[b] = first node index whose graph id is >= b; batch must be sorted.
 __global__ void k_graph_ptr(const int64_t* __restrict__ batch, int N, int B, int* __restrict__ gptr,
                             int* __restrict__ status) {
@@ -149,11 +155,11 @@ CAL_EXPORT int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
     int* cnt_src = work + (n + 1);
     int* cur_dst = work + 2 * (n + 1);
     int* cur_src = work + 3 * (n + 1);
-    if (hipMemsetAsync(work, 0, sizeof(int) * 4 * (size_t)(n + 1), stream) != hipSuccess ||
-        hipMemsetAsync(status, 0, sizeof(int), stream) != hipSuccess) {
-        set_error("cal_plan_build: memset failed");
-        return 1;
-    }
+    // a kernel, not hipMemsetAsync: memset nodes inside several captured hipGraphs faulted on replay
+    // (ROCm 7.2), and one launch is cheaper than two memset nodes anyway
+    hipLaunchKernelGGL(k_zero_i32, dim3(cdiv(4 * (int64_t)(n + 1), 256)), dim3(256), 0, stream, work,
+                       4 * (int64_t)(n + 1), status);
+    CAL_CHECK_LAUNCH("k_zero_i32");
     if (E > 0) {
         hipLaunchKernelGGL(k_plan_count, dim3(cdiv(E, 256)), dim3(256), 0, stream, edge_index, E, n,
                            cnt_dst, cnt_src, row32, col32, status);

@@ -1,0 +1,90 @@
+"""world_size-2 gloo test of the data-parallel exchange: flat
+gradient bucket, one all-reduce, mean over replicas, parameters that never receive a
+gradient (conv_feat.bias) tolerated, disjoint loader shards."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(6, 5)
+        self.unused = torch.nn.Parameter(torch.zeros(3))     # like conv_feat.bias: grad stays None
+        self.b = torch.nn.Linear(5, 2)
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(x)))
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cal_amd.trainer import flatten_parameters
+    torch.manual_seed(0)
+    net = _Net()
+    flat_p, flat_g = flatten_parameters(net)
+    torch.manual_seed(100 + rank)
+    x = torch.randn(7, 6)
+    flat_g.zero_()
+    net(x).pow(2).sum().backward()
+    assert net.unused.grad is not None and torch.all(net.unused.grad == 0)
+    assert net.a.weight.grad.untyped_storage().data_ptr() == flat_g.untyped_storage().data_ptr()  # views of the bucket
+    dist.all_reduce(flat_g)
+    flat_g.mul_(1.0 / world)
+    opt = torch.optim.Adam([flat_p], lr=1e-2)
+    flat_p.grad = flat_g
+    opt.step()
+    q.put((rank, flat_g.numpy().copy(), flat_p.detach().numpy().copy(), x.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, g0, p0, x0), (_, g1, p1, x1) = [(r, *map(torch.from_numpy, t)) for r, *t in res]
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)                # replicas stay identical
+    # single-process reference: mean of the two replica gradients
+    torch.manual_seed(0)
+    net = _Net()
+    ref = []
+    for x in (x0, x1):
+        net.zero_grad()
+        net(x).pow(2).sum().backward()
+        ref.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
+                              for p in net.parameters()]))
+    assert torch.allclose(g0, (ref[0] + ref[1]) / 2, atol=1e-6)
+
+
+def test_loader_shards_are_disjoint_and_cover():
+    from cal_amd.data import DataLoader
+    from tests.helpers import ref_graphs
+    gs = ref_graphs()
+    shards = []
+    for r in range(2):
+        dl = DataLoader(gs, 4, shuffle=True, rank=r, world_size=2, generator=torch.Generator().manual_seed(9))
+        shards.append(dl._indices())
+        assert sum(b.num_graphs for b in dl) == len(shards[-1])
+    assert not set(shards[0]) & set(shards[1])
+    assert sorted(shards[0] + shards[1]) == list(range(len(gs)))
