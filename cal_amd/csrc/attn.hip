@@ -107,13 +107,13 @@ __global__ void __launch_bounds__(256) k_edge_att_bwd_x(const float* __restrict_
 }
 
 // dW [2, 2H], db [2] from the partials
-__global__ void k_edge_att_bwd_finish(const float* __restrict__ part, int nparts, int H,
-                                      float* __restrict__ dW, float* __restrict__ db) {
+__global__ void __launch_bounds__(256) k_edge_att_bwd_finish(const float* __restrict__ part, int nparts, int H,
+                                                             float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float red[256];
     const int P = 2 * H + 4;
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > 2 * H) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * P + c];
+    int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    float s = finish_colsum(part, nparts, P, c, c <= 2 * H, red);
+    if ((threadIdx.x >> 4) != 0 || c > 2 * H) return;
     if (c < 2 * H) {
         dW[c] = s;
         dW[2 * H + c] = -s;
@@ -209,13 +209,13 @@ __global__ void __launch_bounds__(256) k_wcolsum1(const float* __restrict__ x, c
     }
 }
 
-__global__ void k_node_att_bwd_finish(const float* __restrict__ part, int nparts, int H,
-                                      float* __restrict__ dWn, float* __restrict__ dbn) {
+__global__ void __launch_bounds__(256) k_node_att_bwd_finish(const float* __restrict__ part, int nparts, int H,
+                                                             float* __restrict__ dWn, float* __restrict__ dbn) {
+    __shared__ float red[256];
     const int P = H + 4;
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > H) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * P + c];
+    int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    float s = finish_colsum(part, nparts, P, c, c <= H, red);
+    if ((threadIdx.x >> 4) != 0 || c > H) return;
     if (c < H) { dWn[c] = s; dWn[H + c] = -s; }
     else { dbn[0] = s; dbn[1] = -s; }
 }
@@ -264,8 +264,8 @@ __global__ void __launch_bounds__(256) k_add_pool_bwd(const float* __restrict__ 
 using namespace cal;
 
 static inline int rows_per_block_for(int64_t N) {
-    int64_t rpb = (N + 1023) / 1024;
-    return (int)(rpb < 16 ? 16 : rpb);
+    int64_t rpb = (N + 511) / 512;
+    return (int)(rpb < 32 ? 32 : rpb);
 }
 static inline int col_threads(int64_t H, bool vec) {
     int t = (int)(vec ? H / 4 : H);
@@ -330,7 +330,7 @@ CAL_EXPORT int cal_edge_att_bwd(const float* x, const float* W, const float* att
                                accumulate, part, (int)N, (int)H, rpb);
         CAL_CHECK_LAUNCH("k_edge_att_bwd_x");
     }
-    hipLaunchKernelGGL(k_edge_att_bwd_finish, dim3(cdiv(2 * H + 1, 256)), dim3(256), 0, stream, part, nb, (int)H, dW, db);
+    hipLaunchKernelGGL(k_edge_att_bwd_finish, dim3(cdiv(2 * H + 1, 16)), dim3(256), 0, stream, part, nb, (int)H, dW, db);
     CAL_CHECK_LAUNCH("k_edge_att_bwd_finish");
     return 0;
 }
@@ -375,7 +375,7 @@ CAL_EXPORT int cal_node_att_split_bwd(const float* x, const float* Wn, const flo
             hipLaunchKernelGGL((k_wcolsum1<1>), dim3(nb), dim3(col_threads(H, false)), 0, stream, x, dlv, part, (int)N, (int)H, rpb);
         CAL_CHECK_LAUNCH("k_wcolsum1");
     }
-    hipLaunchKernelGGL(k_node_att_bwd_finish, dim3(cdiv(H + 1, 256)), dim3(256), 0, stream, part, nb, (int)H, dWn, dbn);
+    hipLaunchKernelGGL(k_node_att_bwd_finish, dim3(cdiv(H + 1, 16)), dim3(256), 0, stream, part, nb, (int)H, dWn, dbn);
     CAL_CHECK_LAUNCH("k_node_att_bwd_finish");
     return 0;
 }

@@ -45,6 +45,32 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// Column-wise sum of `nparts` partial rows: out-of-line device helper used by every *_finish kernel.
+// Block = 256 threads = 16 columns x 16 part-lanes; lanes of a column reduce through LDS.
+// Returns the total for column c (valid on part-lane 0).
+__device__ __forceinline__ float finish_colsum(const float* __restrict__ part, int nparts, int stride, int c,
+                                               bool valid, float* red /* [256] */) {
+    const int pl = threadIdx.x >> 4;           // part lane 0..15
+    float s0 = 0.f, s1 = 0.f;
+    if (valid) {
+        int p = pl;
+        for (; p + 16 < nparts; p += 32) {
+            s0 += part[(size_t)p * stride + c];
+            s1 += part[(size_t)(p + 16) * stride + c];
+        }
+        if (p < nparts) s0 += part[(size_t)p * stride + c];
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    float t = 0.f;
+    if (pl == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k * 16 + (threadIdx.x & 15)];
+    }
+    __syncthreads();
+    return t;
+}
+
 // vector-of-VEC float load/store helpers (VEC = 1 or 4)
 template <int VEC> struct Vec;
 template <> struct Vec<4> {

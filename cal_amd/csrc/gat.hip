@@ -211,12 +211,12 @@ __global__ void __launch_bounds__(256) k_gat_datt_part(const float* __restrict__
     }
 }
 
-__global__ void k_gat_datt_finish(const float* __restrict__ part, int nparts, int n, float* __restrict__ datt) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + c];
-    datt[c] = s;
+__global__ void __launch_bounds__(256) k_gat_datt_finish(const float* __restrict__ part, int nparts, int n,
+                                                         float* __restrict__ datt) {
+    __shared__ float red[256];
+    int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    float s = finish_colsum(part, nparts, n, c, c < n, red);
+    if ((threadIdx.x >> 4) == 0 && c < n) datt[c] = s;
 }
 
 // keep mask (1/0) as floats, [E + N, K]: row e < E for original edge e, row E + i for node i's loop
@@ -232,8 +232,8 @@ using namespace cal;
 
 static inline bool pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int gat_rows_per_block(int64_t N) {
-    int64_t rpb = (N + 1023) / 1024;
-    return (int)(rpb < 16 ? 16 : rpb);
+    int64_t rpb = (N + 511) / 512;
+    return (int)(rpb < 32 ? 32 : rpb);
 }
 
 // z [N,K*D] (= x W), att [K,2D] (first D: target half, last D: source half), bias [K*D] or null.
@@ -299,7 +299,7 @@ CAL_EXPORT int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, co
         hipLaunchKernelGGL(k_gat_datt_part, dim3(nb), dim3(threads), 0, stream, z, dadst, dasrc, part, (int)N, (int)K, (int)D, rpb);
         CAL_CHECK_LAUNCH("k_gat_datt_part");
     }
-    hipLaunchKernelGGL(k_gat_datt_finish, dim3(cdiv(2 * H, 256)), dim3(256), 0, stream, part, nb, (int)(2 * H), datt);
+    hipLaunchKernelGGL(k_gat_datt_finish, dim3(cdiv(2 * H, 16)), dim3(256), 0, stream, part, nb, (int)(2 * H), datt);
     CAL_CHECK_LAUNCH("k_gat_datt_finish");
     return 0;
 }

@@ -108,13 +108,12 @@ __global__ void __launch_bounds__(256) k_relu_bwd_colsum(const float* __restrict
     }
 }
 
-__global__ void k_colsum_finish(const float* __restrict__ part, float* __restrict__ out, int nparts, int H,
-                                int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= H) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * H + c];
-    out[c] = accumulate ? out[c] + s : s;
+__global__ void __launch_bounds__(256) k_colsum_finish(const float* __restrict__ part, float* __restrict__ out,
+                                                       int nparts, int H, int accumulate) {
+    __shared__ float red[256];
+    int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    float s = finish_colsum(part, nparts, H, c, c < H, red);
+    if ((threadIdx.x >> 4) == 0 && c < H) out[c] = accumulate ? out[c] + s : s;
 }
 
 // gn_e[eid] = <dz[i,:], h[nbr,:]> for every by-destination slot of row i; gself[i] = <dz[i,:], h[i,:]>.
@@ -212,9 +211,9 @@ CAL_EXPORT int cal_spmm_fwd(const int32_t* rowptr, const int32_t* nbr, const int
 }
 
 static inline int colsum_rows_per_block(int64_t N) {
-    // <= 1024 partial rows so the finishing pass stays tiny; >= 16 rows of work per block
-    int64_t rpb = (N + 1023) / 1024;
-    return (int)(rpb < 16 ? 16 : rpb);
+    // <= 512 partial rows so the finishing pass stays tiny; >= 32 rows of work per block
+    int64_t rpb = (N + 511) / 512;
+    return (int)(rpb < 32 ? 32 : rpb);
 }
 
 // dz = dout * (y > 0) (y may be null: plain copy/skip), dbias[H] = column sums of dz.
@@ -239,7 +238,7 @@ CAL_EXPORT int cal_relu_bwd_colsum(const float* dout, const float* y, float* dz,
         CAL_CHECK_LAUNCH("k_relu_bwd_colsum");
     }
     if (dbias) {
-        hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(H, 256)), dim3(256), 0, stream, part, dbias, N > 0 ? nb : 0, (int)H, 0);
+        hipLaunchKernelGGL(k_colsum_finish, dim3(cdiv(H, 16)), dim3(256), 0, stream, part, dbias, N > 0 ? nb : 0, (int)H, 0);
         CAL_CHECK_LAUNCH("k_colsum_finish");
     }
     return 0;

@@ -92,28 +92,28 @@ __global__ void k_plan_fill(const int* __restrict__ row32, const int* __restrict
     nbr_s[q] = c; eid_s[q] = (int)e;
 }
 
-// One thread per (row, direction): insertion sort of the row's slots by edge id.
-__global__ void k_plan_sort(const int* __restrict__ ptr_dst, int* __restrict__ nbr_d, int* __restrict__ eid_d,
-                            const int* __restrict__ ptr_src, int* __restrict__ nbr_s, int* __restrict__ eid_s,
-                            int N) {
+// Stable placement without a sort: one thread per (direction, unordered slot p) counts how many
+// slots of the same row hold a smaller edge id and writes its entry at that rank.  O(sum deg^2)
+// comparisons, all parallel (a hub of degree d is shared by d threads).
+__global__ void k_plan_rank(const int* __restrict__ row32, const int* __restrict__ col32,
+                            const int* __restrict__ ptr_dst, const int* __restrict__ tn_d, const int* __restrict__ te_d,
+                            int* __restrict__ nbr_d, int* __restrict__ eid_d,
+                            const int* __restrict__ ptr_src, const int* __restrict__ tn_s, const int* __restrict__ te_s,
+                            int* __restrict__ nbr_s, int* __restrict__ eid_s, int N) {
+    const int nnz = ptr_dst[N];
     int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * N) return;
-    const int* ptr = t < N ? ptr_dst : ptr_src;
-    int* nbr = t < N ? nbr_d : nbr_s;
-    int* eid = t < N ? eid_d : eid_s;
-    int v = t < N ? t : t - N;
-    int s0 = ptr[v], s1 = ptr[v + 1];
-    for (int i = s0 + 1; i < s1; ++i) {
-        int ke = eid[i], kn = nbr[i];
-        int j = i - 1;
-        while (j >= s0 && eid[j] > ke) {
-            eid[j + 1] = eid[j];
-            nbr[j + 1] = nbr[j];
-            --j;
-        }
-        eid[j + 1] = ke;
-        nbr[j + 1] = kn;
-    }
+    if (t >= 2 * nnz) return;
+    const bool d = t < nnz;
+    const int p = d ? t : t - nnz;
+    const int* te = d ? te_d : te_s;
+    const int e = te[p];
+    const int v = d ? col32[e] : row32[e];
+    const int* ptr = d ? ptr_dst : ptr_src;
+    const int s0 = ptr[v], s1 = ptr[v + 1];
+    int rank = 0;
+    for (int q = s0; q < s1; ++q) rank += te[q] < e;
+    if (d) { nbr_d[s0 + rank] = tn_d[p]; eid_d[s0 + rank] = e; }
+    else { nbr_s[s0 + rank] = tn_s[p]; eid_s[s0 + rank] = e; }
 }
 
 __global__ void k_zero_i32(int* __restrict__ a, int64_t n, int* __restrict__ b) {
@@ -140,7 +140,7 @@ using namespace cal;
 CAL_EXPORT const char* cal_last_error() { return g_err; }
 CAL_EXPORT int cal_version() { return 100; }
 
-// Build both CSR views.  `work` must hold 4*(N+1) ints; `status` one int (bit0: edge index out of
+// Build both CSR views.  `work` must hold 4*(N+1) + 4*E ints; `status` one int (bit0: edge index out of
 // range, bit1: batch vector not sorted / out of range) -- zeroed here, read by the caller when it
 // chooses to validate.
 CAL_EXPORT int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
@@ -155,6 +155,10 @@ CAL_EXPORT int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
     int* cnt_src = work + (n + 1);
     int* cur_dst = work + 2 * (n + 1);
     int* cur_src = work + 3 * (n + 1);
+    int* tn_d = work + 4 * (n + 1);
+    int* te_d = tn_d + E;
+    int* tn_s = te_d + E;
+    int* te_s = tn_s + E;
     // a kernel, not hipMemsetAsync: memset nodes inside several captured hipGraphs faulted on replay
     // (ROCm 7.2), and one launch is cheaper than two memset nodes anyway
     hipLaunchKernelGGL(k_zero_i32, dim3(cdiv(4 * (int64_t)(n + 1), 256)), dim3(256), 0, stream, work,
@@ -169,13 +173,12 @@ CAL_EXPORT int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
     CAL_CHECK_LAUNCH("k_plan_scan");
     if (E > 0) {
         hipLaunchKernelGGL(k_plan_fill, dim3(cdiv(E, 256)), dim3(256), 0, stream, row32, col32, E,
-                           rowptr_dst, rowptr_src, cur_dst, cur_src, nbr_dst, eid_dst, nbr_src, eid_src);
+                           rowptr_dst, rowptr_src, cur_dst, cur_src, tn_d, te_d, tn_s, te_s);
         CAL_CHECK_LAUNCH("k_plan_fill");
-        if (n > 0) {
-            hipLaunchKernelGGL(k_plan_sort, dim3(cdiv(2 * (int64_t)n, 256)), dim3(256), 0, stream,
-                               rowptr_dst, nbr_dst, eid_dst, rowptr_src, nbr_src, eid_src, n);
-            CAL_CHECK_LAUNCH("k_plan_sort");
-        }
+        // grid sized for the upper bound 2E (self loops make nnz <= E); surplus threads exit
+        hipLaunchKernelGGL(k_plan_rank, dim3(cdiv(2 * E, 256)), dim3(256), 0, stream, row32, col32, rowptr_dst, tn_d,
+                           te_d, nbr_dst, eid_dst, rowptr_src, tn_s, te_s, nbr_src, eid_src, n);
+        CAL_CHECK_LAUNCH("k_plan_rank");
     }
     return 0;
 }

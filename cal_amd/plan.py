@@ -52,7 +52,7 @@ class GraphPlan:
             B = int(num_graphs) if num_graphs is not None else (int(batch.max().item()) + 1 if N else 0)
         self.B = B
         sizes = dict(rowptr_dst=N + 1, nbr_dst=E, eid_dst=E, rowptr_src=N + 1, nbr_src=E, eid_src=E,
-                     row32=E, col32=E, work=4 * (N + 1), status=1, gptr=B + 1)
+                     row32=E, col32=E, work=4 * (N + 1) + 4 * E, status=1, gptr=B + 1)
         total = sum(_al4(max(v, 1)) for v in sizes.values())
         self._ints = torch.empty(total, dtype=torch.int32, device=self.device)
         off = 0

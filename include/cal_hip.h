@@ -37,7 +37,7 @@ CAL_API int cal_version(void);
 /* ---- GraphPlan ---------------------------------------------------------------
  * COO -> CSR-by-destination and CSR-by-source with edge ids, explicit self loops
  * dropped (remove_self_loops, gcn_conv.py:56); the N loops add_self_loops
- * appends (gcn_conv.py:57-63) stay implicit.  work: 4*(N+1) int32.  status: 1
+ * appends (gcn_conv.py:57-63) stay implicit.  work: 4*(N+1) + 4*E int32.  status: 1
  * int32, bit0 = edge index out of range, bit1 = batch not sorted/out of range. */
 CAL_API int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
                            int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
@@ -70,6 +70,14 @@ CAL_API int cal_gcn_norm_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, 
                              const float* dis, float loop_w, const float* h, const float* dz,
                              float* gn_e, float* gself, float* ddeg, float* dw, int64_t N,
                              int64_t E, int64_t H, void* stream);
+
+/* ---- dense linear layers on the matrix cores (fp32 MFMA) ----------------------
+ * x @ W (gcn_conv.py:75), torch.nn.Linear (model.py:46-75) and their gradients.
+ * C[M,N] = op(A) op(B) (+bias[N]) (ReLU); transA: A stored [K,M]; transB: B stored [N,K]. */
+CAL_API int64_t cal_gemm_ws(int64_t M, int64_t N, int64_t K);
+CAL_API int cal_gemm(int transA, int transB, const float* A, const float* B, float* C,
+                     const float* bias, int relu, float* ws, int64_t M, int64_t N, int64_t K,
+                     void* stream);
 
 /* ---- causal / trivial soft masks (model.py:97-111) ------------------------- */
 CAL_API int cal_edge_att_fwd(const float* x, const float* W, const float* b, const int32_t* row32,
