@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-engine", action="store_true", help="operator-level autograd path instead of the native step engine")
     return ap.parse_args()
 
 
@@ -193,7 +194,9 @@ def main():
     batches_cpu = make_batches(wl, a.batches, seed=seed + 1000 * rank)
     batches = [b.to("cuda") for b in make_batches(wl, a.batches, seed=seed + 1000 * rank)]
     mode = a.mode
-    trainer = CausalTrainer(model, margs, lr=1e-3, use_graph=(mode == "graph"), world_size=world)
+    use_engine = False if a.no_engine else None
+    trainer = CausalTrainer(model, margs, lr=1e-3, use_graph=(mode == "graph"), world_size=world, use_engine=use_engine)
+    trainer.reserve_for(batches)
     if mode == "graph":
         try:
             for b in batches:
@@ -202,7 +205,8 @@ def main():
             sys.stderr.write("graph capture failed (%r); falling back to eager launches\n" % (exc,))
             mode = "eager"
             model = getattr(M, wl["model"])(10, 4, margs).cuda()
-            trainer = CausalTrainer(model, margs, lr=1e-3, use_graph=False, world_size=world)
+            trainer = CausalTrainer(model, margs, lr=1e-3, use_graph=False, world_size=world, use_engine=use_engine)
+            trainer.reserve_for(batches)
 
     def barrier():
         if world > 1:
@@ -235,11 +239,11 @@ def main():
         "config": {"workload": a.workload, "model": wl["model"], "batch_per_gpu": wl["batch"],
                    "global_batch": wl["batch"] * world, "hidden": wl["hidden"], "layers": wl["layers"],
                    "node_num": wl["node_num"], "mean_nodes_per_batch": nodes, "mean_edges_per_batch": edges,
-                   "launch": mode, "parallelism": "dp%d" % world, "resident_batches": nb,
+                   "launch": mode, "path": "native step engine" if trainer.engine is not None else "operator-level autograd", "parallelism": "dp%d" % world, "resident_batches": nb,
                    "final_loss": final[0]},
     }
     if rank == 0 and world == 1:
-        if not a.no_roofline:
+        if not a.no_roofline and trainer.engine is None:
             try:
                 out["roofline"] = spmm_roofline(trainer, batches, wl)
             except Exception as exc:

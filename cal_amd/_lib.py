@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libcalhip.so")
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
     "uint64_t": ctypes.c_uint64, "float": ctypes.c_float, "double": ctypes.c_double,
+    "void": None,
 }
 
 

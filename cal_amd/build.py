@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcalhip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-         "-Wall", "-Wno-unused-function", "-ffp-contract=on"]
+         "-Wall", "-Wno-unused-function", "-ffp-contract=on", "-munsafe-fp-atomics"]
 
 
 def _hipcc() -> str:

@@ -1,0 +1,705 @@
+// Native CausalGCN step engine: the whole training step of train_causal.py:173-192 on
+// model.py:85-164 -- forward (3 heads), 3-term loss, backward, Adam -- as ONE C call that enqueues
+// ~55 hand-written kernels on a stream (hipGraph-capturable: no allocation, no sync, no memset
+// nodes).  What is fused, relative to the op sequence of the reference:
+//   * every BatchNorm is folded into its consumer: batch statistics are accumulated (fp64) by the
+//     producer's epilogue, the normalised tensor is never written -- the consumer GEMM applies
+//     scale/shift (and the node-attention row scale) while staging its operand;
+//   * bias + ReLU (+ next-BN statistics) ride on the aggregation / GEMM epilogues;
+//   * xc = a0*x, xo = a1*x and the [E,2H] edge representation are never materialised;
+//   * the GCN normalisation is computed on the fly from deg^-1/2 (no per-layer norm(), no
+//     message tensor);
+//   * BatchNorm-backward column sums ride on the GEMM that produces the incoming gradient;
+//   * all parameter gradients that are column sums go through one fp64 arena and one commit
+//     kernel; split-K weight-gradient slabs are reduced deterministically in the same launch;
+//   * Adam is one fused kernel over the flat parameter buffer.
+#include <string.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "engine_kernels.hpp"
+
+namespace cal {
+
+constexpr int MAX_LAYERS = 6;
+constexpr int MAX_SLABS = 16;
+constexpr int MAX_COMMITS = 64;
+
+struct FinishArgs {
+    SlabTask st[MAX_SLABS];
+    CommitTask ct[MAX_COMMITS];
+    int nst, nct;
+};
+__global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, const double* __restrict__ arena,
+                                                float* __restrict__ grad) {
+    const int task = blockIdx.y;
+    if (task < fa.nst) {
+        const SlabTask t = fa.st[task];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n; i += gridDim.x * 256) {
+            float s0 = 0.f, s1 = 0.f;
+            int z = 0;
+            for (; z + 1 < t.S; z += 2) { s0 += t.slabs[(size_t)z * t.n + i]; s1 += t.slabs[(size_t)(z + 1) * t.n + i]; }
+            if (z < t.S) s0 += t.slabs[(size_t)z * t.n + i];
+            t.dst[i] = s0 + s1;
+        }
+    } else if (task - fa.nst < fa.nct) {
+        const CommitTask t = fa.ct[task - fa.nst];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n; i += gridDim.x * 256)
+            grad[t.dst + i] = t.scale * (float)arena[t.src + i];
+    }
+}
+
+struct BNSlot { int gamma, beta; int width; float* rm; float* rv; int64_t* nbt; int arena; };
+
+struct Engine {
+    int F, H, C, L;
+    float loop_w;
+    // bound buffers
+    float *P, *G, *M1, *M2, *step, *lr;
+    int64_t nparam;
+    float beta1, beta2, eps, wd;
+    // parameter offsets (floats into P / G)
+    int o_feat_w;
+    int o_conv_w[MAX_LAYERS], o_conv_b[MAX_LAYERS];
+    int o_eatt_w, o_eatt_b, o_natt_w, o_natt_b;
+    int o_cw, o_cb, o_ow, o_ob;
+    int o_fc1_w[3], o_fc1_b[3], o_fc2_w[3], o_fc2_b[3];
+    // BatchNorms: 0 bn_feat, 1..L bns_conv, L+1 bnc, L+2 bno, L+3+2h fc1_bn_h, L+4+2h fc2_bn_h
+    BNSlot bn[MAX_LAYERS + 9];
+    int nbn;
+    // arena offsets (doubles)
+    int a_convb[MAX_LAYERS], a_cb, a_ob, a_dwn, a_dwe, a_db1, a_db2, arena_n;
+    // workspace
+    char* ws; size_t ws_bytes;
+    int64_t capN, capE, capB;
+    // float regions
+    float *h, *z, *zco, *hco, *anode, *pq, *att, *dis_unit, *dis_co, *pooled, *xco, *y1, *zl, *logp, *stats;
+    float *dzl, *dyh1, *dy1, *dxh, *dpool, *dZco, *gn, *gself, *ddeg, *dl, *dzco, *dXhco, *dZ, *dzi, *dXh, *slabs;
+    size_t slab_floats;
+    double* arena;
+    int *rowptr_dst, *nbr_dst, *eid_dst, *rowptr_src, *nbr_src, *eid_src, *row32, *col32, *work, *status, *gptr, *iperm;
+};
+
+static size_t al(size_t n) { return (n + 63) / 64 * 64; }   // 256 B granules (in floats/ints)
+
+}  // namespace cal
+
+using namespace cal;
+
+extern "C" int cal_plan_build(const int64_t*, int64_t, int64_t, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*,
+                              int32_t*, int32_t*, int32_t*, int32_t*, void*);
+
+// cfg: [F, H, C, L].  Returns an opaque handle (0 on failure).
+CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
+    if (H % 4 != 0 || H > 256 || H < 4 || L < 0 || L > MAX_LAYERS || F < 1 || C < 1 || C > 64) {
+        set_error("cal_engine_create: unsupported shape (need hidden %% 4 == 0, hidden <= 256, layers <= %d, classes <= 64)", MAX_LAYERS);
+        return nullptr;
+    }
+    Engine* e = new Engine();
+    memset(e, 0, sizeof(Engine));
+    e->F = (int)F; e->H = (int)H; e->C = (int)C; e->L = (int)L;
+    e->loop_w = 1.f;
+    e->nbn = (int)L + 9;
+    return e;
+}
+
+CAL_EXPORT void cal_engine_destroy(void* h) { delete (Engine*)h; }
+
+CAL_EXPORT int64_t cal_engine_num_param_slots(void* h) { Engine* e = (Engine*)h; return 3 + 4 * e->L + 12 + 24; }
+CAL_EXPORT int64_t cal_engine_num_bn(void* h) { return ((Engine*)h)->nbn; }
+
+// Bind the flat parameter / gradient / Adam-state buffers.
+//   offs[slot]: float offset of every parameter inside P (and G, M1, M2), slots in the order
+//     bn_feat.{weight,bias}, conv_feat.weight,
+//     {bns_conv.i.weight, bns_conv.i.bias, convs.i.weight, convs.i.bias} for i < L,
+//     edge_att_mlp.{weight,bias}, node_att_mlp.{weight,bias}, bnc.{weight,bias}, bno.{weight,bias},
+//     context_convs.{weight,bias}, objects_convs.{weight,bias},
+//     {fc1_bn_h.weight, .bias, fc1_h.weight, .bias, fc2_bn_h.weight, .bias, fc2_h.weight, .bias} for h in (c, o, co)
+//   bn_ptrs[3*k + {0,1,2}]: running_mean / running_var / num_batches_tracked device addresses of
+//     BatchNorm k in the order bn_feat, bns_conv.*, bnc, bno, fc1_bn_c, fc2_bn_c, fc1_bn_o, fc2_bn_o,
+//     fc1_bn_co, fc2_bn_co.
+//   step, lr: device floats (Adam step counter, learning rate).
+CAL_EXPORT int cal_engine_bind(void* h, float* P, float* G, float* M1, float* M2, float* step, float* lr,
+                               int64_t nparam, const int64_t* offs, const int64_t* bn_ptrs, float beta1, float beta2,
+                               float eps, float weight_decay) {
+    Engine* e = (Engine*)h;
+    e->P = P; e->G = G; e->M1 = M1; e->M2 = M2; e->step = step; e->lr = lr; e->nparam = nparam;
+    e->beta1 = beta1; e->beta2 = beta2; e->eps = eps; e->wd = weight_decay;
+    const int L = e->L, H = e->H, F = e->F, C = e->C;
+    int s = 0;
+    int bn_g[MAX_LAYERS + 9], bn_b[MAX_LAYERS + 9], bn_w[MAX_LAYERS + 9];
+    int k = 0;
+    bn_g[k] = (int)offs[s++]; bn_b[k] = (int)offs[s++]; bn_w[k] = F; ++k;
+    e->o_feat_w = (int)offs[s++];
+    for (int i = 0; i < L; ++i) {
+        bn_g[k] = (int)offs[s++]; bn_b[k] = (int)offs[s++]; bn_w[k] = H; ++k;
+        e->o_conv_w[i] = (int)offs[s++]; e->o_conv_b[i] = (int)offs[s++];
+    }
+    e->o_eatt_w = (int)offs[s++]; e->o_eatt_b = (int)offs[s++];
+    e->o_natt_w = (int)offs[s++]; e->o_natt_b = (int)offs[s++];
+    bn_g[k] = (int)offs[s++]; bn_b[k] = (int)offs[s++]; bn_w[k] = H; ++k;   // bnc
+    bn_g[k] = (int)offs[s++]; bn_b[k] = (int)offs[s++]; bn_w[k] = H; ++k;   // bno
+    e->o_cw = (int)offs[s++]; e->o_cb = (int)offs[s++];
+    e->o_ow = (int)offs[s++]; e->o_ob = (int)offs[s++];
+    for (int hd = 0; hd < 3; ++hd) {
+        bn_g[k] = (int)offs[s++]; bn_b[k] = (int)offs[s++]; bn_w[k] = H; ++k;
+        e->o_fc1_w[hd] = (int)offs[s++]; e->o_fc1_b[hd] = (int)offs[s++];
+        bn_g[k] = (int)offs[s++]; bn_b[k] = (int)offs[s++]; bn_w[k] = H; ++k;
+        e->o_fc2_w[hd] = (int)offs[s++]; e->o_fc2_b[hd] = (int)offs[s++];
+    }
+    int a = 0;
+    for (int i = 0; i < e->nbn; ++i) {
+        BNSlot& b = e->bn[i];
+        b.gamma = bn_g[i]; b.beta = bn_b[i]; b.width = bn_w[i];
+        b.rm = (float*)bn_ptrs[3 * i]; b.rv = (float*)bn_ptrs[3 * i + 1]; b.nbt = (int64_t*)bn_ptrs[3 * i + 2];
+        b.arena = a;
+        a += 4 * ((b.width + 3) / 4 * 4);
+    }
+    for (int i = 0; i < L; ++i) { e->a_convb[i] = a; a += H; }
+    e->a_cb = a; a += H;
+    e->a_ob = a; a += H;
+    e->a_dwn = a; a += H + 4;
+    e->a_dwe = a; a += 2 * H + 4;
+    e->a_db1 = a; a += 3 * H;
+    e->a_db2 = a; a += (3 * C + 3) / 4 * 4;
+    e->arena_n = a;
+    (void)C;
+    return 0;
+}
+
+static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool assign) {
+    const size_t H = e->H, C = e->C, L = e->L, F = e->F;
+    size_t off = 0;   // in 4-byte units
+    auto F32 = [&](float*& p, size_t n) { if (assign) p = (float*)(e->ws) + off; off += al(n); };
+    auto I32 = [&](int*& p, size_t n) { if (assign) p = (int*)(e->ws) + off; off += al(n); };
+    F32(e->h, (L + 1) * N * H); F32(e->z, N * H); F32(e->zco, 2 * N * H); F32(e->hco, 2 * N * H);
+    F32(e->anode, 2 * N); F32(e->pq, 4 * N); F32(e->att, 2 * E); F32(e->dis_unit, N); F32(e->dis_co, 2 * N);
+    F32(e->pooled, 2 * B * H); F32(e->xco, B * H); F32(e->y1, 3 * B * H); F32(e->zl, 3 * B * C); F32(e->logp, 3 * B * C);
+    F32(e->stats, 8);
+    F32(e->dzl, 3 * B * C); F32(e->dyh1, 3 * B * H); F32(e->dy1, 3 * B * H); F32(e->dxh, 3 * B * H); F32(e->dpool, 2 * B * H);
+    F32(e->dZco, 2 * N * H); F32(e->gn, 2 * E); F32(e->gself, 2 * N); F32(e->ddeg, 2 * N); F32(e->dl, E);
+    F32(e->dzco, 2 * N * H); F32(e->dXhco, 2 * N * H); F32(e->dZ, N * H); F32(e->dzi, N * H); F32(e->dXh, N * H);
+    // split-K slabs: worst case per weight gradient (S <= 256, but S*tiles ~ 512 => S*M*N <= ~512*64*64 + M*N)
+    size_t slab = 0;
+    auto slab_of = [&](size_t M, size_t Nn) { return (size_t)(512 * 64 * 64 + 2 * M * Nn); };
+    slab += slab_of(F, H) + (L + 2) * slab_of(H, H) + 3 * slab_of(H, H) + 3 * slab_of(C, H);
+    if (assign) e->slab_floats = slab;
+    F32(e->slabs, slab);
+    {
+        float* tmp = nullptr;
+        F32(tmp, 2 * (size_t)e->arena_n);
+        if (assign) e->arena = (double*)tmp;
+    }
+    I32(e->rowptr_dst, N + 1); I32(e->nbr_dst, E); I32(e->eid_dst, E);
+    I32(e->rowptr_src, N + 1); I32(e->nbr_src, E); I32(e->eid_src, E);
+    I32(e->row32, E); I32(e->col32, E); I32(e->work, 4 * (N + 1) + 4 * E); I32(e->status, 4); I32(e->gptr, B + 1);
+    I32(e->iperm, B);
+    return off * 4;
+}
+
+CAL_EXPORT int64_t cal_engine_workspace_bytes(void* h, int64_t N, int64_t E, int64_t B) {
+    return (int64_t)engine_layout((Engine*)h, N, E, B, false) + 256;
+}
+
+CAL_EXPORT int cal_engine_set_workspace(void* h, void* ws, int64_t bytes, int64_t capN, int64_t capE, int64_t capB) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+    e->ws = (char*)ws;
+    e->capN = capN; e->capE = capE; e->capB = capB;
+    size_t need = engine_layout(e, capN, capE, capB, true);
+    CAL_REQUIRE((int64_t)need <= bytes, "workspace too small");
+    e->ws_bytes = bytes;
+    return 0;
+}
+
+// float offset (from the workspace base) of a named intermediate, for tests / debugging; -1 if unknown
+CAL_EXPORT int64_t cal_engine_buffer_offset(void* h, const char* name) {
+    Engine* e = (Engine*)h;
+    struct { const char* n; void* p; } tab[] = {
+        {"h", e->h}, {"z", e->z}, {"zco", e->zco}, {"hco", e->hco}, {"anode", e->anode}, {"pq", e->pq}, {"att", e->att},
+        {"dis_unit", e->dis_unit}, {"dis_co", e->dis_co}, {"pooled", e->pooled}, {"xco", e->xco}, {"y1", e->y1},
+        {"zl", e->zl}, {"logp", e->logp}, {"stats", e->stats}, {"dzl", e->dzl}, {"dyh1", e->dyh1}, {"dy1", e->dy1},
+        {"dxh", e->dxh}, {"dpool", e->dpool}, {"dZco", e->dZco}, {"gn", e->gn}, {"gself", e->gself}, {"ddeg", e->ddeg},
+        {"dl", e->dl}, {"dzco", e->dzco}, {"dXhco", e->dXhco}, {"dZ", e->dZ}, {"dzi", e->dzi}, {"dXh", e->dXh},
+        {"arena", e->arena}, {"gptr", e->gptr}, {"status", e->status},
+    };
+    for (auto& t : tab)
+        if (!strcmp(t.n, name)) return ((char*)t.p - e->ws) / 4;
+    return -1;
+}
+
+namespace {
+
+struct Ctx {
+    Engine* e;
+    hipStream_t st;
+    int N, B;
+    int64_t E;
+    int training;
+    int rpb_n, rpb_b;   // rows per block for node-level / graph-level row walkers
+};
+
+BNRef bnref(const Ctx& c, int k, int rows, int update) {
+    const Engine* e = c.e;
+    const BNSlot& b = e->bn[k];
+    BNRef r;
+    const int wp = (b.width + 3) / 4 * 4;
+    r.sum = e->arena + b.arena; r.sq = e->arena + b.arena + wp;
+    r.gamma = e->P + b.gamma; r.beta = e->P + b.beta;
+    r.inv_n = 1.0f / (float)rows; r.eps = 1e-5f;
+    r.run_mean = b.rm; r.run_var = b.rv; r.nbt = b.nbt;
+    r.unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
+    r.update = (update && c.training) ? 1 : 0;
+    r.use_running = c.training ? 0 : 1;
+    return r;
+}
+double* bn_stsum(const Ctx& c, int k) { return c.e->arena + c.e->bn[k].arena; }
+double* bn_stsq(const Ctx& c, int k) { return c.e->arena + c.e->bn[k].arena + (c.e->bn[k].width + 3) / 4 * 4; }
+double* bn_dsum(const Ctx& c, int k) { return c.e->arena + c.e->bn[k].arena + 2 * ((c.e->bn[k].width + 3) / 4 * 4); }
+double* bn_dprod(const Ctx& c, int k) { return c.e->arena + c.e->bn[k].arena + 3 * ((c.e->bn[k].width + 3) / 4 * 4); }
+
+GemmArgs gemm_args(int M, int N, int K, bool transA, bool transB, int relu) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.N = N; a.K = K;
+    a.lda = transA ? M : K; a.ldb = transB ? K : N; a.ldc = N;
+    a.relu = relu;
+    gemm_set_split(a, 1);
+    return a;
+}
+
+// pick G for H (VEC = 4): lanes per row
+template <typename F>
+int with_g(int H, F f) {
+    int g = group_for(H, 4);
+    if (g <= 8) return f(std::integral_constant<int, 8>());
+    if (g == 16) return f(std::integral_constant<int, 16>());
+    if (g == 32) return f(std::integral_constant<int, 32>());
+    return f(std::integral_constant<int, 64>());
+}
+
+int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// weight-gradient GEMM (TN) with split-K slabs when the reduction axis is long
+int grad_gemm(Ctx& c, GemmArgs& a, int nbatch, float** dst, FinishArgs& fa, size_t& slab_off) {
+    int S = splitk_for(a.M, a.N, a.K, nbatch);
+    gemm_set_split(a, S);
+    if (a.nsplit > 1) {
+        for (int b = 0; b < nbatch; ++b) {
+            size_t need = (size_t)a.nsplit * a.M * a.N;
+            if (slab_off + need > c.e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
+            a.p[b].C = c.e->slabs + slab_off;
+            fa.st[fa.nst++] = SlabTask{c.e->slabs + slab_off, dst[b], a.M * a.N, a.nsplit};
+            slab_off += need;
+        }
+    } else {
+        for (int b = 0; b < nbatch; ++b) a.p[b].C = dst[b];
+    }
+    return launch_gemm(true, false, a, nbatch, c.st);
+}
+
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int64_t* batch, const int64_t* y,
+                   const int64_t* perm, float wc, float wo, float wco, int want_grad) {
+    Engine* e = c.e;
+    const int N = c.N, B = c.B, H = e->H, F = e->F, C = e->C, L = e->L;
+    const int64_t E = c.E;
+    hipStream_t st = c.st;
+    const size_t NH = (size_t)N * H;
+    // 0. zero the fp64 arena (a kernel, not a memset node)
+    hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(e->arena_n, 256)), dim3(256), 0, st, e->arena, (int64_t)e->arena_n);
+    CAL_CHECK_LAUNCH("k_zero_f64");
+    // 1. GraphPlan
+    RC(cal_plan_build(edge_index, E, N, e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
+                      e->row32, e->col32, e->work, e->status, st));
+    hipLaunchKernelGGL(k_gptr_dis, dim3(cdiv(N + 1, 256)), dim3(256), 0, st, batch, N, B, e->gptr, e->rowptr_src, e->loop_w,
+                       e->dis_unit, e->status);
+    CAL_CHECK_LAUNCH("k_gptr_dis");
+    const CSR gd{e->rowptr_dst, e->nbr_dst, e->eid_dst}, gs{e->rowptr_src, e->nbr_src, e->eid_src};
+    (void)gs;
+    // 2. bn_feat statistics (model.py:90)
+    if (c.training) {
+        int tc = std::min(256, pow2ceil(F));
+        int rpb = std::max(64, cdiv(N, 512));
+        hipLaunchKernelGGL(k_colstats, dim3(cdiv(N, rpb)), dim3(256), 0, st, x0, N, F, tc, rpb, bn_stsum(c, 0), bn_stsq(c, 0));
+        CAL_CHECK_LAUNCH("k_colstats");
+    }
+    // 3. h0 = relu(BN(x0) @ W_feat)   (model.py:90-91, gcn_conv.py:75-77)
+    {
+        GemmArgs a = gemm_args(N, H, F, false, false, 1);
+        a.p[0].A = x0; a.p[0].B = e->P + e->o_feat_w; a.p[0].C = e->h;
+        a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 1);
+        if (c.training && L > 0) { a.p[0].st_sum = bn_stsum(c, 1); a.p[0].st_sq = bn_stsq(c, 1); }
+        RC(launch_gemm(false, false, a, 1, st));
+    }
+    // 4. backbone: h_i = relu(A_hat (BN_i(h_{i-1}) @ W_i) + b_i)   (model.py:93-95)
+    for (int i = 1; i <= L; ++i) {
+        GemmArgs a = gemm_args(N, H, H, false, false, 0);
+        a.p[0].A = e->h + (size_t)(i - 1) * NH; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->z;
+        a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 1);
+        RC(launch_gemm(false, false, a, 1, st));
+        SpmmBranch br{e->z, e->h + (size_t)i * NH, e->P + e->o_conv_b[i - 1], nullptr, e->dis_unit, nullptr, nullptr, nullptr};
+        if (c.training && i < L) { br.st_sum = bn_stsum(c, i + 1); br.st_sq = bn_stsq(c, i + 1); }
+        RC(with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, gd, br, br, 1, e->loop_w, N, H, c.rpb_n);
+            return 0;
+        }));
+        CAL_CHECK_LAUNCH("k_espmm");
+    }
+    const float* x = e->h + (size_t)L * NH;
+    // 5. node attention, edge projections, bnc/bno statistics (model.py:97-111)
+    RC(with_g(H, [&](auto g) {
+        constexpr int G = decltype(g)::value;
+        hipLaunchKernelGGL((k_node_att_fwd<4, G>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, x, e->P + e->o_natt_w,
+                           e->P + e->o_natt_b, e->P + e->o_eatt_w, e->anode, e->pq, bn_stsum(c, L + 1), bn_stsq(c, L + 1),
+                           bn_stsum(c, L + 2), bn_stsq(c, L + 2), N, H, c.rpb_n);
+        return 0;
+    }));
+    CAL_CHECK_LAUNCH("k_node_att_fwd");
+    // 6. edge softmax + weighted degrees (model.py:102-104, gcn_conv.py:63-68)
+    hipLaunchKernelGGL(k_edge_att_deg, dim3(cdiv(N, 32)), dim3(256), 0, st, gs, e->pq, e->P + e->o_eatt_b, e->att, e->dis_co,
+                       e->dis_co + N, e->loop_w, N, E);
+    CAL_CHECK_LAUNCH("k_edge_att_deg");
+    // 7. z_k = BN_k(a_k * x) @ W_k for k in (context, objects)   (model.py:112-113)
+    {
+        GemmArgs a = gemm_args(N, H, H, false, false, 0);
+        for (int k = 0; k < 2; ++k) {
+            a.p[k].A = x; a.p[k].B = e->P + (k ? e->o_ow : e->o_cw); a.p[k].C = e->zco + (size_t)k * NH;
+            a.p[k].xa.rs = e->anode + k; a.p[k].xa.rs_stride = 2;
+            a.p[k].xa.has_bn = 1; a.p[k].xa.bn = bnref(c, L + 1 + k, N, 1);
+        }
+        RC(launch_gemm(false, false, a, 2, st));
+    }
+    // 8. h_k = relu(A_hat_k z_k + b_k)
+    {
+        SpmmBranch b0{e->zco, e->hco, e->P + e->o_cb, e->att, e->dis_co, nullptr, nullptr, nullptr};
+        SpmmBranch b1{e->zco + NH, e->hco + NH, e->P + e->o_ob, e->att + E, e->dis_co + N, nullptr, nullptr, nullptr};
+        RC(with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, gd, b0, b1, 1, e->loop_w, N, H, c.rpb_n);
+            return 0;
+        }));
+        CAL_CHECK_LAUNCH("k_espmm(co)");
+    }
+    // 9. add-pool (model.py:115-116)
+    {
+        int tc = std::min(256, pow2ceil(H / 4));
+        hipLaunchKernelGGL((k_pool2<4>), dim3(B, 2), dim3(256), 0, st, e->hco, e->hco + NH, e->gptr, e->pooled,
+                           e->pooled + (size_t)B * H, H, tc);
+        CAL_CHECK_LAUNCH("k_pool2");
+    }
+    // 10. readouts (model.py:125-164)
+    const int bn_fc1 = L + 3, bn_fc2 = L + 4;   // + 2*head
+    {
+        int tc = std::min(256, pow2ceil(H));
+        hipLaunchKernelGGL(k_readout_prep, dim3(cdiv(B, c.rpb_b)), dim3(256), 0, st, e->pooled, perm, e->iperm, e->xco, B, H, tc,
+                           c.rpb_b, bn_stsum(c, bn_fc1), bn_stsq(c, bn_fc1), bn_stsum(c, bn_fc1 + 2), bn_stsq(c, bn_fc1 + 2),
+                           bn_stsum(c, bn_fc1 + 4), bn_stsq(c, bn_fc1 + 4));
+        CAL_CHECK_LAUNCH("k_readout_prep");
+    }
+    const float* xin[3] = {e->pooled, e->pooled + (size_t)B * H, e->xco};
+    {
+        GemmArgs a = gemm_args(B, H, H, false, true, 1);
+        for (int hd = 0; hd < 3; ++hd) {
+            a.p[hd].A = xin[hd]; a.p[hd].B = e->P + e->o_fc1_w[hd]; a.p[hd].bias = e->P + e->o_fc1_b[hd];
+            a.p[hd].C = e->y1 + (size_t)hd * B * H;
+            a.p[hd].xa.has_bn = 1; a.p[hd].xa.bn = bnref(c, bn_fc1 + 2 * hd, B, 1);
+            if (c.training) { a.p[hd].st_sum = bn_stsum(c, bn_fc2 + 2 * hd); a.p[hd].st_sq = bn_stsq(c, bn_fc2 + 2 * hd); }
+        }
+        RC(launch_gemm(false, true, a, 3, st));
+    }
+    {
+        GemmArgs a = gemm_args(B, C, H, false, true, 0);
+        for (int hd = 0; hd < 3; ++hd) {
+            a.p[hd].A = e->y1 + (size_t)hd * B * H; a.p[hd].B = e->P + e->o_fc2_w[hd]; a.p[hd].bias = e->P + e->o_fc2_b[hd];
+            a.p[hd].C = e->zl + (size_t)hd * B * C;
+            a.p[hd].xa.has_bn = 1; a.p[hd].xa.bn = bnref(c, bn_fc2 + 2 * hd, B, 1);
+        }
+        RC(launch_gemm(false, true, a, 3, st));
+    }
+    hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, st, e->zl, y, e->logp, e->dzl, e->stats, e->arena + e->a_db2, B, C, wc, wo,
+                       wco, want_grad);
+    CAL_CHECK_LAUNCH("k_loss");
+    return 0;
+}
+
+int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
+    Engine* e = c.e;
+    const int N = c.N, B = c.B, H = e->H, F = e->F, C = e->C, L = e->L;
+    const int64_t E = c.E;
+    hipStream_t st = c.st;
+    const size_t NH = (size_t)N * H, BH = (size_t)B * H;
+    const CSR gd{e->rowptr_dst, e->nbr_dst, e->eid_dst}, gs{e->rowptr_src, e->nbr_src, e->eid_src};
+    const int bn_fc1 = L + 3, bn_fc2 = L + 4;
+    const float* xin[3] = {e->pooled, e->pooled + BH, e->xco};
+    FinishArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    size_t slab_off = 0;
+    auto commit = [&](int src, int dst, int n, float scale) { fa.ct[fa.nct++] = CommitTask{src, dst, n, scale}; };
+
+    // R1. dW2_h = dz_h^T @ BN2(y1_h)
+    {
+        GemmArgs a = gemm_args(C, H, B, true, false, 0);
+        float* dst[3];
+        for (int hd = 0; hd < 3; ++hd) {
+            a.p[hd].A = e->dzl + (size_t)hd * B * C; a.p[hd].B = e->y1 + hd * BH;
+            a.p[hd].xb.has_bn = 1; a.p[hd].xb.bn = bnref(c, bn_fc2 + 2 * hd, B, 0);
+            dst[hd] = e->G + e->o_fc2_w[hd];
+        }
+        RC(grad_gemm(c, a, 3, dst, fa, slab_off));
+    }
+    // R2. d(BN2 out)_h = dz_h @ W2_h, with the BN2-backward sums
+    {
+        GemmArgs a = gemm_args(B, H, C, false, false, 0);
+        for (int hd = 0; hd < 3; ++hd) {
+            a.p[hd].A = e->dzl + (size_t)hd * B * C; a.p[hd].B = e->P + e->o_fc2_w[hd]; a.p[hd].C = e->dyh1 + hd * BH;
+            a.p[hd].aux = e->y1 + hd * BH; a.p[hd].has_aux = 1; a.p[hd].aux_bn = bnref(c, bn_fc2 + 2 * hd, B, 0);
+            a.p[hd].dot_sum = bn_dsum(c, bn_fc2 + 2 * hd); a.p[hd].dot_prod = bn_dprod(c, bn_fc2 + 2 * hd);
+        }
+        RC(launch_gemm(false, false, a, 3, st));
+    }
+    // R3. BN2 backward + ReLU mask + fc1 bias gradients
+    {
+        BnBwdProb p[3];
+        for (int hd = 0; hd < 3; ++hd)
+            p[hd] = BnBwdProb{e->dyh1 + hd * BH, e->y1 + hd * BH, e->dy1 + hd * BH, bnref(c, bn_fc2 + 2 * hd, B, 0),
+                              bn_dsum(c, bn_fc2 + 2 * hd), bn_dprod(c, bn_fc2 + 2 * hd), e->arena + e->a_db1 + hd * H};
+        RC(with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(B, c.rpb_b), 3), dim3(256), 0, st, p[0], p[1], p[2], 1, B, H, c.rpb_b);
+            return 0;
+        }));
+        CAL_CHECK_LAUNCH("k_bn_bwd(readout)");
+    }
+    // R4. dW1_h = dy1_h^T @ BN1(xin_h)
+    {
+        GemmArgs a = gemm_args(H, H, B, true, false, 0);
+        float* dst[3];
+        for (int hd = 0; hd < 3; ++hd) {
+            a.p[hd].A = e->dy1 + hd * BH; a.p[hd].B = xin[hd];
+            a.p[hd].xb.has_bn = 1; a.p[hd].xb.bn = bnref(c, bn_fc1 + 2 * hd, B, 0);
+            dst[hd] = e->G + e->o_fc1_w[hd];
+        }
+        RC(grad_gemm(c, a, 3, dst, fa, slab_off));
+    }
+    // R5. d(BN1 out)_h = dy1_h @ W1_h with the BN1-backward sums
+    {
+        GemmArgs a = gemm_args(B, H, H, false, false, 0);
+        for (int hd = 0; hd < 3; ++hd) {
+            a.p[hd].A = e->dy1 + hd * BH; a.p[hd].B = e->P + e->o_fc1_w[hd]; a.p[hd].C = e->dxh + hd * BH;
+            a.p[hd].aux = xin[hd]; a.p[hd].has_aux = 1; a.p[hd].aux_bn = bnref(c, bn_fc1 + 2 * hd, B, 0);
+            a.p[hd].dot_sum = bn_dsum(c, bn_fc1 + 2 * hd); a.p[hd].dot_prod = bn_dprod(c, bn_fc1 + 2 * hd);
+        }
+        RC(launch_gemm(false, false, a, 3, st));
+    }
+    // R6. BN1 backward + un-permute the random intervention -> d pooled
+    {
+        BnIn in[3];
+        for (int hd = 0; hd < 3; ++hd)
+            in[hd] = BnIn{e->dxh + hd * BH, xin[hd], bnref(c, bn_fc1 + 2 * hd, B, 0), bn_dsum(c, bn_fc1 + 2 * hd), bn_dprod(c, bn_fc1 + 2 * hd)};
+        hipLaunchKernelGGL(k_readout_bwd_tail, dim3(cdiv((int64_t)BH, 256)), dim3(256), 0, st, in[0], in[1], in[2], e->iperm, e->dpool, B, H);
+        CAL_CHECK_LAUNCH("k_readout_bwd_tail");
+    }
+    // P1. add-pool backward + ReLU of the causal/trivial convs + their bias gradients
+    RC(with_g(H, [&](auto g) {
+        constexpr int G = decltype(g)::value;
+        hipLaunchKernelGGL((k_pool_bwd_relu<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, e->dpool, batch, e->hco, e->hco + NH,
+                           e->dZco, e->dZco + NH, e->arena + e->a_cb, e->arena + e->a_ob, N, B, H, c.rpb_n);
+        return 0;
+    }));
+    CAL_CHECK_LAUNCH("k_pool_bwd_relu");
+    // P2-P4. gradient w.r.t. the edge weights through propagate and through the normalisation
+    RC(with_g(H, [&](auto g) {
+        constexpr int G = decltype(g)::value;
+        hipLaunchKernelGGL((k_sddmm2<4, G>), dim3(cdiv(N, 256 / G), 2), dim3(256), 0, st, gd, e->dZco, e->dZco + NH, e->zco,
+                           e->zco + NH, e->gn, e->gself, N, E, H);
+        return 0;
+    }));
+    CAL_CHECK_LAUNCH("k_sddmm2");
+    hipLaunchKernelGGL(k_normbwd_node2, dim3(cdiv(N, 32), 2), dim3(256), 0, st, gs, gd, e->att, e->dis_co, e->gn, e->gself, e->ddeg,
+                       e->loop_w, N, E);
+    CAL_CHECK_LAUNCH("k_normbwd_node2");
+    if (E > 0) {
+        hipLaunchKernelGGL(k_normbwd_edge, dim3(cdiv(E, 256)), dim3(256), 0, st, e->row32, e->col32, e->att, e->dis_co, e->gn, e->ddeg,
+                           e->dl, N, E);
+        CAL_CHECK_LAUNCH("k_normbwd_edge");
+    }
+    // P5. dz_k = A_hat_k^T dZ_k
+    {
+        SpmmBranch b0{e->dZco, e->dzco, nullptr, e->att, e->dis_co, nullptr, nullptr, nullptr};
+        SpmmBranch b1{e->dZco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, nullptr, nullptr, nullptr};
+        RC(with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, gs, b0, b1, 0, e->loop_w, N, H, c.rpb_n);
+            return 0;
+        }));
+        CAL_CHECK_LAUNCH("k_espmm(co,T)");
+    }
+    const float* x = e->h + (size_t)L * NH;
+    // P6. dW_k = BN_k(a_k x)^T @ dz_k
+    {
+        GemmArgs a = gemm_args(H, H, N, true, false, 0);
+        float* dst[2];
+        for (int k = 0; k < 2; ++k) {
+            a.p[k].A = x; a.p[k].B = e->dzco + (size_t)k * NH;
+            a.p[k].xa.rs = e->anode + k; a.p[k].xa.rs_stride = 2;
+            a.p[k].xa.has_bn = 1; a.p[k].xa.bn = bnref(c, L + 1 + k, N, 0);
+            dst[k] = e->G + (k ? e->o_ow : e->o_cw);
+        }
+        RC(grad_gemm(c, a, 2, dst, fa, slab_off));
+    }
+    // P7. d(BN_k out) = dz_k @ W_k^T with the BN_k-backward sums
+    {
+        GemmArgs a = gemm_args(N, H, H, false, true, 0);
+        for (int k = 0; k < 2; ++k) {
+            a.p[k].A = e->dzco + (size_t)k * NH; a.p[k].B = e->P + (k ? e->o_ow : e->o_cw); a.p[k].C = e->dXhco + (size_t)k * NH;
+            a.p[k].aux = x; a.p[k].aux_rs = e->anode + k; a.p[k].aux_rs_stride = 2; a.p[k].has_aux = 1;
+            a.p[k].aux_bn = bnref(c, L + 1 + k, N, 0);
+            a.p[k].dot_sum = bn_dsum(c, L + 1 + k); a.p[k].dot_prod = bn_dprod(c, L + 1 + k);
+        }
+        RC(launch_gemm(false, true, a, 2, st));
+    }
+    // P8. everything between the last backbone conv and the two causal convs
+    {
+        AttBwdArgs aa;
+        aa.x = x; aa.anode = e->anode; aa.dxhc = e->dXhco; aa.dxho = e->dXhco + NH;
+        aa.bnc = bnref(c, L + 1, N, 0); aa.bno = bnref(c, L + 2, N, 0);
+        aa.dsc = bn_dsum(c, L + 1); aa.dpc = bn_dprod(c, L + 1); aa.dso = bn_dsum(c, L + 2); aa.dpo = bn_dprod(c, L + 2);
+        aa.Wn = e->P + e->o_natt_w; aa.We = e->P + e->o_eatt_w; aa.dl = e->dl;
+        aa.gs = gs; aa.gd = gd; aa.dZ = e->dZ;
+        aa.dbias = L > 0 ? e->arena + e->a_convb[L - 1] : nullptr;
+        aa.dWn = e->arena + e->a_dwn; aa.dWe = e->arena + e->a_dwe;
+        RC(with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL((k_att_bwd<4, G>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, aa, 1, N, H, c.rpb_n);
+            return 0;
+        }));
+        CAL_CHECK_LAUNCH("k_att_bwd");
+    }
+    // Q. backbone layers, last to first
+    for (int i = L; i >= 1; --i) {
+        SpmmBranch br{e->dZ, e->dzi, nullptr, nullptr, e->dis_unit, nullptr, nullptr, nullptr};
+        RC(with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, gs, br, br, 0, e->loop_w, N, H, c.rpb_n);
+            return 0;
+        }));
+        CAL_CHECK_LAUNCH("k_espmm(T)");
+        const float* hin = e->h + (size_t)(i - 1) * NH;
+        {
+            GemmArgs a = gemm_args(H, H, N, true, false, 0);
+            a.p[0].A = hin; a.p[0].B = e->dzi;
+            a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 0);
+            float* dst[1] = {e->G + e->o_conv_w[i - 1]};
+            RC(grad_gemm(c, a, 1, dst, fa, slab_off));
+        }
+        {
+            GemmArgs a = gemm_args(N, H, H, false, true, 0);
+            a.p[0].A = e->dzi; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->dXh;
+            a.p[0].aux = hin; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, i, N, 0);
+            a.p[0].dot_sum = bn_dsum(c, i); a.p[0].dot_prod = bn_dprod(c, i);
+            RC(launch_gemm(false, true, a, 1, st));
+        }
+        {
+            BnBwdProb p{e->dXh, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i),
+                        i >= 2 ? e->arena + e->a_convb[i - 2] : nullptr};
+            RC(with_g(H, [&](auto g) {
+                constexpr int G = decltype(g)::value;
+                hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
+                return 0;
+            }));
+            CAL_CHECK_LAUNCH("k_bn_bwd");
+        }
+    }
+    // S. conv_feat weight and bn_feat affine gradients
+    {
+        GemmArgs a = gemm_args(F, H, N, true, false, 0);
+        a.p[0].A = x0; a.p[0].B = e->dZ;
+        a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 0);
+        float* dst[1] = {e->G + e->o_feat_w};
+        RC(grad_gemm(c, a, 1, dst, fa, slab_off));
+    }
+    {
+        GemmArgs a = gemm_args(N, F, H, false, true, 0);
+        a.p[0].A = e->dZ; a.p[0].B = e->P + e->o_feat_w; a.p[0].C = nullptr;
+        a.p[0].aux = x0; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, 0, N, 0);
+        a.p[0].dot_sum = bn_dsum(c, 0); a.p[0].dot_prod = bn_dprod(c, 0);
+        RC(launch_gemm(false, true, a, 1, st));
+    }
+    // commits: fp64 arena -> fp32 gradients
+    for (int k = 0; k < e->nbn; ++k) {
+        const BNSlot& b = e->bn[k];
+        const int wp = (b.width + 3) / 4 * 4;
+        commit(b.arena + 3 * wp, b.gamma, b.width, 1.f);   // d gamma = sum dyh * x_n
+        commit(b.arena + 2 * wp, b.beta, b.width, 1.f);    // d beta  = sum dyh
+    }
+    for (int i = 0; i < L; ++i) commit(e->a_convb[i], e->o_conv_b[i], H, 1.f);
+    commit(e->a_cb, e->o_cb, H, 1.f);
+    commit(e->a_ob, e->o_ob, H, 1.f);
+    commit(e->a_dwn, e->o_natt_w, H, 1.f);
+    commit(e->a_dwn, e->o_natt_w + H, H, -1.f);
+    commit(e->a_dwn + H, e->o_natt_b, 1, 1.f);
+    commit(e->a_dwn + H, e->o_natt_b + 1, 1, -1.f);
+    commit(e->a_dwe, e->o_eatt_w, 2 * H, 1.f);
+    commit(e->a_dwe, e->o_eatt_w + 2 * H, 2 * H, -1.f);
+    commit(e->a_dwe + 2 * H, e->o_eatt_b, 1, 1.f);
+    commit(e->a_dwe + 2 * H, e->o_eatt_b + 1, 1, -1.f);
+    for (int hd = 0; hd < 3; ++hd) {
+        commit(e->a_db1 + hd * H, e->o_fc1_b[hd], H, 1.f);
+        commit(e->a_db2 + hd * C, e->o_fc2_b[hd], C, 1.f);
+    }
+    if (fa.nct > MAX_COMMITS) { set_error("engine: too many commit tasks"); return 2; }
+    hipLaunchKernelGGL(k_finish, dim3(16, fa.nst + fa.nct), dim3(256), 0, st, fa, e->arena, e->G);
+    CAL_CHECK_LAUNCH("k_finish");
+    return 0;
+}
+
+}  // namespace
+
+// One training step (or, with mode bits cleared, parts of it) for a device-resident batch.
+//   x0 [N,F] fp32, edge_index [2,E] int64, batch [N] int64 (sorted), y [B] int64, perm [B] int64
+//   (the random-intervention index, model.py:147-152; identity = arange).
+//   mode: bit0 = forward in training mode (batch statistics, running-stat updates);
+//         bit1 = loss gradient + backward (fills the flat gradient buffer);
+//         bit2 = Adam update.  mode = 0 is an eval-mode forward.
+//   Outputs live in the workspace: "logp" [3,B,C] log-probabilities (c, o, co), "stats" [5].
+CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_index, const int64_t* batch, const int64_t* y,
+                               const int64_t* perm, int64_t N, int64_t E, int64_t B, float wc, float wo, float wco, int mode,
+                               void* stream_) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e && e->ws, "engine has no workspace");
+    CAL_REQUIRE(N <= e->capN && E <= e->capE && B <= e->capB, "batch exceeds the workspace capacity");
+    CAL_REQUIRE(N > 0 && B > 0, "empty batch");
+    Ctx c;
+    c.e = e; c.st = (hipStream_t)stream_; c.N = (int)N; c.B = (int)B; c.E = E;
+    c.training = (mode & 1) ? 1 : 0;
+    c.rpb_n = std::max(32, cdiv(N, 1024));
+    c.rpb_b = std::max(8, cdiv(B, 256));
+    const int want_grad = (mode & 2) ? 1 : 0;
+    CAL_REQUIRE(!want_grad || c.training, "backward needs a training-mode forward");
+    RC(engine_forward(c, x0, edge_index, batch, y, perm, wc, wo, wco, want_grad));
+    if (want_grad) RC(engine_backward(c, x0, batch));
+    if (mode & 4) {
+        hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, c.st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
+                           e->beta2, e->eps, e->wd, e->nparam);
+        CAL_CHECK_LAUNCH("k_adam");
+        hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, c.st, e->step);
+        CAL_CHECK_LAUNCH("k_adam_tick");
+    }
+    return 0;
+}
+
+// Adam alone (after an external gradient all-reduce)
+CAL_EXPORT int cal_engine_adam(void* h, void* stream_) {
+    Engine* e = (Engine*)h;
+    hipStream_t st = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
+                       e->beta2, e->eps, e->wd, e->nparam);
+    CAL_CHECK_LAUNCH("k_adam");
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, e->step);
+    CAL_CHECK_LAUNCH("k_adam_tick");
+    return 0;
+}

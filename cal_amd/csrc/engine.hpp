@@ -1,0 +1,115 @@
+// Internal types of the native CausalGCN step engine (not part of the C ABI).
+#pragma once
+#include "common.hpp"
+
+namespace cal {
+
+// Reference to one BatchNorm1d instance whose batch statistics live in the fp64 accumulator arena
+// (sum, sum of squares per column, filled by the producer kernel's epilogue / a stats kernel).
+// Consumers derive scale = gamma*rstd, shift = beta - mean*scale (torch BatchNorm1d, eps 1e-5,
+// biased variance for normalisation) on the fly.
+struct BNRef {
+    const double* sum;     // [W]
+    const double* sq;      // [W]
+    const float* gamma;    // [W] (null -> 1)
+    const float* beta;     // [W] (null -> 0)
+    float inv_n;           // 1 / rows
+    float eps;
+    // running statistics (updated by exactly one consumer block when update != 0; momentum 0.1,
+    // unbiased variance, num_batches_tracked += 1)
+    float* run_mean;
+    float* run_var;
+    int64_t* nbt;
+    float unbias;          // n / (n - 1)
+    int update;
+    int use_running;       // eval mode: normalise with running statistics instead of batch statistics
+};
+
+__device__ __forceinline__ void bn_scale_shift(const BNRef& bn, int c, float& sc, float& sh) {
+    float mean, var;
+    if (bn.use_running) {
+        mean = bn.run_mean[c];
+        var = bn.run_var[c];
+    } else {
+        double m = bn.sum[c] * (double)bn.inv_n;
+        double v = bn.sq[c] * (double)bn.inv_n - m * m;
+        mean = (float)m;
+        var = (float)(v > 0.0 ? v : 0.0);
+    }
+    float rstd = 1.0f / sqrtf(var + bn.eps);
+    float g = bn.gamma ? bn.gamma[c] : 1.f;
+    float b = bn.beta ? bn.beta[c] : 0.f;
+    sc = g * rstd;
+    sh = b - mean * sc;
+}
+
+// mean / rstd only (for the normalised value x_n = (x - mean) * rstd used by BN backward)
+__device__ __forceinline__ void bn_mean_rstd(const BNRef& bn, int c, float& mean, float& rstd) {
+    float var;
+    if (bn.use_running) {
+        mean = bn.run_mean[c];
+        var = bn.run_var[c];
+    } else {
+        double m = bn.sum[c] * (double)bn.inv_n;
+        double v = bn.sq[c] * (double)bn.inv_n - m * m;
+        mean = (float)m;
+        var = (float)(v > 0.0 ? v : 0.0);
+    }
+    rstd = 1.0f / sqrtf(var + bn.eps);
+}
+
+__device__ __forceinline__ void bn_update_running(const BNRef& bn, int c) {
+    double m = bn.sum[c] * (double)bn.inv_n;
+    double v = bn.sq[c] * (double)bn.inv_n - m * m;
+    if (v < 0.0) v = 0.0;
+    bn.run_mean[c] = 0.9f * bn.run_mean[c] + 0.1f * (float)m;
+    bn.run_var[c] = 0.9f * bn.run_var[c] + 0.1f * (float)(v * (double)bn.unbias);
+    if (c == 0 && bn.nbt) *bn.nbt += 1;
+}
+
+// Optional transform applied to a GEMM operand while it is staged, in STORAGE coordinates
+// (storage row = node / sample index, storage column = feature index):
+//     v' = (rs[row] * v) * sc[col] + sh[col]        (sc, sh from `bn`; rs may be null)
+struct Xform {
+    const float* rs;   // per storage row scale (node attention a_k[v]), stride rs_stride
+    int rs_stride;
+    int has_bn;
+    BNRef bn;
+};
+
+// One problem of a (batched) GEMM launch.
+struct GemmProb {
+    const float* A;
+    const float* B;
+    float* C;            // may be null (statistics only)
+    const float* bias;   // [N] or null
+    Xform xa, xb;
+    // epilogue statistics over the rows of C (after bias / ReLU): sum and sum of squares per column
+    double* st_sum;
+    double* st_sq;
+    // epilogue "dot statistics": dot_sum[col] += C, dot_prod[col] += C * aux_n where
+    // aux_n = ((aux_rs[row] * aux[row, col]) - mean[col]) * rstd[col]   (BN backward sums)
+    const float* aux;
+    const float* aux_rs;
+    int aux_rs_stride;
+    int has_aux;
+    BNRef aux_bn;
+    double* dot_sum;
+    double* dot_prod;
+};
+
+struct GemmArgs {
+    GemmProb p[3];
+    int M, N, K;
+    int lda, ldb, ldc;
+    int relu;
+    int kchunk;          // split-K slice length (multiple of BK); slices write C + z * M * ldc
+    int nsplit;
+};
+
+int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStream_t stream);
+int splitk_for(int64_t M, int64_t N, int64_t K, int nbatch);
+void gemm_set_split(GemmArgs& a, int S);
+
+
+}  // namespace cal

@@ -1,0 +1,734 @@
+// Node-/edge-/graph-level kernels of the native CausalGCN step engine (included by engine.hip only).
+//
+// Conventions: fp32 activations, fp64 accumulation of every cross-row reduction (BatchNorm batch
+// statistics, BatchNorm-backward sums, bias / attention-parameter gradients) with one atomic per
+// column per workgroup into the accumulator arena; G lanes cooperate on one feature row (VEC = 4
+// floats per lane -> one coalesced 16 B access per lane); a workgroup walks `rows_per_block` rows
+// so the per-column pre-reduction in LDS keeps the atomic count at (#blocks x #columns).
+#pragma once
+#include "engine.hpp"
+
+namespace cal {
+
+struct CSR {
+    const int* ptr;
+    const int* nbr;
+    const int* eid;
+};
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+// Sum `v` over the row-lanes of a block for column slot `cslot` (0..ncols-1) and add it to dst[col].
+// lds: at least nrl * ncols doubles.  Must be called by every thread of the block.
+__device__ __forceinline__ void block_col_atomic(double v, int cslot, int rlane, int nrl, int ncols, bool valid,
+                                                 double* dst, int col, double* lds) {
+    lds[rlane * ncols + cslot] = valid ? v : 0.0;
+    __syncthreads();
+    if (rlane == 0 && valid) {
+        double t = 0.0;
+        for (int k = 0; k < nrl; ++k) t += lds[k * ncols + cslot];
+        atomicAdd(dst + col, t);
+    }
+    __syncthreads();
+}
+
+__global__ void k_zero_f64(double* __restrict__ a, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column statistics of a raw matrix (the bn_feat input, model.py:90)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_colstats(const float* __restrict__ x, int N, int W, int tc, int rows_per_block,
+                                                  double* __restrict__ sum, double* __restrict__ sq) {
+    __shared__ double lds[256];
+    const int nrl = 256 / tc, c = threadIdx.x % tc, rl = threadIdx.x / tc;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    for (int cc = c; cc - c < W; cc += tc) {
+        const bool ok = cc < W;
+        double s = 0.0, q = 0.0;
+        if (ok)
+            for (int r = r0 + rl; r < r1; r += nrl) {
+                double v = x[(size_t)r * W + cc];
+                s += v; q += v * v;
+            }
+        block_col_atomic(s, c, rl, nrl, tc, ok, sum, cc, lds);
+        block_col_atomic(q, c, rl, nrl, tc, ok, sq, cc, lds);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gptr + unweighted deg^-1/2 (gcn_conv.py:65-68 with edge_weight = 1)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gptr_dis(const int64_t* __restrict__ batch, int N, int B, int* __restrict__ gptr,
+                           const int* __restrict__ ptr_src, float loop_w, float* __restrict__ dis_unit,
+                           int* __restrict__ status) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > N) return;
+    if (i < N) {
+        float d = (float)(ptr_src[i + 1] - ptr_src[i]) + loop_w;
+        dis_unit[i] = d == 0.f ? 0.f : 1.0f / sqrtf(d);
+    }
+    int64_t prev = i == 0 ? -1 : batch[i - 1];
+    int64_t cur = i == N ? (int64_t)B : batch[i];
+    if (i < N && (cur < prev || cur >= B || cur < 0)) { atomicOr(status, 2); return; }
+    for (int64_t b = prev + 1; b <= cur && b <= B; ++b) gptr[b] = i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// aggregation  out = act(A_hat h + bias)  (gcn_conv.py:92-104) with optional output statistics
+// ------------------------------------------------------------------------------------------------
+struct SpmmBranch {
+    const float* h;
+    float* out;
+    const float* bias;     // null -> none
+    const float* w;        // per-edge weight (edge-id order) or null (all ones)
+    const float* dis;      // deg^-1/2 per node
+    double* st_sum;        // column statistics of the output (next BatchNorm) or null
+    double* st_sq;
+    double* colsum;        // plain column sums of the output (unused by the forward) or null
+};
+
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch b0, const SpmmBranch b1, int relu,
+                                               float loop_w, int N, int H, int rows_per_block) {
+    __shared__ double lds[2][256 * (VEC == 4 ? 4 : 1)];
+    constexpr int RPB = 256 / G;
+    const SpmmBranch& br = blockIdx.y ? b1 : b0;
+    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
+    using V = Vec<VEC>;
+    const bool want = br.st_sum != nullptr;
+    for (int c = l * VEC; c - l * VEC < H; c += G * VEC) {
+        const bool cok = c < H;
+        double s1[VEC], s2[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
+        for (int i = rbeg + grp; i < rend; i += RPB) {
+            if (!cok) continue;
+            const int p0 = g.ptr[i], p1 = g.ptr[i + 1];
+            const float di = br.dis[i];
+            V acc = V::zero();
+            int s = p0;
+            for (; s + 4 <= p1; s += 4) {
+                const int j0 = g.nbr[s], j1 = g.nbr[s + 1], j2 = g.nbr[s + 2], j3 = g.nbr[s + 3];
+                float c0 = br.dis[j0], c1 = br.dis[j1], c2 = br.dis[j2], c3 = br.dis[j3];
+                if (br.w) {
+                    c0 *= br.w[g.eid[s]]; c1 *= br.w[g.eid[s + 1]]; c2 *= br.w[g.eid[s + 2]]; c3 *= br.w[g.eid[s + 3]];
+                }
+                V h0 = V::ld(br.h + (size_t)j0 * H + c), h1 = V::ld(br.h + (size_t)j1 * H + c);
+                V h2 = V::ld(br.h + (size_t)j2 * H + c), h3 = V::ld(br.h + (size_t)j3 * H + c);
+                acc.fma(c0, h0); acc.fma(c1, h1); acc.fma(c2, h2); acc.fma(c3, h3);
+            }
+            for (; s < p1; ++s) {
+                const int j = g.nbr[s];
+                float cf = br.dis[j];
+                if (br.w) cf *= br.w[g.eid[s]];
+                acc.fma(cf, V::ld(br.h + (size_t)j * H + c));
+            }
+            acc.fma(di * loop_w, V::ld(br.h + (size_t)i * H + c));
+            acc.scale(di);
+            if (br.bias) acc.add(V::ld(br.bias + c));
+            if (relu) acc.relu();
+            acc.st(br.out + (size_t)i * H + c);
+            if (want) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { double v = acc.get(j); s1[j] += v; s2[j] += v * v; }
+            }
+        }
+        if (want) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                block_col_atomic(s1[j], l * VEC + j, grp, RPB, G * VEC, cok, br.st_sum, c + j, lds[0]);
+                block_col_atomic(s2[j], l * VEC + j, grp, RPB, G * VEC, cok, br.st_sq, c + j, lds[0]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node attention + edge projections (model.py:97-111):  a = softmax2(x Wn^T + bn),
+// pq = (x.We[0,:H], x.We[1,:H], x.We[0,H:], x.We[1,H:]), and the batch statistics of
+// xc = a0 x and xo = a1 x (inputs of bnc / bno) -- xc / xo themselves are never stored.
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_node_att_fwd(const float* __restrict__ x, const float* __restrict__ Wn,
+                                                      const float* __restrict__ bn, const float* __restrict__ We,
+                                                      float* __restrict__ anode, float* __restrict__ pq,
+                                                      double* __restrict__ stc_sum, double* __restrict__ stc_sq,
+                                                      double* __restrict__ sto_sum, double* __restrict__ sto_sq,
+                                                      int N, int H, int rows_per_block) {
+    __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
+    constexpr int RPB = 256 / G;
+    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
+    using V = Vec<VEC>;
+    // pass 1: logits / projections per row (full-row dot products)
+    for (int v = rbeg + grp; v < rend; v += RPB) {
+        float l0 = 0.f, l1 = 0.f, p0 = 0.f, p1 = 0.f, q0 = 0.f, q1 = 0.f;
+        for (int c = l * VEC; c < H; c += G * VEC) {
+            V xv = V::ld(x + (size_t)v * H + c);
+            l0 += xv.dot(V::ld(Wn + c));
+            l1 += xv.dot(V::ld(Wn + H + c));
+            p0 += xv.dot(V::ld(We + c));
+            p1 += xv.dot(V::ld(We + 2 * H + c));
+            q0 += xv.dot(V::ld(We + H + c));
+            q1 += xv.dot(V::ld(We + 3 * H + c));
+        }
+        l0 = group_sum<G>(l0) + bn[0]; l1 = group_sum<G>(l1) + bn[1];
+        p0 = group_sum<G>(p0); p1 = group_sum<G>(p1); q0 = group_sum<G>(q0); q1 = group_sum<G>(q1);
+        if (l == 0) {
+            float m = fmaxf(l0, l1);
+            float e0 = expf(l0 - m), e1 = expf(l1 - m);
+            float inv = 1.f / (e0 + e1);
+            anode[2 * (size_t)v] = e0 * inv;
+            anode[2 * (size_t)v + 1] = e1 * inv;
+            *reinterpret_cast<float4*>(pq + 4 * (size_t)v) = make_float4(p0, p1, q0, q1);
+        }
+    }
+    __syncthreads();   // anode of this block's rows is visible to the block (same-CU L1 write-through + barrier)
+    // pass 2: statistics of a0*x and a1*x
+    for (int c = l * VEC; c - l * VEC < H; c += G * VEC) {
+        const bool cok = c < H;
+        double sc1[VEC], sc2[VEC], so1[VEC], so2[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { sc1[j] = sc2[j] = so1[j] = so2[j] = 0.0; }
+        if (cok)
+            for (int v = rbeg + grp; v < rend; v += RPB) {
+                // recompute a0/a1 from the logits written by lane 0 of this very group: same thread
+                // group, ordered by the barrier above
+                const float a0 = anode[2 * (size_t)v], a1 = anode[2 * (size_t)v + 1];
+                V xv = V::ld(x + (size_t)v * H + c);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    double xc = (double)(a0 * xv.get(j)), xo = (double)(a1 * xv.get(j));
+                    sc1[j] += xc; sc2[j] += xc * xc; so1[j] += xo; so2[j] += xo * xo;
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            block_col_atomic(sc1[j], l * VEC + j, grp, RPB, G * VEC, cok, stc_sum, c + j, lds);
+            block_col_atomic(sc2[j], l * VEC + j, grp, RPB, G * VEC, cok, stc_sq, c + j, lds);
+            block_col_atomic(so1[j], l * VEC + j, grp, RPB, G * VEC, cok, sto_sum, c + j, lds);
+            block_col_atomic(so2[j], l * VEC + j, grp, RPB, G * VEC, cok, sto_sq, c + j, lds);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// edge softmax (model.py:102-104) + weighted degrees of both branches (gcn_conv.py:63-68).
+// 8 lanes per source node walk its out-edges; att[0,E] = edge_weight_c, att[1,E] = edge_weight_o.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_edge_att_deg(const CSR gs, const float* __restrict__ pq, const float* __restrict__ be,
+                                                      float* __restrict__ att, float* __restrict__ dis_c,
+                                                      float* __restrict__ dis_o, float loop_w, int N, int64_t E) {
+    const int v = blockIdx.x * 32 + threadIdx.x / 8, l = threadIdx.x % 8;
+    if (v >= N) return;
+    const float4 pv = *reinterpret_cast<const float4*>(pq + 4 * (size_t)v);
+    const float b0 = be[0], b1 = be[1];
+    float dc = 0.f, dq = 0.f;
+    for (int s = gs.ptr[v] + l; s < gs.ptr[v + 1]; s += 8) {
+        const int d = gs.nbr[s], e = gs.eid[s];
+        const float4 qd = *reinterpret_cast<const float4*>(pq + 4 * (size_t)d);
+        const float l0 = pv.x + qd.z + b0, l1 = pv.y + qd.w + b1;
+        const float m = fmaxf(l0, l1);
+        const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+        const float inv = 1.f / (e0 + e1);
+        const float a0 = e0 * inv, a1 = e1 * inv;
+        att[e] = a0;
+        att[E + e] = a1;
+        dc += a0; dq += a1;
+    }
+    dc = group_sum<8>(dc); dq = group_sum<8>(dq);
+    if (l == 0) {
+        dc += loop_w; dq += loop_w;
+        dis_c[v] = dc == 0.f ? 0.f : 1.0f / sqrtf(dc);
+        dis_o[v] = dq == 0.f ? 0.f : 1.0f / sqrtf(dq);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// global_add_pool for both branches (model.py:115-116): grid (B, 2)
+// ------------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256) k_pool2(const float* __restrict__ hc, const float* __restrict__ ho,
+                                               const int* __restrict__ gptr, float* __restrict__ pc,
+                                               float* __restrict__ po, int H, int tc) {
+    __shared__ float lds[256 * 4];
+    const float* h = blockIdx.y ? ho : hc;
+    float* out = blockIdx.y ? po : pc;
+    const int b = blockIdx.x;
+    const int nrl = 256 / tc, cl = threadIdx.x % tc, rl = threadIdx.x / tc;
+    const int n0 = gptr[b], n1 = gptr[b + 1];
+    using V = Vec<VEC>;
+    for (int c = cl * VEC; c - cl * VEC < H; c += tc * VEC) {
+        const bool cok = c < H;
+        V a = V::zero(), a2 = V::zero();
+        if (cok) {
+            int r = n0 + rl;
+            for (; r + nrl < n1; r += 2 * nrl) {
+                a.add(V::ld(h + (size_t)r * H + c));
+                a2.add(V::ld(h + (size_t)(r + nrl) * H + c));
+            }
+            if (r < n1) a.add(V::ld(h + (size_t)r * H + c));
+            a.add(a2);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) lds[(rl * tc + cl) * VEC + j] = a.get(j);
+        __syncthreads();
+        if (rl == 0 && cok) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float t = 0.f;
+                for (int k = 0; k < nrl; ++k) t += lds[(k * tc + cl) * VEC + j];
+                out[(size_t)b * H + c + j] = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// readout inputs (model.py:145-156): x_co = xc[perm] + xo, inverse permutation, and the batch
+// statistics of the three readout inputs (fc1_bn_c / _o / _co).  pooled: [2,B,H]; xin: [3,B,H].
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_readout_prep(const float* __restrict__ pooled, const int64_t* __restrict__ perm,
+                                                      int* __restrict__ iperm, float* __restrict__ xco, int B, int H,
+                                                      int tc, int rows_per_block, double* __restrict__ s_c,
+                                                      double* __restrict__ q_c, double* __restrict__ s_o,
+                                                      double* __restrict__ q_o, double* __restrict__ s_co,
+                                                      double* __restrict__ q_co) {
+    __shared__ double lds[256];
+    const int nrl = 256 / tc, cl = threadIdx.x % tc, rl = threadIdx.x / tc;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(B, r0 + rows_per_block);
+    const float* pc = pooled;
+    const float* po = pooled + (size_t)B * H;
+    if (cl == 0)
+        for (int r = r0 + rl; r < r1; r += nrl) iperm[perm[r]] = r;
+    for (int c = cl; c - cl < H; c += tc) {
+        const bool cok = c < H;
+        double a1 = 0, a2 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0;
+        if (cok)
+            for (int r = r0 + rl; r < r1; r += nrl) {
+                const float vc = pc[(size_t)r * H + c], vo = po[(size_t)r * H + c];
+                const float vco = pc[(size_t)perm[r] * H + c] + vo;
+                xco[(size_t)r * H + c] = vco;
+                a1 += vc; a2 += (double)vc * vc; b1 += vo; b2 += (double)vo * vo; c1 += vco; c2 += (double)vco * vco;
+            }
+        block_col_atomic(a1, cl, rl, nrl, tc, cok, s_c, c, lds);
+        block_col_atomic(a2, cl, rl, nrl, tc, cok, q_c, c, lds);
+        block_col_atomic(b1, cl, rl, nrl, tc, cok, s_o, c, lds);
+        block_col_atomic(b2, cl, rl, nrl, tc, cok, q_o, c, lds);
+        block_col_atomic(c1, cl, rl, nrl, tc, cok, s_co, c, lds);
+        block_col_atomic(c2, cl, rl, nrl, tc, cok, q_co, c, lds);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// log_softmax + 3-term loss (train_causal.py:176-183) + gradient w.r.t. the pre-softmax scores.
+// One workgroup.  z, logp, dz: [3,B,C] (heads c, o, co).  stats: [loss, c, o, co, correct_o].
+// db2[h*C + k] = column sums of dz (fc2 bias gradients), written to the fp64 arena.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_loss(const float* __restrict__ z, const int64_t* __restrict__ y,
+                                              float* __restrict__ logp, float* __restrict__ dz,
+                                              float* __restrict__ stats, double* __restrict__ db2, int B, int C,
+                                              float wc, float wo, float wco, int want_grad) {
+    __shared__ double red[256];
+    __shared__ double tot[4];
+    const float w[3] = {wc, wo, wco};
+    double part[4] = {0.0, 0.0, 0.0, 0.0};   // c, o, co, correct
+    const float u = 1.0f / (float)C, invB = 1.0f / (float)B;
+    for (int t = threadIdx.x; t < 3 * B; t += 256) {
+        const int hd = t / B, b = t % B;
+        const float* zr = z + (size_t)t * C;
+        float m = -INFINITY;
+        for (int k = 0; k < C; ++k) m = fmaxf(m, zr[k]);
+        float se = 0.f;
+        for (int k = 0; k < C; ++k) se += expf(zr[k] - m);
+        const float lse = m + logf(se);
+        const int yy = (int)y[b];
+        int arg = 0; float best = -INFINITY;
+        for (int k = 0; k < C; ++k) {
+            const float lp = zr[k] - lse;
+            logp[(size_t)t * C + k] = lp;
+            if (lp > best) { best = lp; arg = k; }
+            if (hd == 0) part[0] += (double)(u * (logf(u) - lp));           // KL(c || uniform), batchmean
+            if (want_grad) {
+                const float p = expf(lp);
+                const float g = hd == 0 ? (p - u) : (p - (k == yy ? 1.f : 0.f));
+                dz[(size_t)t * C + k] = w[hd] * invB * g;
+            }
+        }
+        if (hd == 1) { part[1] += (double)(-(zr[yy] - lse)); part[3] += (arg == yy) ? 1.0 : 0.0; }
+        if (hd == 2) part[2] += (double)(-(zr[yy] - lse));
+    }
+    for (int q = 0; q < 4; ++q) {
+        red[threadIdx.x] = part[q];
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) tot[q] = red[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float lc = (float)(tot[0] * invB), lo = (float)(tot[1] * invB), lco = (float)(tot[2] * invB);
+        stats[0] = wc * lc + wo * lo + wco * lco;
+        stats[1] = lc; stats[2] = lo; stats[3] = lco; stats[4] = (float)tot[3];
+    }
+    if (want_grad) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 3 * C; t += 256) {
+            const int hd = t / C, k = t % C;
+            double s = 0.0;
+            for (int b = 0; b < B; ++b) s += (double)dz[((size_t)hd * B + b) * C + k];
+            db2[t] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm backward (elementwise part) + ReLU mask of the producer + bias-gradient column sums.
+//   dy = gamma*rstd*(dyh - m1 - x_n*m2) * [relu ? (x > 0) : 1],  x_n = (x - mean)*rstd,
+//   m1 = dot_sum/n, m2 = dot_prod/n (accumulated by the GEMM that produced dyh).
+// Batched over blockIdx.y (readout heads).  x is the BN input (= previous post-ReLU activation).
+// ------------------------------------------------------------------------------------------------
+struct BnBwdProb {
+    const float* dyh;
+    const float* x;
+    float* dy;
+    BNRef bn;
+    const double* dot_sum;
+    const double* dot_prod;
+    double* colsum;      // column sums of dy (bias gradient of the producing layer) or null
+};
+
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_bn_bwd(const BnBwdProb p0, const BnBwdProb p1, const BnBwdProb p2, int relu,
+                                                int N, int W, int rows_per_block) {
+    __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
+    constexpr int RPB = 256 / G;
+    const BnBwdProb& p = blockIdx.y == 0 ? p0 : (blockIdx.y == 1 ? p1 : p2);
+    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
+    using V = Vec<VEC>;
+    for (int c = l * VEC; c - l * VEC < W; c += G * VEC) {
+        const bool cok = c < W;
+        float mean[VEC], rstd[VEC], gs[VEC], m1[VEC], m2[VEC];
+        double cs[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            cs[j] = 0.0;
+            if (cok && c + j < W) {
+                bn_mean_rstd(p.bn, c + j, mean[j], rstd[j]);
+                gs[j] = (p.bn.gamma ? p.bn.gamma[c + j] : 1.f) * rstd[j];
+                m1[j] = (float)(p.dot_sum[c + j] * (double)p.bn.inv_n);
+                m2[j] = (float)(p.dot_prod[c + j] * (double)p.bn.inv_n);
+            } else { mean[j] = rstd[j] = gs[j] = m1[j] = m2[j] = 0.f; }
+        }
+        if (cok)
+            for (int r = rbeg + grp; r < rend; r += RPB) {
+                V d = V::ld(p.dyh + (size_t)r * W + c), xv = V::ld(p.x + (size_t)r * W + c);
+                float o[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float xn = (xv.get(j) - mean[j]) * rstd[j];
+                    float t = gs[j] * (d.get(j) - m1[j] - xn * m2[j]);
+                    if (relu && !(xv.get(j) > 0.f)) t = 0.f;
+                    o[j] = t;
+                    cs[j] += (double)t;
+                }
+                V ov;
+                if constexpr (VEC == 4) ov.v = make_float4(o[0], o[1], o[2], o[3]); else ov.v = o[0];
+                ov.st(p.dy + (size_t)r * W + c);
+            }
+        if (p.colsum) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                block_col_atomic(cs[j], l * VEC + j, grp, RPB, G * VEC, cok, p.colsum, c + j, lds);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// readout tail of the backward: BN-backward of the three fc1_bn inputs and the scatter of the
+// random-intervention sum back to the two pooled vectors (model.py:153-156):
+//   dpool_c[j] = dxc[j] + dxco[iperm[j]],   dpool_o[b] = dxo[b] + dxco[b].
+// ------------------------------------------------------------------------------------------------
+struct BnIn {
+    const float* dyh;   // [B,H]
+    const float* x;     // [B,H]
+    BNRef bn;
+    const double* dot_sum;
+    const double* dot_prod;
+};
+__device__ __forceinline__ float bn_bwd_elem(const BnIn& p, int r, int c, int H) {
+    float mean, rstd;
+    bn_mean_rstd(p.bn, c, mean, rstd);
+    const float gs = (p.bn.gamma ? p.bn.gamma[c] : 1.f) * rstd;
+    const float m1 = (float)(p.dot_sum[c] * (double)p.bn.inv_n), m2 = (float)(p.dot_prod[c] * (double)p.bn.inv_n);
+    const float xn = (p.x[(size_t)r * H + c] - mean) * rstd;
+    return gs * (p.dyh[(size_t)r * H + c] - m1 - xn * m2);
+}
+__global__ void __launch_bounds__(256) k_readout_bwd_tail(const BnIn hc, const BnIn ho, const BnIn hco,
+                                                          const int* __restrict__ iperm, float* __restrict__ dpool,
+                                                          int B, int H) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)B * H) return;
+    const int r = (int)(t / H), c = (int)(t % H);
+    dpool[t] = bn_bwd_elem(hc, r, c, H) + bn_bwd_elem(hco, iperm[r], c, H);
+    dpool[(size_t)B * H + t] = bn_bwd_elem(ho, r, c, H) + bn_bwd_elem(hco, r, c, H);
+}
+
+// ------------------------------------------------------------------------------------------------
+// add-pool backward + ReLU mask + bias-gradient sums for both branches: grid (blocks, 2)
+//   dZ[v,:] = dpool[batch[v],:] * (h[v,:] > 0)
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_pool_bwd_relu(const float* __restrict__ dpool, const int64_t* __restrict__ batch,
+                                                       const float* __restrict__ hc, const float* __restrict__ ho,
+                                                       float* __restrict__ dzc, float* __restrict__ dzo,
+                                                       double* __restrict__ dbc, double* __restrict__ dbo, int N, int B,
+                                                       int H, int rows_per_block) {
+    __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
+    constexpr int RPB = 256 / G;
+    const int brn = blockIdx.y;
+    const float* h = brn ? ho : hc;
+    float* dz = brn ? dzo : dzc;
+    double* db = brn ? dbo : dbc;
+    const float* dp = dpool + (size_t)brn * B * H;
+    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
+    using V = Vec<VEC>;
+    for (int c = l * VEC; c - l * VEC < H; c += G * VEC) {
+        const bool cok = c < H;
+        double cs[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) cs[j] = 0.0;
+        if (cok)
+            for (int v = rbeg + grp; v < rend; v += RPB) {
+                V g = V::ld(dp + (size_t)batch[v] * H + c), hv = V::ld(h + (size_t)v * H + c);
+                float o[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { o[j] = hv.get(j) > 0.f ? g.get(j) : 0.f; cs[j] += (double)o[j]; }
+                V ov;
+                if constexpr (VEC == 4) ov.v = make_float4(o[0], o[1], o[2], o[3]); else ov.v = o[0];
+                ov.st(dz + (size_t)v * H + c);
+            }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            block_col_atomic(cs[j], l * VEC + j, grp, RPB, G * VEC, cok, db, c + j, lds);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SDDMM for both branches: gn[br,e] = <dZ_br[col_e], z_br[row_e]>, gself[br,v] = <dZ_br[v], z_br[v]>
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_sddmm2(const CSR gd, const float* __restrict__ dzc, const float* __restrict__ dzo,
+                                                const float* __restrict__ zc, const float* __restrict__ zo,
+                                                float* __restrict__ gn, float* __restrict__ gself, int N, int64_t E, int H) {
+    constexpr int RPB = 256 / G;
+    const int brn = blockIdx.y;
+    const float* dz = brn ? dzo : dzc;
+    const float* z = brn ? zo : zc;
+    float* gne = gn + (size_t)brn * E;
+    float* gs = gself + (size_t)brn * N;
+    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const int i = blockIdx.x * RPB + grp;
+    if (i >= N) return;
+    using V = Vec<VEC>;
+    const int p0 = gd.ptr[i], p1 = gd.ptr[i + 1];
+    for (int s = p0; s <= p1; ++s) {
+        const int j = s < p1 ? gd.nbr[s] : i;
+        float p = 0.f;
+        for (int c = l * VEC; c < H; c += G * VEC)
+            p += V::ld(dz + (size_t)i * H + c).dot(V::ld(z + (size_t)j * H + c));
+        p = group_sum<G>(p);
+        if (l == 0) { if (s < p1) gne[gd.eid[s]] = p; else gs[i] = p; }
+    }
+}
+
+// d deg for both branches (gcn_conv.py:63-70 differentiated); 8 lanes per node
+__global__ void __launch_bounds__(256) k_normbwd_node2(const CSR gs, const CSR gd, const float* __restrict__ att,
+                                                       const float* __restrict__ dis, const float* __restrict__ gn,
+                                                       const float* __restrict__ gself, float* __restrict__ ddeg,
+                                                       float loop_w, int N, int64_t E) {
+    const int brn = blockIdx.y;
+    const float* w = att + (size_t)brn * E;
+    const float* di = dis + (size_t)brn * N;
+    const float* g = gn + (size_t)brn * E;
+    const int v = blockIdx.x * 32 + threadIdx.x / 8, l = threadIdx.x % 8;
+    if (v >= N) return;
+    float acc = 0.f;
+    for (int s = gs.ptr[v] + l; s < gs.ptr[v + 1]; s += 8) { const int e = gs.eid[s]; acc += g[e] * w[e] * di[gs.nbr[s]]; }
+    for (int s = gd.ptr[v] + l; s < gd.ptr[v + 1]; s += 8) { const int e = gd.eid[s]; acc += g[e] * w[e] * di[gd.nbr[s]]; }
+    acc = group_sum<8>(acc);
+    if (l == 0) {
+        const float d = di[v];
+        acc += 2.f * gself[(size_t)brn * N + v] * d * loop_w;
+        ddeg[(size_t)brn * N + v] = -0.5f * d * d * d * acc;
+    }
+}
+
+// d edge_weight of both branches -> d(edge logit 0): dl[e] = a0 a1 (dw_c - dw_o)  (softmax2 backward)
+__global__ void k_normbwd_edge(const int* __restrict__ row32, const int* __restrict__ col32, const float* __restrict__ att,
+                               const float* __restrict__ dis, const float* __restrict__ gn, const float* __restrict__ ddeg,
+                               float* __restrict__ dl, int N, int64_t E) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int r = row32[e], c = col32[e];
+    if (r == c) { dl[e] = 0.f; return; }
+    const float dwc = gn[e] * dis[r] * dis[c] + ddeg[r];
+    const float dwo = gn[E + e] * dis[(size_t)N + r] * dis[(size_t)N + c] + ddeg[(size_t)N + r];
+    dl[e] = att[e] * att[E + e] * (dwc - dwo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward through bnc/bno, the node attention split, the node/edge attention MLPs and the ReLU of
+// the last backbone layer, in one pass over the nodes (model.py:97-113 differentiated):
+//   dxc = BNbwd_c(dXc_hat), dxo = BNbwd_o(dXo_hat)            (inputs were a0*x, a1*x)
+//   dl0 = a0 a1 (<dxc,x> - <dxo,x>)                            (node softmax2 backward)
+//   sp = sum_{row_e=v} dl[e], sq = sum_{col_e=v} dl[e]         (edge projections backward)
+//   dx = a0 dxc + a1 dxo + dl0 (Wn0-Wn1) + sp (We0[:H]-We1[:H]) + sq (We0[H:]-We1[H:])
+//   dZ = dx * (x > 0)                                           (x = relu output of the last conv)
+// and the column sums for d bias_L, d Wn, d bn, d We, d be.
+// ------------------------------------------------------------------------------------------------
+struct AttBwdArgs {
+    const float* x; const float* anode; const float* dxhc; const float* dxho;
+    BNRef bnc, bno;
+    const double *dsc, *dpc, *dso, *dpo;    // dot sums of bnc / bno
+    const float* Wn; const float* We; const float* dl;
+    CSR gs, gd;
+    float* dZ;
+    double* dbias;     // [H] bias gradient of the last backbone conv (null when there is none)
+    double* dWn;       // [H] (+1: d bn0 at [H])
+    double* dWe;       // [2H] (+1: d be0 at [2H])
+};
+
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, int N, int H, int rows_per_block) {
+    __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
+    __shared__ double sc_lds[2][256 / G];
+    constexpr int RPB = 256 / G;
+    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
+    using V = Vec<VEC>;
+    const float inv_n = a.bnc.inv_n;
+    double sdl = 0.0, ssp = 0.0;
+    // the kernel supports one column chunk per lane (H <= G*VEC), enforced by the host
+    const int c = l * VEC;
+    const bool cok = c < H;
+    float mc[VEC], rc[VEC], gc[VEC], m1c[VEC], m2c[VEC], mo[VEC], ro[VEC], go[VEC], m1o[VEC], m2o[VEC];
+    float wn[VEC], wp[VEC], wq[VEC];
+    double cs_b[VEC], cs_n[VEC], cs_p[VEC], cs_q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        cs_b[j] = cs_n[j] = cs_p[j] = cs_q[j] = 0.0;
+        if (cok && c + j < H) {
+            bn_mean_rstd(a.bnc, c + j, mc[j], rc[j]);
+            bn_mean_rstd(a.bno, c + j, mo[j], ro[j]);
+            gc[j] = (a.bnc.gamma ? a.bnc.gamma[c + j] : 1.f) * rc[j];
+            go[j] = (a.bno.gamma ? a.bno.gamma[c + j] : 1.f) * ro[j];
+            m1c[j] = (float)(a.dsc[c + j] * (double)inv_n); m2c[j] = (float)(a.dpc[c + j] * (double)inv_n);
+            m1o[j] = (float)(a.dso[c + j] * (double)inv_n); m2o[j] = (float)(a.dpo[c + j] * (double)inv_n);
+            wn[j] = a.Wn[c + j] - a.Wn[H + c + j];
+            wp[j] = a.We[c + j] - a.We[2 * H + c + j];
+            wq[j] = a.We[H + c + j] - a.We[3 * H + c + j];
+        } else {
+            mc[j] = rc[j] = gc[j] = m1c[j] = m2c[j] = mo[j] = ro[j] = go[j] = m1o[j] = m2o[j] = 0.f;
+            wn[j] = wp[j] = wq[j] = 0.f;
+        }
+    }
+    for (int v = rbeg + grp; v < rend; v += RPB) {
+        const float a0 = a.anode[2 * (size_t)v], a1 = a.anode[2 * (size_t)v + 1];
+        float xv[VEC], dxc[VEC], dxo[VEC];
+        float d0 = 0.f, d1 = 0.f;
+        if (cok) {
+            V x4 = V::ld(a.x + (size_t)v * H + c), hc4 = V::ld(a.dxhc + (size_t)v * H + c), ho4 = V::ld(a.dxho + (size_t)v * H + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                xv[j] = x4.get(j);
+                const float xcn = (a0 * xv[j] - mc[j]) * rc[j], xon = (a1 * xv[j] - mo[j]) * ro[j];
+                dxc[j] = gc[j] * (hc4.get(j) - m1c[j] - xcn * m2c[j]);
+                dxo[j] = go[j] * (ho4.get(j) - m1o[j] - xon * m2o[j]);
+                d0 = fmaf(dxc[j], xv[j], d0);
+                d1 = fmaf(dxo[j], xv[j], d1);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { xv[j] = dxc[j] = dxo[j] = 0.f; }
+        }
+        d0 = group_sum<G>(d0); d1 = group_sum<G>(d1);
+        const float dl0 = a0 * a1 * (d0 - d1);
+        float sp = 0.f, sq = 0.f;
+        for (int s = a.gs.ptr[v] + l; s < a.gs.ptr[v + 1]; s += G) sp += a.dl[a.gs.eid[s]];
+        for (int s = a.gd.ptr[v] + l; s < a.gd.ptr[v + 1]; s += G) sq += a.dl[a.gd.eid[s]];
+        sp = group_sum<G>(sp); sq = group_sum<G>(sq);
+        if (l == 0) { sdl += (double)dl0; ssp += (double)sp; }
+        if (cok) {
+            float o[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float dx = a0 * dxc[j] + a1 * dxo[j] + dl0 * wn[j] + sp * wp[j] + sq * wq[j];
+                if (relu && !(xv[j] > 0.f)) dx = 0.f;
+                o[j] = dx;
+                cs_b[j] += (double)dx;
+                cs_n[j] += (double)(dl0 * xv[j]);
+                cs_p[j] += (double)(sp * xv[j]);
+                cs_q[j] += (double)(sq * xv[j]);
+            }
+            V ov;
+            if constexpr (VEC == 4) ov.v = make_float4(o[0], o[1], o[2], o[3]); else ov.v = o[0];
+            ov.st(a.dZ + (size_t)v * H + c);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        if (a.dbias) block_col_atomic(cs_b[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dbias, c + j, lds);
+        block_col_atomic(cs_n[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dWn, c + j, lds);
+        block_col_atomic(cs_p[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dWe, c + j, lds);
+        block_col_atomic(cs_q[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dWe, H + c + j, lds);
+    }
+    if (l == 0) { sc_lds[0][grp] = sdl; sc_lds[1][grp] = ssp; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int k = 0; k < RPB; ++k) { t0 += sc_lds[0][k]; t1 += sc_lds[1][k]; }
+        atomicAdd(a.dWn + H, t0);
+        atomicAdd(a.dWe + 2 * H, t1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic reduction of split-K weight-gradient slabs + commit of the fp64 arena to the fp32
+// gradient buffer + Adam (torch.optim.Adam semantics: bias-corrected, eps outside the sqrt of the
+// corrected second moment, optional L2 weight decay added to the gradient).
+// ------------------------------------------------------------------------------------------------
+struct SlabTask { const float* slabs; float* dst; int n; int S; };
+struct CommitTask { int src; int dst; int n; float scale; };   // arena offset -> flat-gradient offset
+
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                       float* __restrict__ step, const float* __restrict__ lr_ptr, float beta1, float beta2, float eps,
+                       float wd, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // every thread reads the (not yet incremented) step; thread 0 of the LAST block to finish would
+    // race, so the increment happens in a separate tiny launch (k_adam_tick)
+    if (i >= n) return;
+    const float t = step[0] + 1.f;
+    const float lr = lr_ptr[0];
+    float gi = g[i];
+    if (wd != 0.f) gi = fmaf(wd, p[i], gi);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * (mi / denom);
+}
+__global__ void k_adam_tick(float* step) { step[0] += 1.f; }
+
+}  // namespace cal

@@ -1,0 +1,157 @@
+"""Python handle of the native CausalGCN step engine (cal_amd/csrc/engine.hip).
+
+``StepEngine(model)`` re-homes the module's parameters into one flat buffer
+(so the module, its state_dict and any torch optimizer keep working on the same
+memory), binds gradients / Adam state, owns the device workspace and exposes
+
+* ``forward(batch, perm, training)`` -> three ``[B, C]`` log-prob tensors,
+* ``train_step(batch, perm)``       -> forward + 3-term loss + backward (+ Adam),
+
+each as ONE C call that enqueues the fused kernels on torch's current stream
+(hipGraph-capturable).  Only ``CausalGCN`` with ``cat_or_add == "add"`` and both
+attentions enabled is covered; everything else stays on the operator-level
+path (``cal_amd.model``).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .plan import _p, _stream
+
+_BN_ORDER_TAIL = ["bnc", "bno", "fc1_bn_c", "fc2_bn_c", "fc1_bn_o", "fc2_bn_o", "fc1_bn_co", "fc2_bn_co"]
+
+
+def supported(model) -> bool:
+    from .model import CausalGCN
+    a = model.args
+    h = a.hidden
+    return (isinstance(model, CausalGCN) and a.cat_or_add == "add" and not model.without_node_attention
+            and not model.without_edge_attention and h % 4 == 0 and h <= 256 and a.layers <= 6
+            and model.num_classes <= 64 and not any(c.improved for c in model.convs))
+
+
+def _slot_names(layers: int):
+    names = ["bn_feat.weight", "bn_feat.bias", "conv_feat.weight"]
+    for i in range(layers):
+        names += [f"bns_conv.{i}.weight", f"bns_conv.{i}.bias", f"convs.{i}.weight", f"convs.{i}.bias"]
+    names += ["edge_att_mlp.weight", "edge_att_mlp.bias", "node_att_mlp.weight", "node_att_mlp.bias",
+              "bnc.weight", "bnc.bias", "bno.weight", "bno.bias",
+              "context_convs.weight", "context_convs.bias", "objects_convs.weight", "objects_convs.bias"]
+    for h in ("c", "o", "co"):
+        names += [f"fc1_bn_{h}.weight", f"fc1_bn_{h}.bias", f"fc1_{h}.weight", f"fc1_{h}.bias",
+                  f"fc2_bn_{h}.weight", f"fc2_bn_{h}.bias", f"fc2_{h}.weight", f"fc2_{h}.bias"]
+    return names
+
+
+class StepEngine:
+    def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, flat=None):
+        if not supported(model):
+            raise ValueError("StepEngine covers CausalGCN (cat_or_add='add', attentions on, hidden % 4 == 0, <= 256)")
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise _lib.CalError("StepEngine needs the model on the GPU (no CPU fallback)")
+        self.model = model
+        self.device = p0.device
+        a = model.args
+        self.F = model.bn_feat.num_features
+        self.H, self.C, self.L = a.hidden, model.num_classes, a.layers
+        from .trainer import flatten_parameters
+        self.flat_p, self.flat_g = flat if flat is not None else flatten_parameters(model)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.lr = torch.full((1,), float(lr), dtype=torch.float32, device=self.device)
+        h = _lib.lib().cal_engine_create(self.F, self.H, self.C, self.L)
+        if not h:
+            raise _lib.CalError("cal_engine_create failed: " + _lib.lib().cal_last_error().decode())
+        self._h = ctypes.c_void_p(h)
+        # parameter offsets in slot order
+        base = self.flat_p.data_ptr()
+        params = dict(model.named_parameters())
+        offs = []
+        for n in _slot_names(self.L):
+            p = params[n]
+            off = (p.data_ptr() - base) // 4
+            assert 0 <= off and off + p.numel() <= self.flat_p.numel(), n
+            offs.append(off)
+        assert len(offs) == _lib.query("cal_engine_num_param_slots", self._h)
+        bns = [model.bn_feat] + list(model.bns_conv) + [getattr(model, n) for n in _BN_ORDER_TAIL]
+        ptrs = []
+        for bn in bns:
+            ptrs += [bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()]
+        self._offs = (ctypes.c_int64 * len(offs))(*offs)
+        self._bn = (ctypes.c_int64 * len(ptrs))(*ptrs)
+        _lib.call("cal_engine_bind", self._h, _p(self.flat_p), _p(self.flat_g), _p(self.exp_avg), _p(self.exp_avg_sq),
+                  _p(self.step_count), _p(self.lr), self.flat_p.numel(), self._offs, self._bn,
+                  betas[0], betas[1], eps, weight_decay)
+        self._ws: Optional[torch.Tensor] = None
+        self._cap = (0, 0, 0)
+        self.wc, self.wo, self.wco = float(getattr(a, "c", 0.5)), float(getattr(a, "o", 1.0)), float(getattr(a, "co", 0.5))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                _lib.lib().cal_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- workspace
+    def reserve(self, N: int, E: int, B: int):
+        """(Re)allocate the workspace for batches up to (N nodes, E edges, B graphs)."""
+        cn, ce, cb = self._cap
+        if N <= cn and E <= ce and B <= cb and self._ws is not None:
+            return
+        N, E, B = max(N, cn), max(E, ce), max(B, cb)
+        nbytes = _lib.query("cal_engine_workspace_bytes", self._h, N, E, B)
+        self._ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
+        assert self._ws.data_ptr() % 256 == 0
+        _lib.call("cal_engine_set_workspace", self._h, _p(self._ws), nbytes, N, E, B)
+        self._cap = (N, E, B)
+
+    def buffer(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
+        off = _lib.query("cal_engine_buffer_offset", self._h, name.encode())
+        if off < 0:
+            raise KeyError(name)
+        if dtype == torch.float64:
+            return self._ws[off:off + 2 * numel].view(torch.float64)
+        if dtype == torch.int32:
+            return self._ws[off:off + numel].view(torch.int32)
+        return self._ws[off:off + numel]
+
+    # --------------------------------------------------------------------- run
+    def _run(self, batch, perm, mode: int):
+        x = batch.x if getattr(batch, "x", None) is not None else batch.feat
+        ei, bvec, y = batch.edge_index, batch.batch, batch.y
+        if not (x.is_cuda and ei.is_cuda):
+            raise _lib.CalError("StepEngine: batch must be on the GPU (no CPU fallback)")
+        N, E, B = x.size(0), ei.size(1), int(batch.num_graphs)
+        if x.dtype != torch.float32 or x.size(1) != self.F:
+            raise ValueError("features must be float32 [N, %d]" % self.F)
+        self.reserve(N, E, B)
+        if perm is None:
+            perm = torch.arange(B, device=self.device)
+        if y is None:
+            y = torch.zeros(B, dtype=torch.long, device=self.device)
+        _lib.call("cal_engine_step", self._h, _p(x.contiguous()), _p(ei.contiguous()), _p(bvec.contiguous()),
+                  _p(y.view(-1).contiguous()), _p(perm.contiguous()), N, E, B, self.wc, self.wo, self.wco, mode, _stream())
+        return B
+
+    def forward(self, batch, perm=None, training: bool = False):
+        B = self._run(batch, perm, 1 if training else 0)
+        lp = self.buffer("logp", 3 * B * self.C).view(3, B, self.C)
+        return lp[0], lp[1], lp[2]
+
+    def train_step(self, batch, perm=None, adam: bool = True):
+        """forward + loss + backward (+ Adam); returns the device stats tensor
+        [loss, c_loss, o_loss, co_loss, correct_o] (a view into the workspace)."""
+        self._run(batch, perm, 3 | (4 if adam else 0))
+        return self.buffer("stats", 5)
+
+    def adam(self):
+        _lib.call("cal_engine_adam", self._h, _stream())

@@ -7,9 +7,12 @@ MI355X-first choices (DESIGN.md section "step engine"):
   ONE flat gradient buffer -> Adam is a single fused update over one tensor and
   the data-parallel exchange is a single RCCL all-reduce of ~0.5 MB
   (latency-bound on xGMI, so: one bucket, one call);
-* forward + 3-term loss + backward for one resident, pre-collated batch is
-  captured once into a hipGraph (the kernels are enqueued through the C ABI on
-  the capturing stream) and replayed -- no per-op host launch cost;
+* CausalGCN runs on the native step engine (cal_amd/csrc/engine.hip): forward +
+  3-term loss + backward + Adam are ~55 fused kernels enqueued by ONE C call;
+  other models run the operator-level autograd path (cal_amd.ops) with torch's
+  loss / Adam;
+* either way the step for one resident, pre-collated batch is captured once
+  into a hipGraph and replayed -- no per-kernel host launch cost;
 * the GraphPlan (CSR build) is rebuilt inside every step: it is part of the
   work the reference does per step (GCNConv.norm, gcn_conv.py:79-89);
 * the random-intervention permutation (model.py:147-152) stays a host-side
@@ -18,7 +21,7 @@ MI355X-first choices (DESIGN.md section "step engine"):
 from __future__ import annotations
 
 import random
-from typing import Dict, Optional
+from typing import Dict, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -49,20 +52,34 @@ class _Captured:
 
 class CausalTrainer:
     def __init__(self, model, args, lr: float = 1e-3, weight_decay: float = 0.0,
-                 use_graph: bool = True, world_size: int = 1, rebuild_plan: bool = True):
+                 use_graph: bool = True, world_size: int = 1, rebuild_plan: bool = True,
+                 use_engine: Optional[bool] = None):
+        from . import engine as eng_mod
         self.model, self.args = model, args
         self.use_graph = use_graph
         self.world_size = world_size
         self.rebuild_plan = rebuild_plan
         self.flat_p, self.flat_g = flatten_parameters(model)
         self.flat_p.grad = self.flat_g
-        self.lr = torch.tensor(float(lr), device=self.flat_p.device) if use_graph else float(lr)
-        self.opt = torch.optim.Adam([self.flat_p], lr=self.lr, weight_decay=weight_decay,
-                                    capturable=use_graph)
+        if use_engine is None:
+            use_engine = eng_mod.supported(model)
+        self.engine = None
+        if use_engine:
+            self.engine = eng_mod.StepEngine(model, lr=lr, weight_decay=weight_decay,
+                                             flat=(self.flat_p, self.flat_g))
+            self.engine.wc, self.engine.wo, self.engine.wco = float(args.c), float(args.o), float(args.co)
+            self.lr = self.engine.lr
+            self.opt = None
+        else:
+            self.lr = torch.tensor(float(lr), device=self.flat_p.device) if use_graph else float(lr)
+            self.opt = torch.optim.Adam([self.flat_p], lr=self.lr, weight_decay=weight_decay,
+                                        capturable=use_graph)
         self._graphs: Dict[int, _Captured] = {}
         self._pool = torch.cuda.graph_pool_handle() if use_graph else None
         self._opt_graph: Optional[torch.cuda.CUDAGraph] = None
         self.stats = torch.zeros(5, dtype=torch.float32, device=self.flat_p.device)
+        # with one GPU the optimizer update rides in the same graph as forward/backward
+        self.fused_opt = self.engine is not None and world_size == 1
         self.model.train()
 
     # ------------------------------------------------------------------ pieces
@@ -81,7 +98,18 @@ class CausalTrainer:
             random.shuffle(l)
         return torch.tensor(l, dtype=torch.long)
 
+    def reserve_for(self, batches: Sequence):
+        """Size the engine workspace for the largest of `batches` BEFORE any graph is captured."""
+        if self.engine is not None:
+            n = max(int(b.batch.numel()) for b in batches)
+            e = max(int(b.edge_index.size(1)) for b in batches)
+            g = max(int(b.num_graphs) for b in batches)
+            self.engine.reserve(n, e, g)
+
     def _fwd_bwd(self, batch, perm, stats):
+        if self.engine is not None:
+            stats.copy_(self.engine.train_step(batch, perm, adam=self.fused_opt))
+            return
         self.flat_g.zero_()
         if self.rebuild_plan:
             batch._plan = None
@@ -97,25 +125,49 @@ class CausalTrainer:
             dist.all_reduce(self.flat_g)
             self.flat_g.mul_(1.0 / self.world_size)
 
+    def _snapshot(self):
+        state = {k: v.clone() for k, v in self.model.state_dict().items()}
+        extra = None
+        if self.engine is not None:
+            extra = (self.engine.exp_avg.clone(), self.engine.exp_avg_sq.clone(), self.engine.step_count.clone())
+        return state, extra
+
+    def _restore(self, snap):
+        state, extra = snap
+        with torch.no_grad():
+            for k, v in self.model.state_dict().items():
+                v.copy_(state[k])
+        if extra is not None:
+            self.engine.exp_avg.copy_(extra[0])
+            self.engine.exp_avg_sq.copy_(extra[1])
+            self.engine.step_count.copy_(extra[2])
+
     def _capture(self, batch) -> _Captured:
         cap = _Captured()
         nb = batch.num_graphs
         cap.perm = torch.arange(nb, dtype=torch.long, device=self.flat_p.device)
         cap.stats = torch.zeros(5, dtype=torch.float32, device=self.flat_p.device)
-        # warm-up on a side stream (allocator + autograd state), restoring BN statistics after
-        bn_state = {k: v.clone() for k, v in self.model.state_dict().items()
-                    if "running_" in k or "num_batches" in k}
+        if self.engine is not None:
+            x = batch.x if getattr(batch, "x", None) is not None else batch.feat
+            cn, ce, cb = self.engine._cap
+            if x.size(0) > cn or batch.edge_index.size(1) > ce or nb > cb:
+                if self._graphs:
+                    raise RuntimeError("engine workspace would be re-allocated under captured graphs: "
+                                       "call reserve_for(all batches) before the first prepare()")
+                self.engine.reserve(x.size(0), batch.edge_index.size(1), nb)
+        # warm-up on a side stream (allocator / autograd state); everything it touched is restored
+        snap = self._snapshot()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
                 self._fwd_bwd(batch, cap.perm, cap.stats)
         torch.cuda.current_stream().wait_stream(s)
-        self.model.load_state_dict(bn_state, strict=False)
+        self._restore(snap)
         cap.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(cap.graph, pool=self._pool):
             self._fwd_bwd(batch, cap.perm, cap.stats)
-        self.model.load_state_dict(bn_state, strict=False)
+        self._restore(snap)
         return cap
 
     def _reset_opt_state(self):
@@ -125,33 +177,42 @@ class CausalTrainer:
         st["exp_avg_sq"].zero_()
 
     def _build_opt_graph(self):
-        """Capture Adam's update once.  Its lazy state init must happen outside
-        capture, so one throw-away step runs first and everything it touched is
-        restored."""
-        saved_p, saved_g = self.flat_p.clone(), self.flat_g.clone()
-        fresh = self.flat_p not in self.opt.state or len(self.opt.state[self.flat_p]) == 0
+        """Capture the optimizer update once.  torch Adam's lazy state init must happen outside
+        capture, so one throw-away step runs first and everything it touched is restored."""
+        saved_g = self.flat_g.clone()
+        snap = self._snapshot()
         saved_state = None
-        if not fresh:
-            saved_state = {k: v.clone() for k, v in self.opt.state[self.flat_p].items()}
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self.opt.step()
-        torch.cuda.current_stream().wait_stream(s)
+        if self.opt is not None:
+            fresh = self.flat_p not in self.opt.state or len(self.opt.state[self.flat_p]) == 0
+            saved_state = None if fresh else {k: v.clone() for k, v in self.opt.state[self.flat_p].items()}
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.opt.step()
+            torch.cuda.current_stream().wait_stream(s)
         self._opt_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._opt_graph):
-            self.opt.step()
-        if saved_state is None:
-            self._reset_opt_state()
-        else:
-            for k, v in saved_state.items():
-                self.opt.state[self.flat_p][k].copy_(v)
-        self.flat_p.copy_(saved_p)
+        with torch.cuda.graph(self._opt_graph, pool=self._pool):
+            if self.opt is not None:
+                self.opt.step()
+            else:
+                self.engine.adam()
+        if self.opt is not None:
+            if saved_state is None:
+                self._reset_opt_state()
+            else:
+                for k, v in saved_state.items():
+                    self.opt.state[self.flat_p][k].copy_(v)
+        self._restore(snap)
         self.flat_g.copy_(saved_g)
 
     def _opt_step(self):
+        if self.fused_opt:
+            return
         if not self.use_graph:
-            self.opt.step()
+            if self.opt is not None:
+                self.opt.step()
+            else:
+                self.engine.adam()
             return
         if self._opt_graph is None:
             self._build_opt_graph()
@@ -163,7 +224,7 @@ class CausalTrainer:
         if self.use_graph:
             if id(batch) not in self._graphs:
                 self._graphs[id(batch)] = self._capture(batch)
-            if self._opt_graph is None:
+            if self._opt_graph is None and not self.fused_opt:
                 self._build_opt_graph()
 
     def step(self, batch, perm: Optional[torch.Tensor] = None) -> torch.Tensor:

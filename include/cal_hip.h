@@ -117,6 +117,30 @@ CAL_API int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const
 CAL_API int cal_gat_dropout_mask(uint64_t seed, int64_t E, int64_t N, int64_t K, float p,
                                  float* mask, void* stream);
 
+/* ---- native CausalGCN step engine ------------------------------------------------
+ * The whole train step of train_causal.py:173-192 on model.py:85-164 (forward, 3-term loss,
+ * backward, Adam) as one call enqueuing ~55 fused kernels; see cal_amd/csrc/engine.hip for the
+ * slot order of `offs` / `bn_ptrs`.  mode bits: 1 = training-mode forward, 2 = loss gradient +
+ * backward into the flat gradient buffer, 4 = Adam.  Outputs ("logp" [3,B,C], "stats" [5] =
+ * loss, c_loss, o_loss, co_loss, correct_o) live in the caller-owned workspace at
+ * cal_engine_buffer_offset(name) floats from its base. */
+CAL_API void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L);
+CAL_API void cal_engine_destroy(void* engine);
+CAL_API int64_t cal_engine_num_param_slots(void* engine);
+CAL_API int64_t cal_engine_num_bn(void* engine);
+CAL_API int cal_engine_bind(void* engine, float* P, float* G, float* M1, float* M2, float* step,
+                            float* lr, int64_t nparam, const int64_t* offs, const int64_t* bn_ptrs,
+                            float beta1, float beta2, float eps, float weight_decay);
+CAL_API int64_t cal_engine_workspace_bytes(void* engine, int64_t N, int64_t E, int64_t B);
+CAL_API int cal_engine_set_workspace(void* engine, void* ws, int64_t bytes, int64_t capN,
+                                     int64_t capE, int64_t capB);
+CAL_API int64_t cal_engine_buffer_offset(void* engine, const char* name);
+CAL_API int cal_engine_step(void* engine, const float* x0, const int64_t* edge_index,
+                            const int64_t* batch, const int64_t* y, const int64_t* perm, int64_t N,
+                            int64_t E, int64_t B, float wc, float wo, float wco, int mode,
+                            void* stream);
+CAL_API int cal_engine_adam(void* engine, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
