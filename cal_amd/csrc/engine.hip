@@ -31,8 +31,7 @@ struct FinishArgs {
     CommitTask ct[MAX_COMMITS];
     int nst, nct;
 };
-__global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, const double* __restrict__ arena,
-                                                float* __restrict__ grad) {
+__global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __restrict__ grad) {
     const int task = blockIdx.y;
     if (task < fa.nst) {
         const SlabTask t = fa.st[task];
@@ -45,8 +44,24 @@ __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, const doubl
         }
     } else if (task - fa.nst < fa.nct) {
         const CommitTask t = fa.ct[task - fa.nst];
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n; i += gridDim.x * 256)
-            grad[t.dst + i] = t.scale * (float)arena[t.src + i];
+        // 16 part-lanes x 16 columns per block pass
+        __shared__ double red[256];
+        const int pl = threadIdx.x >> 4, cl = threadIdx.x & 15;
+        for (int c0 = blockIdx.x * 16; c0 < t.n; c0 += gridDim.x * 16) {
+            const int c = c0 + cl;
+            double sacc = 0.0;
+            if (c < t.n)
+                for (int q = pl; q < t.P; q += 16) sacc += t.src[(size_t)q * t.stride + c];
+            red[threadIdx.x] = sacc;
+            __syncthreads();
+            if (pl == 0 && c < t.n) {
+                double tot = 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) tot += red[k * 16 + cl];
+                grad[t.dst + c] = t.scale * (float)tot;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -78,6 +93,7 @@ struct Engine {
     float *dzl, *dyh1, *dy1, *dxh, *dpool, *dZco, *gn, *gself, *ddeg, *dl, *dzco, *dXhco, *dZ, *dzi, *dXh, *slabs;
     size_t slab_floats;
     double* arena;
+    double* parts; size_t parts_doubles;
     int *rowptr_dst, *nbr_dst, *eid_dst, *rowptr_src, *nbr_src, *eid_src, *row32, *col32, *work, *status, *gptr, *iperm;
 };
 
@@ -190,6 +206,12 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
         float* tmp = nullptr;
         F32(tmp, 2 * (size_t)e->arena_n);
         if (assign) e->arena = (double*)tmp;
+        // partial rows of the cross-row sums: <= 1024 producer blocks x (2..6)H columns per set,
+        // ~(3L + 16) sets alive per step
+        size_t pcap = (N + 15) / 16 + 1;
+        size_t pd = pcap * (size_t)H * 2 * (3 * L + 20);
+        F32(tmp, 2 * pd);
+        if (assign) { e->parts = (double*)tmp; e->parts_doubles = pd; }
     }
     I32(e->rowptr_dst, N + 1); I32(e->nbr_dst, E); I32(e->eid_dst, E);
     I32(e->rowptr_src, N + 1); I32(e->nbr_src, E); I32(e->eid_src, E);
@@ -238,6 +260,8 @@ struct Ctx {
     int64_t E;
     int training;
     int rpb_n, rpb_b;   // rows per block for node-level / graph-level row walkers
+    size_t parts_off;   // bump allocator over Engine::parts
+    FinalArgs fin;      // pending k_stats_final tasks
 };
 
 BNRef bnref(const Ctx& c, int k, int rows, int update) {
@@ -258,6 +282,60 @@ double* bn_stsum(const Ctx& c, int k) { return c.e->arena + c.e->bn[k].arena; }
 double* bn_stsq(const Ctx& c, int k) { return c.e->arena + c.e->bn[k].arena + (c.e->bn[k].width + 3) / 4 * 4; }
 double* bn_dsum(const Ctx& c, int k) { return c.e->arena + c.e->bn[k].arena + 2 * ((c.e->bn[k].width + 3) / 4 * 4); }
 double* bn_dprod(const Ctx& c, int k) { return c.e->arena + c.e->bn[k].arena + 3 * ((c.e->bn[k].width + 3) / 4 * 4); }
+
+// partial-row accumulator: `cols` columns x P producer blocks, finalised into `dst` by flush_finals
+double* parts_alloc(Ctx& c, size_t n) {
+    n = (n + 1) & ~(size_t)1;
+    if (c.parts_off + n > c.e->parts_doubles) return nullptr;
+    double* p = c.e->parts + c.parts_off;
+    c.parts_off += n;
+    return p;
+}
+void final_task(Ctx& c, const double* parts, int P, int stride, int n, double* dst) {
+    c.fin.t[c.fin.nt++] = FinalTask{parts, P, stride, n, dst};
+}
+int flush_finals(Ctx& c) {
+    if (c.fin.nt == 0) return 0;
+    int nmax = 0;
+    for (int i = 0; i < c.fin.nt; ++i) nmax = std::max(nmax, c.fin.t[i].n);
+    hipLaunchKernelGGL(k_stats_final, dim3(cdiv(nmax, 16), c.fin.nt), dim3(256), 0, c.st, c.fin);
+    c.fin.nt = 0;
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) { set_error("k_stats_final: %s", hipGetErrorString(e_)); return 1; }
+    return 0;
+}
+// aggregation launches: one feature row per lane group when nothing is reduced across rows
+// (most waves in flight for the gather), two rows per group when the epilogue carries statistics
+int spmm_rpb(int H, bool stats) { const int rows = 256 / group_for(H, 4); return stats ? 2 * rows : rows; }
+Acc spmm_acc(Ctx& c, double* dst, int cols, int rpb) {
+    const int P = cdiv(c.N, rpb);
+    double* p = parts_alloc(c, (size_t)P * cols);
+    if (!p) return Acc(dst);
+    final_task(c, p, P, cols, cols, dst);
+    return Acc(dst, p, cols);
+}
+
+// statistics destination for a node-level kernel with P = cdiv(N, rpb_n) blocks: partial rows
+// (finalised right away into dst) when the launch is large, atomics otherwise
+Acc node_acc(Ctx& c, double* dst, int cols) {
+    const int P = cdiv(c.N, c.rpb_n);
+    if ((size_t)P * cols <= 4096) return Acc(dst);
+    double* p = parts_alloc(c, (size_t)P * cols);
+    if (!p) return Acc(dst);
+    final_task(c, p, P, cols, cols, dst);
+    return Acc(dst, p, cols);
+}
+// same for a GEMM epilogue (two sums per column, P = row tiles)
+void gemm_stats(Ctx& c, GemmProb& pr, int M, int N, double* d0, double* d1, bool dot) {
+    if (dot) { pr.dot_sum = d0; pr.dot_prod = d1; } else { pr.st_sum = d0; pr.st_sq = d1; }
+    const int P = gemm_row_tiles(M);
+    if ((size_t)P * N * 2 <= 4096) return;
+    double* p = parts_alloc(c, (size_t)P * 2 * N);
+    if (!p) return;
+    pr.parts = p;
+    final_task(c, p, P, 2 * N, N, d0);
+    final_task(c, p + N, P, 2 * N, N, d1);
+}
 
 GemmArgs gemm_args(int M, int N, int K, bool transA, bool transB, int relu) {
     GemmArgs a;
@@ -300,6 +378,10 @@ int grad_gemm(Ctx& c, GemmArgs& a, int nbatch, float** dst, FinishArgs& fa, size
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+// profiling aid: cal_engine_debug_stop(k) makes the step return after its k-th launch site (0 = run all)
+static int g_stop_after = 0;
+static int g_stage = 0;
+#define STAGE() do { if (g_stop_after > 0 && ++g_stage >= g_stop_after) return -12345; } while (0)
 
 int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int64_t* batch, const int64_t* y,
                    const int64_t* perm, float wc, float wo, float wco, int want_grad) {
@@ -310,59 +392,67 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     const size_t NH = (size_t)N * H;
     // 0. zero the fp64 arena (a kernel, not a memset node)
     hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(e->arena_n, 256)), dim3(256), 0, st, e->arena, (int64_t)e->arena_n);
-    CAL_CHECK_LAUNCH("k_zero_f64");
+    CAL_CHECK_LAUNCH("k_zero_f64"); STAGE();
     // 1. GraphPlan
     RC(cal_plan_build(edge_index, E, N, e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
-                      e->row32, e->col32, e->work, e->status, st));
+                      e->row32, e->col32, e->work, e->status, st)); STAGE();
     hipLaunchKernelGGL(k_gptr_dis, dim3(cdiv(N + 1, 256)), dim3(256), 0, st, batch, N, B, e->gptr, e->rowptr_src, e->loop_w,
                        e->dis_unit, e->status);
-    CAL_CHECK_LAUNCH("k_gptr_dis");
+    CAL_CHECK_LAUNCH("k_gptr_dis"); STAGE();
     const CSR gd{e->rowptr_dst, e->nbr_dst, e->eid_dst}, gs{e->rowptr_src, e->nbr_src, e->eid_src};
     (void)gs;
     // 2. bn_feat statistics (model.py:90)
     if (c.training) {
         int tc = std::min(256, pow2ceil(F));
-        int rpb = std::max(64, cdiv(N, 512));
-        hipLaunchKernelGGL(k_colstats, dim3(cdiv(N, rpb)), dim3(256), 0, st, x0, N, F, tc, rpb, bn_stsum(c, 0), bn_stsq(c, 0));
-        CAL_CHECK_LAUNCH("k_colstats");
+        int rpb = std::max(128, cdiv(N, 256));
+        hipLaunchKernelGGL(k_colstats, dim3(cdiv(N, rpb)), dim3(256), 0, st, x0, N, F, tc, rpb, Acc(bn_stsum(c, 0)), Acc(bn_stsq(c, 0)));
+        CAL_CHECK_LAUNCH("k_colstats"); STAGE();
     }
     // 3. h0 = relu(BN(x0) @ W_feat)   (model.py:90-91, gcn_conv.py:75-77)
     {
         GemmArgs a = gemm_args(N, H, F, false, false, 1);
         a.p[0].A = x0; a.p[0].B = e->P + e->o_feat_w; a.p[0].C = e->h;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 1);
-        if (c.training && L > 0) { a.p[0].st_sum = bn_stsum(c, 1); a.p[0].st_sq = bn_stsq(c, 1); }
-        RC(launch_gemm(false, false, a, 1, st));
+        if (c.training && L > 0) gemm_stats(c, a.p[0], N, H, bn_stsum(c, 1), bn_stsq(c, 1), false);
+        RC(launch_gemm(false, false, a, 1, st)); STAGE();
+        RC(flush_finals(c)); STAGE();
     }
     // 4. backbone: h_i = relu(A_hat (BN_i(h_{i-1}) @ W_i) + b_i)   (model.py:93-95)
     for (int i = 1; i <= L; ++i) {
         GemmArgs a = gemm_args(N, H, H, false, false, 0);
         a.p[0].A = e->h + (size_t)(i - 1) * NH; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->z;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 1);
-        RC(launch_gemm(false, false, a, 1, st));
-        SpmmBranch br{e->z, e->h + (size_t)i * NH, e->P + e->o_conv_b[i - 1], nullptr, e->dis_unit, nullptr, nullptr, nullptr};
-        if (c.training && i < L) { br.st_sum = bn_stsum(c, i + 1); br.st_sq = bn_stsq(c, i + 1); }
+        RC(launch_gemm(false, false, a, 1, st)); STAGE();
+        SpmmBranch br{e->z, e->h + (size_t)i * NH, e->P + e->o_conv_b[i - 1], nullptr, e->dis_unit, Acc(), Acc()};
+        const bool wst = c.training && i < L;
+        const int rpb = spmm_rpb(H, wst);
+        if (wst) { br.st_sum = spmm_acc(c, bn_stsum(c, i + 1), H, rpb); br.st_sq = spmm_acc(c, bn_stsq(c, i + 1), H, rpb); }
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, gd, br, br, 1, e->loop_w, N, H, c.rpb_n);
+            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, rpb), 1), dim3(256), 0, st, gd, br, br, 1, e->loop_w, N, H, rpb);
             return 0;
         }));
-        CAL_CHECK_LAUNCH("k_espmm");
+        CAL_CHECK_LAUNCH("k_espmm"); STAGE();
+        RC(flush_finals(c)); STAGE();
     }
     const float* x = e->h + (size_t)L * NH;
     // 5. node attention, edge projections, bnc/bno statistics (model.py:97-111)
-    RC(with_g(H, [&](auto g) {
-        constexpr int G = decltype(g)::value;
-        hipLaunchKernelGGL((k_node_att_fwd<4, G>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, x, e->P + e->o_natt_w,
-                           e->P + e->o_natt_b, e->P + e->o_eatt_w, e->anode, e->pq, bn_stsum(c, L + 1), bn_stsq(c, L + 1),
-                           bn_stsum(c, L + 2), bn_stsq(c, L + 2), N, H, c.rpb_n);
-        return 0;
-    }));
-    CAL_CHECK_LAUNCH("k_node_att_fwd");
+    {
+        const Acc a0 = node_acc(c, bn_stsum(c, L + 1), H), a1 = node_acc(c, bn_stsq(c, L + 1), H);
+        const Acc a2 = node_acc(c, bn_stsum(c, L + 2), H), a3 = node_acc(c, bn_stsq(c, L + 2), H);
+        RC(with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL((k_node_att_fwd<4, G>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, x, e->P + e->o_natt_w,
+                               e->P + e->o_natt_b, e->P + e->o_eatt_w, e->anode, e->pq, a0, a1, a2, a3, N, H, c.rpb_n);
+            return 0;
+        }));
+        CAL_CHECK_LAUNCH("k_node_att_fwd"); STAGE();
+        RC(flush_finals(c)); STAGE();
+    }
     // 6. edge softmax + weighted degrees (model.py:102-104, gcn_conv.py:63-68)
     hipLaunchKernelGGL(k_edge_att_deg, dim3(cdiv(N, 32)), dim3(256), 0, st, gs, e->pq, e->P + e->o_eatt_b, e->att, e->dis_co,
                        e->dis_co + N, e->loop_w, N, E);
-    CAL_CHECK_LAUNCH("k_edge_att_deg");
+    CAL_CHECK_LAUNCH("k_edge_att_deg"); STAGE();
     // 7. z_k = BN_k(a_k * x) @ W_k for k in (context, objects)   (model.py:112-113)
     {
         GemmArgs a = gemm_args(N, H, H, false, false, 0);
@@ -371,25 +461,25 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             a.p[k].xa.rs = e->anode + k; a.p[k].xa.rs_stride = 2;
             a.p[k].xa.has_bn = 1; a.p[k].xa.bn = bnref(c, L + 1 + k, N, 1);
         }
-        RC(launch_gemm(false, false, a, 2, st));
+        RC(launch_gemm(false, false, a, 2, st)); STAGE();
     }
     // 8. h_k = relu(A_hat_k z_k + b_k)
     {
-        SpmmBranch b0{e->zco, e->hco, e->P + e->o_cb, e->att, e->dis_co, nullptr, nullptr, nullptr};
-        SpmmBranch b1{e->zco + NH, e->hco + NH, e->P + e->o_ob, e->att + E, e->dis_co + N, nullptr, nullptr, nullptr};
+        SpmmBranch b0{e->zco, e->hco, e->P + e->o_cb, e->att, e->dis_co, Acc(), Acc()};
+        SpmmBranch b1{e->zco + NH, e->hco + NH, e->P + e->o_ob, e->att + E, e->dis_co + N, Acc(), Acc()};
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, gd, b0, b1, 1, e->loop_w, N, H, c.rpb_n);
+            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 2), dim3(256), 0, st, gd, b0, b1, 1, e->loop_w, N, H, spmm_rpb(H, false));
             return 0;
         }));
-        CAL_CHECK_LAUNCH("k_espmm(co)");
+        CAL_CHECK_LAUNCH("k_espmm(co)"); STAGE();
     }
     // 9. add-pool (model.py:115-116)
     {
         int tc = std::min(256, pow2ceil(H / 4));
         hipLaunchKernelGGL((k_pool2<4>), dim3(B, 2), dim3(256), 0, st, e->hco, e->hco + NH, e->gptr, e->pooled,
                            e->pooled + (size_t)B * H, H, tc);
-        CAL_CHECK_LAUNCH("k_pool2");
+        CAL_CHECK_LAUNCH("k_pool2"); STAGE();
     }
     // 10. readouts (model.py:125-164)
     const int bn_fc1 = L + 3, bn_fc2 = L + 4;   // + 2*head
@@ -398,7 +488,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         hipLaunchKernelGGL(k_readout_prep, dim3(cdiv(B, c.rpb_b)), dim3(256), 0, st, e->pooled, perm, e->iperm, e->xco, B, H, tc,
                            c.rpb_b, bn_stsum(c, bn_fc1), bn_stsq(c, bn_fc1), bn_stsum(c, bn_fc1 + 2), bn_stsq(c, bn_fc1 + 2),
                            bn_stsum(c, bn_fc1 + 4), bn_stsq(c, bn_fc1 + 4));
-        CAL_CHECK_LAUNCH("k_readout_prep");
+        CAL_CHECK_LAUNCH("k_readout_prep"); STAGE();
     }
     const float* xin[3] = {e->pooled, e->pooled + (size_t)B * H, e->xco};
     {
@@ -407,9 +497,10 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             a.p[hd].A = xin[hd]; a.p[hd].B = e->P + e->o_fc1_w[hd]; a.p[hd].bias = e->P + e->o_fc1_b[hd];
             a.p[hd].C = e->y1 + (size_t)hd * B * H;
             a.p[hd].xa.has_bn = 1; a.p[hd].xa.bn = bnref(c, bn_fc1 + 2 * hd, B, 1);
-            if (c.training) { a.p[hd].st_sum = bn_stsum(c, bn_fc2 + 2 * hd); a.p[hd].st_sq = bn_stsq(c, bn_fc2 + 2 * hd); }
+            if (c.training) gemm_stats(c, a.p[hd], B, H, bn_stsum(c, bn_fc2 + 2 * hd), bn_stsq(c, bn_fc2 + 2 * hd), false);
         }
-        RC(launch_gemm(false, true, a, 3, st));
+        RC(launch_gemm(false, true, a, 3, st)); STAGE();
+        RC(flush_finals(c)); STAGE();
     }
     {
         GemmArgs a = gemm_args(B, C, H, false, true, 0);
@@ -418,11 +509,11 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             a.p[hd].C = e->zl + (size_t)hd * B * C;
             a.p[hd].xa.has_bn = 1; a.p[hd].xa.bn = bnref(c, bn_fc2 + 2 * hd, B, 1);
         }
-        RC(launch_gemm(false, true, a, 3, st));
+        RC(launch_gemm(false, true, a, 3, st)); STAGE();
     }
     hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, st, e->zl, y, e->logp, e->dzl, e->stats, e->arena + e->a_db2, B, C, wc, wo,
                        wco, want_grad);
-    CAL_CHECK_LAUNCH("k_loss");
+    CAL_CHECK_LAUNCH("k_loss"); STAGE();
     return 0;
 }
 
@@ -438,7 +529,21 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     FinishArgs fa;
     memset(&fa, 0, sizeof(fa));
     size_t slab_off = 0;
-    auto commit = [&](int src, int dst, int n, float scale) { fa.ct[fa.nct++] = CommitTask{src, dst, n, scale}; };
+    auto commit_p = [&](const double* src, int P, int stride, int dst, int n, float scale) {
+        if (fa.nct < MAX_COMMITS) fa.ct[fa.nct] = CommitTask{src, P, stride, dst, n, scale};
+        fa.nct++;
+    };
+    auto commit = [&](int src, int dst, int n, float scale) { commit_p(e->arena + src, 1, 0, dst, n, scale); };
+    // deferred column sums: partial rows kept until the final commit (no finalise launch needed)
+    const int PN = cdiv(N, c.rpb_n);
+    struct Deferred { double* p; int P; int stride; };
+    auto deferred = [&](int cols, Deferred& d) -> Acc {
+        d.p = parts_alloc(c, (size_t)PN * cols); d.P = PN; d.stride = cols;
+        return d.p ? Acc(nullptr, d.p, cols) : Acc();
+    };
+    Deferred d_convb[MAX_LAYERS], d_cb, d_ob, d_dwn, d_dwe, d_bn0;
+    memset(d_convb, 0, sizeof(d_convb));
+    d_bn0.p = nullptr;
 
     // R1. dW2_h = dz_h^T @ BN2(y1_h)
     {
@@ -449,7 +554,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[hd].xb.has_bn = 1; a.p[hd].xb.bn = bnref(c, bn_fc2 + 2 * hd, B, 0);
             dst[hd] = e->G + e->o_fc2_w[hd];
         }
-        RC(grad_gemm(c, a, 3, dst, fa, slab_off));
+        RC(grad_gemm(c, a, 3, dst, fa, slab_off)); STAGE();
     }
     // R2. d(BN2 out)_h = dz_h @ W2_h, with the BN2-backward sums
     {
@@ -457,9 +562,10 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         for (int hd = 0; hd < 3; ++hd) {
             a.p[hd].A = e->dzl + (size_t)hd * B * C; a.p[hd].B = e->P + e->o_fc2_w[hd]; a.p[hd].C = e->dyh1 + hd * BH;
             a.p[hd].aux = e->y1 + hd * BH; a.p[hd].has_aux = 1; a.p[hd].aux_bn = bnref(c, bn_fc2 + 2 * hd, B, 0);
-            a.p[hd].dot_sum = bn_dsum(c, bn_fc2 + 2 * hd); a.p[hd].dot_prod = bn_dprod(c, bn_fc2 + 2 * hd);
+            gemm_stats(c, a.p[hd], B, H, bn_dsum(c, bn_fc2 + 2 * hd), bn_dprod(c, bn_fc2 + 2 * hd), true);
         }
-        RC(launch_gemm(false, false, a, 3, st));
+        RC(launch_gemm(false, false, a, 3, st)); STAGE();
+        RC(flush_finals(c)); STAGE();
     }
     // R3. BN2 backward + ReLU mask + fc1 bias gradients
     {
@@ -472,7 +578,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(B, c.rpb_b), 3), dim3(256), 0, st, p[0], p[1], p[2], 1, B, H, c.rpb_b);
             return 0;
         }));
-        CAL_CHECK_LAUNCH("k_bn_bwd(readout)");
+        CAL_CHECK_LAUNCH("k_bn_bwd(readout)"); STAGE();
     }
     // R4. dW1_h = dy1_h^T @ BN1(xin_h)
     {
@@ -483,7 +589,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[hd].xb.has_bn = 1; a.p[hd].xb.bn = bnref(c, bn_fc1 + 2 * hd, B, 0);
             dst[hd] = e->G + e->o_fc1_w[hd];
         }
-        RC(grad_gemm(c, a, 3, dst, fa, slab_off));
+        RC(grad_gemm(c, a, 3, dst, fa, slab_off)); STAGE();
     }
     // R5. d(BN1 out)_h = dy1_h @ W1_h with the BN1-backward sums
     {
@@ -491,9 +597,10 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         for (int hd = 0; hd < 3; ++hd) {
             a.p[hd].A = e->dy1 + hd * BH; a.p[hd].B = e->P + e->o_fc1_w[hd]; a.p[hd].C = e->dxh + hd * BH;
             a.p[hd].aux = xin[hd]; a.p[hd].has_aux = 1; a.p[hd].aux_bn = bnref(c, bn_fc1 + 2 * hd, B, 0);
-            a.p[hd].dot_sum = bn_dsum(c, bn_fc1 + 2 * hd); a.p[hd].dot_prod = bn_dprod(c, bn_fc1 + 2 * hd);
+            gemm_stats(c, a.p[hd], B, H, bn_dsum(c, bn_fc1 + 2 * hd), bn_dprod(c, bn_fc1 + 2 * hd), true);
         }
-        RC(launch_gemm(false, false, a, 3, st));
+        RC(launch_gemm(false, false, a, 3, st)); STAGE();
+        RC(flush_finals(c)); STAGE();
     }
     // R6. BN1 backward + un-permute the random intervention -> d pooled
     {
@@ -501,42 +608,42 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         for (int hd = 0; hd < 3; ++hd)
             in[hd] = BnIn{e->dxh + hd * BH, xin[hd], bnref(c, bn_fc1 + 2 * hd, B, 0), bn_dsum(c, bn_fc1 + 2 * hd), bn_dprod(c, bn_fc1 + 2 * hd)};
         hipLaunchKernelGGL(k_readout_bwd_tail, dim3(cdiv((int64_t)BH, 256)), dim3(256), 0, st, in[0], in[1], in[2], e->iperm, e->dpool, B, H);
-        CAL_CHECK_LAUNCH("k_readout_bwd_tail");
+        CAL_CHECK_LAUNCH("k_readout_bwd_tail"); STAGE();
     }
     // P1. add-pool backward + ReLU of the causal/trivial convs + their bias gradients
-    RC(with_g(H, [&](auto g) {
-        constexpr int G = decltype(g)::value;
-        hipLaunchKernelGGL((k_pool_bwd_relu<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, e->dpool, batch, e->hco, e->hco + NH,
-                           e->dZco, e->dZco + NH, e->arena + e->a_cb, e->arena + e->a_ob, N, B, H, c.rpb_n);
-        return 0;
-    }));
-    CAL_CHECK_LAUNCH("k_pool_bwd_relu");
+    {
+        const Acc acb = deferred(H, d_cb), aob = deferred(H, d_ob);
+        if (!acb.on() || !aob.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
+        RC(with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL((k_pool_bwd_relu<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, e->dpool, batch, e->hco, e->hco + NH,
+                               e->dZco, e->dZco + NH, acb, aob, N, B, H, c.rpb_n);
+            return 0;
+        }));
+    }
+    CAL_CHECK_LAUNCH("k_pool_bwd_relu"); STAGE();
     // P2-P4. gradient w.r.t. the edge weights through propagate and through the normalisation
-    RC(with_g(H, [&](auto g) {
-        constexpr int G = decltype(g)::value;
-        hipLaunchKernelGGL((k_sddmm2<4, G>), dim3(cdiv(N, 256 / G), 2), dim3(256), 0, st, gd, e->dZco, e->dZco + NH, e->zco,
-                           e->zco + NH, e->gn, e->gself, N, E, H);
-        return 0;
-    }));
-    CAL_CHECK_LAUNCH("k_sddmm2");
+    hipLaunchKernelGGL(k_sddmm2, dim3(cdiv(E + N, 32), 2), dim3(256), 0, st, e->row32, e->col32, e->dZco, e->dZco + NH, e->zco,
+                       e->zco + NH, e->gn, e->gself, N, E, H);
+    CAL_CHECK_LAUNCH("k_sddmm2"); STAGE();
     hipLaunchKernelGGL(k_normbwd_node2, dim3(cdiv(N, 32), 2), dim3(256), 0, st, gs, gd, e->att, e->dis_co, e->gn, e->gself, e->ddeg,
                        e->loop_w, N, E);
-    CAL_CHECK_LAUNCH("k_normbwd_node2");
+    CAL_CHECK_LAUNCH("k_normbwd_node2"); STAGE();
     if (E > 0) {
         hipLaunchKernelGGL(k_normbwd_edge, dim3(cdiv(E, 256)), dim3(256), 0, st, e->row32, e->col32, e->att, e->dis_co, e->gn, e->ddeg,
                            e->dl, N, E);
-        CAL_CHECK_LAUNCH("k_normbwd_edge");
+        CAL_CHECK_LAUNCH("k_normbwd_edge"); STAGE();
     }
     // P5. dz_k = A_hat_k^T dZ_k
     {
-        SpmmBranch b0{e->dZco, e->dzco, nullptr, e->att, e->dis_co, nullptr, nullptr, nullptr};
-        SpmmBranch b1{e->dZco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, nullptr, nullptr, nullptr};
+        SpmmBranch b0{e->dZco, e->dzco, nullptr, e->att, e->dis_co, Acc(), Acc()};
+        SpmmBranch b1{e->dZco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, Acc(), Acc()};
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, gs, b0, b1, 0, e->loop_w, N, H, c.rpb_n);
+            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 2), dim3(256), 0, st, gs, b0, b1, 0, e->loop_w, N, H, spmm_rpb(H, false));
             return 0;
         }));
-        CAL_CHECK_LAUNCH("k_espmm(co,T)");
+        CAL_CHECK_LAUNCH("k_espmm(co,T)"); STAGE();
     }
     const float* x = e->h + (size_t)L * NH;
     // P6. dW_k = BN_k(a_k x)^T @ dz_k
@@ -549,7 +656,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[k].xa.has_bn = 1; a.p[k].xa.bn = bnref(c, L + 1 + k, N, 0);
             dst[k] = e->G + (k ? e->o_ow : e->o_cw);
         }
-        RC(grad_gemm(c, a, 2, dst, fa, slab_off));
+        RC(grad_gemm(c, a, 2, dst, fa, slab_off)); STAGE();
     }
     // P7. d(BN_k out) = dz_k @ W_k^T with the BN_k-backward sums
     {
@@ -558,9 +665,10 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[k].A = e->dzco + (size_t)k * NH; a.p[k].B = e->P + (k ? e->o_ow : e->o_cw); a.p[k].C = e->dXhco + (size_t)k * NH;
             a.p[k].aux = x; a.p[k].aux_rs = e->anode + k; a.p[k].aux_rs_stride = 2; a.p[k].has_aux = 1;
             a.p[k].aux_bn = bnref(c, L + 1 + k, N, 0);
-            a.p[k].dot_sum = bn_dsum(c, L + 1 + k); a.p[k].dot_prod = bn_dprod(c, L + 1 + k);
+            gemm_stats(c, a.p[k], N, H, bn_dsum(c, L + 1 + k), bn_dprod(c, L + 1 + k), true);
         }
-        RC(launch_gemm(false, true, a, 2, st));
+        RC(launch_gemm(false, true, a, 2, st)); STAGE();
+        RC(flush_finals(c)); STAGE();
     }
     // P8. everything between the last backbone conv and the two causal convs
     {
@@ -570,48 +678,50 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         aa.dsc = bn_dsum(c, L + 1); aa.dpc = bn_dprod(c, L + 1); aa.dso = bn_dsum(c, L + 2); aa.dpo = bn_dprod(c, L + 2);
         aa.Wn = e->P + e->o_natt_w; aa.We = e->P + e->o_eatt_w; aa.dl = e->dl;
         aa.gs = gs; aa.gd = gd; aa.dZ = e->dZ;
-        aa.dbias = L > 0 ? e->arena + e->a_convb[L - 1] : nullptr;
-        aa.dWn = e->arena + e->a_dwn; aa.dWe = e->arena + e->a_dwe;
+        aa.dbias = L > 0 ? deferred(H, d_convb[L - 1]) : Acc();
+        aa.dWn = deferred(H + 4, d_dwn); aa.dWe = deferred(2 * H + 4, d_dwe);
+        if (!aa.dWn.on() || !aa.dWe.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
             hipLaunchKernelGGL((k_att_bwd<4, G>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, aa, 1, N, H, c.rpb_n);
             return 0;
         }));
-        CAL_CHECK_LAUNCH("k_att_bwd");
+        CAL_CHECK_LAUNCH("k_att_bwd"); STAGE();
     }
     // Q. backbone layers, last to first
     for (int i = L; i >= 1; --i) {
-        SpmmBranch br{e->dZ, e->dzi, nullptr, nullptr, e->dis_unit, nullptr, nullptr, nullptr};
+        SpmmBranch br{e->dZ, e->dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, gs, br, br, 0, e->loop_w, N, H, c.rpb_n);
+            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, br, br, 0, e->loop_w, N, H, spmm_rpb(H, false));
             return 0;
         }));
-        CAL_CHECK_LAUNCH("k_espmm(T)");
+        CAL_CHECK_LAUNCH("k_espmm(T)"); STAGE();
         const float* hin = e->h + (size_t)(i - 1) * NH;
         {
             GemmArgs a = gemm_args(H, H, N, true, false, 0);
             a.p[0].A = hin; a.p[0].B = e->dzi;
             a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 0);
             float* dst[1] = {e->G + e->o_conv_w[i - 1]};
-            RC(grad_gemm(c, a, 1, dst, fa, slab_off));
+            RC(grad_gemm(c, a, 1, dst, fa, slab_off)); STAGE();
         }
         {
             GemmArgs a = gemm_args(N, H, H, false, true, 0);
             a.p[0].A = e->dzi; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->dXh;
             a.p[0].aux = hin; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, i, N, 0);
-            a.p[0].dot_sum = bn_dsum(c, i); a.p[0].dot_prod = bn_dprod(c, i);
-            RC(launch_gemm(false, true, a, 1, st));
+            gemm_stats(c, a.p[0], N, H, bn_dsum(c, i), bn_dprod(c, i), true);
+            RC(launch_gemm(false, true, a, 1, st)); STAGE();
+            RC(flush_finals(c)); STAGE();
         }
         {
             BnBwdProb p{e->dXh, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i),
-                        i >= 2 ? e->arena + e->a_convb[i - 2] : nullptr};
+                        i >= 2 ? deferred(H, d_convb[i - 2]) : Acc()};
             RC(with_g(H, [&](auto g) {
                 constexpr int G = decltype(g)::value;
                 hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
                 return 0;
             }));
-            CAL_CHECK_LAUNCH("k_bn_bwd");
+            CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();
         }
     }
     // S. conv_feat weight and bn_feat affine gradients
@@ -620,40 +730,55 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         a.p[0].A = x0; a.p[0].B = e->dZ;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 0);
         float* dst[1] = {e->G + e->o_feat_w};
-        RC(grad_gemm(c, a, 1, dst, fa, slab_off));
+        RC(grad_gemm(c, a, 1, dst, fa, slab_off)); STAGE();
     }
     {
         GemmArgs a = gemm_args(N, F, H, false, true, 0);
         a.p[0].A = e->dZ; a.p[0].B = e->P + e->o_feat_w; a.p[0].C = nullptr;
         a.p[0].aux = x0; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, 0, N, 0);
         a.p[0].dot_sum = bn_dsum(c, 0); a.p[0].dot_prod = bn_dprod(c, 0);
-        RC(launch_gemm(false, true, a, 1, st));
+        {   // bn_feat's sums are only needed by the commit: keep the partial rows, no finalise launch
+            const int P0 = gemm_row_tiles(N);
+            if ((size_t)P0 * F * 2 > 4096) {
+                d_bn0.p = parts_alloc(c, (size_t)P0 * 2 * F); d_bn0.P = P0; d_bn0.stride = 2 * F;
+                a.p[0].parts = d_bn0.p;
+            }
+        }
+        RC(launch_gemm(false, true, a, 1, st)); STAGE();
     }
     // commits: fp64 arena -> fp32 gradients
     for (int k = 0; k < e->nbn; ++k) {
         const BNSlot& b = e->bn[k];
         const int wp = (b.width + 3) / 4 * 4;
+        if (k == 0 && d_bn0.p) {
+            commit_p(d_bn0.p + F, d_bn0.P, d_bn0.stride, b.gamma, F, 1.f);
+            commit_p(d_bn0.p, d_bn0.P, d_bn0.stride, b.beta, F, 1.f);
+            continue;
+        }
         commit(b.arena + 3 * wp, b.gamma, b.width, 1.f);   // d gamma = sum dyh * x_n
         commit(b.arena + 2 * wp, b.beta, b.width, 1.f);    // d beta  = sum dyh
     }
-    for (int i = 0; i < L; ++i) commit(e->a_convb[i], e->o_conv_b[i], H, 1.f);
-    commit(e->a_cb, e->o_cb, H, 1.f);
-    commit(e->a_ob, e->o_ob, H, 1.f);
-    commit(e->a_dwn, e->o_natt_w, H, 1.f);
-    commit(e->a_dwn, e->o_natt_w + H, H, -1.f);
-    commit(e->a_dwn + H, e->o_natt_b, 1, 1.f);
-    commit(e->a_dwn + H, e->o_natt_b + 1, 1, -1.f);
-    commit(e->a_dwe, e->o_eatt_w, 2 * H, 1.f);
-    commit(e->a_dwe, e->o_eatt_w + 2 * H, 2 * H, -1.f);
-    commit(e->a_dwe + 2 * H, e->o_eatt_b, 1, 1.f);
-    commit(e->a_dwe + 2 * H, e->o_eatt_b + 1, 1, -1.f);
+    for (int i = 0; i < L; ++i) {
+        if (!d_convb[i].p) { set_error("engine: missing bias-gradient partials"); return 2; }
+        commit_p(d_convb[i].p, d_convb[i].P, d_convb[i].stride, e->o_conv_b[i], H, 1.f);
+    }
+    commit_p(d_cb.p, d_cb.P, d_cb.stride, e->o_cb, H, 1.f);
+    commit_p(d_ob.p, d_ob.P, d_ob.stride, e->o_ob, H, 1.f);
+    commit_p(d_dwn.p, d_dwn.P, d_dwn.stride, e->o_natt_w, H, 1.f);
+    commit_p(d_dwn.p, d_dwn.P, d_dwn.stride, e->o_natt_w + H, H, -1.f);
+    commit_p(d_dwn.p + H, d_dwn.P, d_dwn.stride, e->o_natt_b, 1, 1.f);
+    commit_p(d_dwn.p + H, d_dwn.P, d_dwn.stride, e->o_natt_b + 1, 1, -1.f);
+    commit_p(d_dwe.p, d_dwe.P, d_dwe.stride, e->o_eatt_w, 2 * H, 1.f);
+    commit_p(d_dwe.p, d_dwe.P, d_dwe.stride, e->o_eatt_w + 2 * H, 2 * H, -1.f);
+    commit_p(d_dwe.p + 2 * H, d_dwe.P, d_dwe.stride, e->o_eatt_b, 1, 1.f);
+    commit_p(d_dwe.p + 2 * H, d_dwe.P, d_dwe.stride, e->o_eatt_b + 1, 1, -1.f);
     for (int hd = 0; hd < 3; ++hd) {
         commit(e->a_db1 + hd * H, e->o_fc1_b[hd], H, 1.f);
         commit(e->a_db2 + hd * C, e->o_fc2_b[hd], C, 1.f);
     }
     if (fa.nct > MAX_COMMITS) { set_error("engine: too many commit tasks"); return 2; }
-    hipLaunchKernelGGL(k_finish, dim3(16, fa.nst + fa.nct), dim3(256), 0, st, fa, e->arena, e->G);
-    CAL_CHECK_LAUNCH("k_finish");
+    hipLaunchKernelGGL(k_finish, dim3(64, fa.nst + fa.nct), dim3(256), 0, st, fa, e->G);
+    CAL_CHECK_LAUNCH("k_finish"); STAGE();
     return 0;
 }
 
@@ -677,11 +802,22 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     c.e = e; c.st = (hipStream_t)stream_; c.N = (int)N; c.B = (int)B; c.E = E;
     c.training = (mode & 1) ? 1 : 0;
     c.rpb_n = std::max(32, cdiv(N, 1024));
-    c.rpb_b = std::max(8, cdiv(B, 256));
+    c.rpb_b = std::max(32, cdiv(B, 64));
+    c.parts_off = 0;
+    c.fin.nt = 0;
     const int want_grad = (mode & 2) ? 1 : 0;
     CAL_REQUIRE(!want_grad || c.training, "backward needs a training-mode forward");
-    RC(engine_forward(c, x0, edge_index, batch, y, perm, wc, wo, wco, want_grad));
-    if (want_grad) RC(engine_backward(c, x0, batch));
+    g_stage = 0;
+    {
+        int rc = engine_forward(c, x0, edge_index, batch, y, perm, wc, wo, wco, want_grad);
+        if (rc == -12345) return 0;
+        if (rc) return rc;
+        if (want_grad) {
+            rc = engine_backward(c, x0, batch);
+            if (rc == -12345) return 0;
+            if (rc) return rc;
+        }
+    }
     if (mode & 4) {
         hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, c.st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
                            e->beta2, e->eps, e->wd, e->nparam);
@@ -691,6 +827,8 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     }
     return 0;
 }
+
+CAL_EXPORT int cal_engine_debug_stop(int k) { g_stop_after = k; return 0; }
 
 // Adam alone (after an external gradient all-reduce)
 CAL_EXPORT int cal_engine_adam(void* h, void* stream_) {

@@ -96,6 +96,10 @@ struct GemmProb {
     BNRef aux_bn;
     double* dot_sum;
     double* dot_prod;
+    // when non-null the two epilogue sums are written as one partial row per row tile,
+    // parts[(row_tile * 2 + {0,1}) * N + col], instead of being added atomically (k_stats_final
+    // sums them): hot-address fp64 atomics cost ~0.65 ns each chip-wide on MI355X
+    double* parts;
 };
 
 struct GemmArgs {
@@ -110,6 +114,7 @@ struct GemmArgs {
 int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStream_t stream);
 int splitk_for(int64_t M, int64_t N, int64_t K, int nbatch);
 void gemm_set_split(GemmArgs& a, int S);
+int gemm_row_tiles(int M);
 
 
 }  // namespace cal

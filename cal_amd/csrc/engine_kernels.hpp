@@ -19,18 +19,60 @@ struct CSR {
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
-// Sum `v` over the row-lanes of a block for column slot `cslot` (0..ncols-1) and add it to dst[col].
+// Destination of a per-column cross-row sum.  Two modes:
+//   atomic : dst[col] += t with one fp64 atomic per (block, column) -- fine for small launches;
+//   partial: parts[blockIdx.x * stride + col] = t, one plain store; k_stats_final (or the final
+//            commit) sums the rows.  Hot-address fp64 atomics run at only ~1.5 per ns chip-wide on
+//            MI355X, so the ~230-block node-level kernels use partial rows.
+struct Acc {
+    double* dst;
+    double* parts;
+    int stride;
+    __host__ __device__ Acc() : dst(nullptr), parts(nullptr), stride(0) {}
+    __host__ __device__ Acc(double* d) : dst(d), parts(nullptr), stride(0) {}
+    __host__ __device__ Acc(double* d, double* p, int s) : dst(d), parts(p), stride(s) {}
+    __host__ __device__ bool on() const { return dst != nullptr || parts != nullptr; }
+    __device__ __forceinline__ void add(int col, double t) const {
+        if (parts) parts[(size_t)blockIdx.x * stride + col] = t;
+        else atomicAdd(dst + col, t);
+    }
+};
+
+// Sum `v` over the row-lanes of a block for column slot `cslot` (0..ncols-1) and emit it for `col`.
 // lds: at least nrl * ncols doubles.  Must be called by every thread of the block.
 __device__ __forceinline__ void block_col_atomic(double v, int cslot, int rlane, int nrl, int ncols, bool valid,
-                                                 double* dst, int col, double* lds) {
+                                                 const Acc& dst, int col, double* lds) {
     lds[rlane * ncols + cslot] = valid ? v : 0.0;
     __syncthreads();
     if (rlane == 0 && valid) {
         double t = 0.0;
         for (int k = 0; k < nrl; ++k) t += lds[k * ncols + cslot];
-        atomicAdd(dst + col, t);
+        dst.add(col, t);
     }
     __syncthreads();
+}
+
+// Sum the rows of partial buffers into their final destination.  grid (ceil(n/16), ntasks).
+struct FinalTask { const double* parts; int P; int stride; int n; double* dst; };
+struct FinalArgs { FinalTask t[8]; int nt; };
+__global__ void __launch_bounds__(256) k_stats_final(const FinalArgs fa) {
+    __shared__ double red[256];
+    const FinalTask t = fa.t[blockIdx.y];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < t.n) {
+        int p = pl;
+        for (; p + 16 < t.P; p += 32) { s0 += t.parts[(size_t)p * t.stride + c]; s1 += t.parts[(size_t)(p + 16) * t.stride + c]; }
+        if (p < t.P) s0 += t.parts[(size_t)p * t.stride + c];
+    }
+    red[threadIdx.x] = s0 + s1;
+    __syncthreads();
+    if (pl == 0 && c < t.n) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k * 16 + (threadIdx.x & 15)];
+        t.dst[c] = tot;
+    }
 }
 
 __global__ void k_zero_f64(double* __restrict__ a, int64_t n) {
@@ -42,7 +84,7 @@ __global__ void k_zero_f64(double* __restrict__ a, int64_t n) {
 // column statistics of a raw matrix (the bn_feat input, model.py:90)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_colstats(const float* __restrict__ x, int N, int W, int tc, int rows_per_block,
-                                                  double* __restrict__ sum, double* __restrict__ sq) {
+                                                  const Acc sum, const Acc sq) {
     __shared__ double lds[256];
     const int nrl = 256 / tc, c = threadIdx.x % tc, rl = threadIdx.x / tc;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
@@ -86,9 +128,8 @@ struct SpmmBranch {
     const float* bias;     // null -> none
     const float* w;        // per-edge weight (edge-id order) or null (all ones)
     const float* dis;      // deg^-1/2 per node
-    double* st_sum;        // column statistics of the output (next BatchNorm) or null
-    double* st_sq;
-    double* colsum;        // plain column sums of the output (unused by the forward) or null
+    Acc st_sum;            // column statistics of the output (next BatchNorm) or off
+    Acc st_sq;
 };
 
 template <int VEC, int G>
@@ -100,7 +141,7 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch b0,
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
     using V = Vec<VEC>;
-    const bool want = br.st_sum != nullptr;
+    const bool want = br.st_sum.on();
     for (int c = l * VEC; c - l * VEC < H; c += G * VEC) {
         const bool cok = c < H;
         double s1[VEC], s2[VEC];
@@ -157,9 +198,8 @@ template <int VEC, int G>
 __global__ void __launch_bounds__(256) k_node_att_fwd(const float* __restrict__ x, const float* __restrict__ Wn,
                                                       const float* __restrict__ bn, const float* __restrict__ We,
                                                       float* __restrict__ anode, float* __restrict__ pq,
-                                                      double* __restrict__ stc_sum, double* __restrict__ stc_sq,
-                                                      double* __restrict__ sto_sum, double* __restrict__ sto_sq,
-                                                      int N, int H, int rows_per_block) {
+                                                      const Acc stc_sum, const Acc stc_sq, const Acc sto_sum,
+                                                      const Acc sto_sq, int N, int H, int rows_per_block) {
     __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
     constexpr int RPB = 256 / G;
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
@@ -296,10 +336,8 @@ __global__ void __launch_bounds__(256) k_pool2(const float* __restrict__ hc, con
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_readout_prep(const float* __restrict__ pooled, const int64_t* __restrict__ perm,
                                                       int* __restrict__ iperm, float* __restrict__ xco, int B, int H,
-                                                      int tc, int rows_per_block, double* __restrict__ s_c,
-                                                      double* __restrict__ q_c, double* __restrict__ s_o,
-                                                      double* __restrict__ q_o, double* __restrict__ s_co,
-                                                      double* __restrict__ q_co) {
+                                                      int tc, int rows_per_block, const Acc s_c, const Acc q_c,
+                                                      const Acc s_o, const Acc q_o, const Acc s_co, const Acc q_co) {
     __shared__ double lds[256];
     const int nrl = 256 / tc, cl = threadIdx.x % tc, rl = threadIdx.x / tc;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(B, r0 + rows_per_block);
@@ -311,6 +349,7 @@ __global__ void __launch_bounds__(256) k_readout_prep(const float* __restrict__ 
         const bool cok = c < H;
         double a1 = 0, a2 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0;
         if (cok)
+#pragma unroll 4
             for (int r = r0 + rl; r < r1; r += nrl) {
                 const float vc = pc[(size_t)r * H + c], vo = po[(size_t)r * H + c];
                 const float vco = pc[(size_t)perm[r] * H + c] + vo;
@@ -381,11 +420,20 @@ __global__ void __launch_bounds__(256) k_loss(const float* __restrict__ z, const
     }
     if (want_grad) {
         __syncthreads();
-        for (int t = threadIdx.x; t < 3 * C; t += 256) {
-            const int hd = t / C, k = t % C;
-            double s = 0.0;
-            for (int b = 0; b < B; ++b) s += (double)dz[((size_t)hd * B + b) * C + k];
-            db2[t] = s;
+        // column sums of dz: (3C columns) x (256 / 3C row lanes), then a serial LDS tail per column
+        const int nc = 3 * C, nl = 256 / nc;
+        const int cidx = threadIdx.x % nc, pl = threadIdx.x / nc;
+        double sacc = 0.0;
+        if (pl < nl) {
+            const int hd = cidx / C, k = cidx % C;
+            for (int b = pl; b < B; b += nl) sacc += (double)dz[((size_t)hd * B + b) * C + k];
+        }
+        red[threadIdx.x] = sacc;
+        __syncthreads();
+        if (threadIdx.x < nc) {
+            double tsum = 0.0;
+            for (int q = 0; q < nl; ++q) tsum += red[q * nc + threadIdx.x];
+            db2[threadIdx.x] = tsum;
         }
     }
 }
@@ -403,7 +451,7 @@ struct BnBwdProb {
     BNRef bn;
     const double* dot_sum;
     const double* dot_prod;
-    double* colsum;      // column sums of dy (bias gradient of the producing layer) or null
+    Acc colsum;          // column sums of dy (bias gradient of the producing layer) or off
 };
 
 template <int VEC, int G>
@@ -445,7 +493,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd(const BnBwdProb p0, const BnBwdP
                 if constexpr (VEC == 4) ov.v = make_float4(o[0], o[1], o[2], o[3]); else ov.v = o[0];
                 ov.st(p.dy + (size_t)r * W + c);
             }
-        if (p.colsum) {
+        if (p.colsum.on()) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
                 block_col_atomic(cs[j], l * VEC + j, grp, RPB, G * VEC, cok, p.colsum, c + j, lds);
@@ -491,14 +539,14 @@ template <int VEC, int G>
 __global__ void __launch_bounds__(256) k_pool_bwd_relu(const float* __restrict__ dpool, const int64_t* __restrict__ batch,
                                                        const float* __restrict__ hc, const float* __restrict__ ho,
                                                        float* __restrict__ dzc, float* __restrict__ dzo,
-                                                       double* __restrict__ dbc, double* __restrict__ dbo, int N, int B,
+                                                       const Acc dbc, const Acc dbo, int N, int B,
                                                        int H, int rows_per_block) {
     __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
     constexpr int RPB = 256 / G;
     const int brn = blockIdx.y;
     const float* h = brn ? ho : hc;
     float* dz = brn ? dzo : dzc;
-    double* db = brn ? dbo : dbc;
+    const Acc db = brn ? dbo : dbc;
     const float* dp = dpool + (size_t)brn * B * H;
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
@@ -527,29 +575,28 @@ __global__ void __launch_bounds__(256) k_pool_bwd_relu(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 // SDDMM for both branches: gn[br,e] = <dZ_br[col_e], z_br[row_e]>, gself[br,v] = <dZ_br[v], z_br[v]>
 // ------------------------------------------------------------------------------------------------
-template <int VEC, int G>
-__global__ void __launch_bounds__(256) k_sddmm2(const CSR gd, const float* __restrict__ dzc, const float* __restrict__ dzo,
+// 8 lanes per item; items 0..E-1 are the input edges (self loops skipped), E..E+N-1 the added loops.
+__global__ void __launch_bounds__(256) k_sddmm2(const int* __restrict__ row32, const int* __restrict__ col32,
+                                                const float* __restrict__ dzc, const float* __restrict__ dzo,
                                                 const float* __restrict__ zc, const float* __restrict__ zo,
                                                 float* __restrict__ gn, float* __restrict__ gself, int N, int64_t E, int H) {
-    constexpr int RPB = 256 / G;
     const int brn = blockIdx.y;
     const float* dz = brn ? dzo : dzc;
     const float* z = brn ? zo : zc;
-    float* gne = gn + (size_t)brn * E;
-    float* gs = gself + (size_t)brn * N;
-    const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int i = blockIdx.x * RPB + grp;
-    if (i >= N) return;
-    using V = Vec<VEC>;
-    const int p0 = gd.ptr[i], p1 = gd.ptr[i + 1];
-    for (int s = p0; s <= p1; ++s) {
-        const int j = s < p1 ? gd.nbr[s] : i;
-        float p = 0.f;
-        for (int c = l * VEC; c < H; c += G * VEC)
-            p += V::ld(dz + (size_t)i * H + c).dot(V::ld(z + (size_t)j * H + c));
-        p = group_sum<G>(p);
-        if (l == 0) { if (s < p1) gne[gd.eid[s]] = p; else gs[i] = p; }
+    const int64_t item = (int64_t)blockIdx.x * 32 + threadIdx.x / 8;
+    const int l = threadIdx.x % 8;
+    if (item >= E + N) return;
+    int r, c;
+    if (item < E) { r = row32[item]; c = col32[item]; if (r == c) return; }
+    else { r = c = (int)(item - E); }
+    float p = 0.f;
+    for (int k = l * 4; k < H; k += 32) {
+        const float4 a = *reinterpret_cast<const float4*>(dz + (size_t)c * H + k);
+        const float4 b = *reinterpret_cast<const float4*>(z + (size_t)r * H + k);
+        p = fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, fmaf(a.x, b.x, p))));
     }
+    p = group_sum<8>(p);
+    if (l == 0) { if (item < E) gn[(size_t)brn * E + item] = p; else gself[(size_t)brn * N + (item - E)] = p; }
 }
 
 // d deg for both branches (gcn_conv.py:63-70 differentiated); 8 lanes per node
@@ -604,9 +651,9 @@ struct AttBwdArgs {
     const float* Wn; const float* We; const float* dl;
     CSR gs, gd;
     float* dZ;
-    double* dbias;     // [H] bias gradient of the last backbone conv (null when there is none)
-    double* dWn;       // [H] (+1: d bn0 at [H])
-    double* dWe;       // [2H] (+1: d be0 at [2H])
+    Acc dbias;         // [H] bias gradient of the last backbone conv (off when there is none)
+    Acc dWn;           // [H] (+1: d bn0 at [H])
+    Acc dWe;           // [2H] (+1: d be0 at [2H])
 };
 
 template <int VEC, int G>
@@ -688,7 +735,7 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        if (a.dbias) block_col_atomic(cs_b[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dbias, c + j, lds);
+        if (a.dbias.on()) block_col_atomic(cs_b[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dbias, c + j, lds);
         block_col_atomic(cs_n[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dWn, c + j, lds);
         block_col_atomic(cs_p[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dWe, c + j, lds);
         block_col_atomic(cs_q[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dWe, H + c + j, lds);
@@ -698,8 +745,8 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
     if (threadIdx.x == 0) {
         double t0 = 0.0, t1 = 0.0;
         for (int k = 0; k < RPB; ++k) { t0 += sc_lds[0][k]; t1 += sc_lds[1][k]; }
-        atomicAdd(a.dWn + H, t0);
-        atomicAdd(a.dWe + 2 * H, t1);
+        a.dWn.add(H, t0);
+        a.dWe.add(2 * H, t1);
     }
 }
 
@@ -709,7 +756,7 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
 // corrected second moment, optional L2 weight decay added to the gradient).
 // ------------------------------------------------------------------------------------------------
 struct SlabTask { const float* slabs; float* dst; int n; int S; };
-struct CommitTask { int src; int dst; int n; float scale; };   // arena offset -> flat-gradient offset
+struct CommitTask { const double* src; int P; int stride; int dst; int n; float scale; };   // (partial rows of) fp64 sums -> flat-gradient offset
 
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        float* __restrict__ step, const float* __restrict__ lr_ptr, float beta1, float beta2, float eps,

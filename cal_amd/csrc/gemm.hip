@@ -6,14 +6,17 @@
 //
 // Workgroup tile 64x64, K step 32, 4 waves (2x2), one 32x32 accumulator per wave.  Both operands
 // are staged in LDS k-major (As[k][i], Bs[k][j]) so each MFMA operand fetch is one conflict-free
-// ds_read_b32 of 32 consecutive floats per half-wave; the next K tile is prefetched into registers
-// while the current one feeds the MFMAs.  64x64 tiles keep >= 230 workgroups in flight for the
-// config-2 shape [7315,128]x[128,128] (256 CUs).
+// ds_read_b32 of 32 consecutive floats per half-wave.  Two LDS stages, one barrier per K tile:
+// the global loads of tile t+1 are issued raw into registers, then the 32 operand reads and the 16
+// MFMAs of tile t run, and only then are the prefetched registers transformed and stored (the
+// sched_barriers keep hipcc from waiting on them early).  64x64 tiles keep >= 230 workgroups in
+// flight for the config-2 shape [7315,128]x[128,128] (256 CUs).
 //
 // Fusions (engine.hpp): BatchNorm-apply (+ node-attention row scale) on either operand while it is
 // staged (model.py:90,94,112-113,127-131 -- BN outputs are never materialised), bias + ReLU
 // epilogue, per-column sum / sum-of-squares of the output (the next BatchNorm's batch statistics)
-// and the BN-backward column sums, accumulated in fp64 with one atomic per column per workgroup.
+// and the BN-backward column sums, pre-reduced per workgroup in fp64 and either written as one
+// partial row per row-tile (large launches; finished by k_stats_final) or added atomically (small).
 #include "engine.hpp"
 
 namespace cal {
@@ -25,91 +28,117 @@ constexpr int LDT = 65;   // LDS row stride (floats) for tiles filled by transpo
 constexpr int LDD = 68;   // LDS row stride for tiles filled by direct 16B stores
 constexpr int XMAX = 512; // max feature width of a BN-transformed k-contiguous operand
 
-// Operand tile loader.  The operand is logically T[mn][k] (mn = row of A / column of B).
-//   KC = true : memory is [mn][k] row-major (k contiguous)  -> transposing store
-//   KC = false: memory is [k][mn] row-major (mn contiguous) -> direct store
-// sc/sh: LDS arrays with the BN scale/shift of the feature (storage column) axis, indexed by
-// (k - kb) for KC and by the tile-local mn for !KC; null when the operand has no BN transform.
-template <bool KC>
-struct Loader {
-    static constexpr int LD = KC ? LDT : LDD;
-    float4 r[2];
-    __device__ __forceinline__ void load(const float* __restrict__ p, int ld, int mn0, int mn_end, int k0, int k_end,
-                                         int kb, bool vec, const Xform& xf, const float* sc, const float* sh) {
+// Operand tiles.  The operand is logically T[mn][k] (mn = row of A / column of B).
+//   KC = true : memory is [mn][k] row-major (k contiguous)  -> transposing LDS store
+//   KC = false: memory is [k][mn] row-major (mn contiguous) -> direct 16 B LDS store
+// FULL = interior tile: unconditional 16 B loads.  Otherwise every element is loaded from a clamped
+// (always valid) address and zeroed at store time -- no divergent control flow either way.
+template <bool KC, bool FULL>
+__device__ __forceinline__ void tile_load(float4 (&r)[2], const float* __restrict__ p, int ld, int mn0, int mn_end,
+                                          int k0, int k_end) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            int f = threadIdx.x + q * 256;
-            int mn, k;
-            if (KC) { mn = f / (BK / 4); k = (f % (BK / 4)) * 4; }
-            else { k = f / (BM / 4); mn = (f % (BM / 4)) * 4; }
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            bool ok[4] = {false, false, false, false};
-            if (KC) {
-                int gm = mn0 + mn;
-                if (gm < mn_end) {
-                    const float* src = p + (size_t)gm * ld + k0 + k;
-                    if (vec && k0 + k + 3 < k_end) {
-                        float4 t = *reinterpret_cast<const float4*>(src);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                        ok[0] = ok[1] = ok[2] = ok[3] = true;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (k0 + k + j < k_end) { v[j] = src[j]; ok[j] = true; }
-                    }
-                    float rs = xf.rs ? xf.rs[(size_t)gm * xf.rs_stride] : 1.f;
-                    if (xf.rs || sc) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (ok[j]) {
-                            float t = rs * v[j];
-                            v[j] = sc ? fmaf(t, sc[k0 + k + j - kb], sh[k0 + k + j - kb]) : t;
-                        }
-                    }
-                }
-            } else {
-                int gk = k0 + k;
-                if (gk < k_end) {
-                    const float* src = p + (size_t)gk * ld + mn0 + mn;
-                    if (vec && mn0 + mn + 3 < mn_end) {
-                        float4 t = *reinterpret_cast<const float4*>(src);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                        ok[0] = ok[1] = ok[2] = ok[3] = true;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (mn0 + mn + j < mn_end) { v[j] = src[j]; ok[j] = true; }
-                    }
-                    float rs = xf.rs ? xf.rs[(size_t)gk * xf.rs_stride] : 1.f;
-                    if (xf.rs || sc) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) if (ok[j]) {
-                            float t = rs * v[j];
-                            v[j] = sc ? fmaf(t, sc[mn + j], sh[mn + j]) : t;
-                        }
-                    }
-                }
-            }
-            r[q] = make_float4(v[0], v[1], v[2], v[3]);
+    for (int q = 0; q < 2; ++q) {
+        const int f = threadIdx.x + q * 256;
+        const int mn = KC ? f / (BK / 4) : (f % (BM / 4)) * 4;
+        const int k = KC ? (f % (BK / 4)) * 4 : f / (BM / 4);
+        if (FULL) {
+            r[q] = KC ? *reinterpret_cast<const float4*>(p + (size_t)(mn0 + mn) * ld + k0 + k)
+                      : *reinterpret_cast<const float4*>(p + (size_t)(k0 + k) * ld + mn0 + mn);
+        } else if (KC) {
+            const float* row = p + (size_t)min(mn0 + mn, mn_end - 1) * ld;
+            const int kl = k_end - 1;
+            r[q] = make_float4(row[min(k0 + k, kl)], row[min(k0 + k + 1, kl)], row[min(k0 + k + 2, kl)], row[min(k0 + k + 3, kl)]);
+        } else {
+            const float* row = p + (size_t)min(k0 + k, k_end - 1) * ld;
+            const int ml = mn_end - 1;
+            r[q] = make_float4(row[min(mn0 + mn, ml)], row[min(mn0 + mn + 1, ml)], row[min(mn0 + mn + 2, ml)], row[min(mn0 + mn + 3, ml)]);
         }
     }
-    __device__ __forceinline__ void store(float* __restrict__ s) const {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            int f = threadIdx.x + q * 256;
-            if (KC) {
-                int mn = f / (BK / 4), k = (f % (BK / 4)) * 4;
-                s[(k + 0) * LD + mn] = r[q].x; s[(k + 1) * LD + mn] = r[q].y;
-                s[(k + 2) * LD + mn] = r[q].z; s[(k + 3) * LD + mn] = r[q].w;
-            } else {
-                int k = f / (BM / 4), mn = (f % (BM / 4)) * 4;
-                *reinterpret_cast<float4*>(s + k * LD + mn) = r[q];
-            }
-        }
-    }
-};
+}
 
-template <bool A_KC, bool B_KC>
+// XF: 0 = plain, 1 = BN scale/shift on the feature axis, 2 = per-storage-row scale, then BN.
+// sc/sh: LDS tables indexed by (k - kb) for KC operands and by the tile-local mn for !KC ones.
+template <bool KC, bool FULL, int XF>
+__device__ __forceinline__ void tile_store(const float4 (&r)[2], float* __restrict__ s, int mn0, int mn_end, int k0,
+                                           int k_end, int kb, const float* __restrict__ rsp, int rs_stride,
+                                           const float* sc, const float* sh) {
+    constexpr int LD = KC ? LDT : LDD;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int f = threadIdx.x + q * 256;
+        const int mn = KC ? f / (BK / 4) : (f % (BM / 4)) * 4;
+        const int k = KC ? (f % (BK / 4)) * 4 : f / (BM / 4);
+        float v[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
+        if (XF > 0) {
+            float rs = 1.f;
+            if (XF == 2) rs = rsp[(size_t)(KC ? min(mn0 + mn, mn_end - 1) : min(k0 + k, k_end - 1)) * rs_stride];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int fi = KC ? (k0 + k + j - kb) : (mn + j);     // feature index into the tables
+                v[j] = fmaf(XF == 2 ? rs * v[j] : v[j], sc[fi], sh[fi]);
+            }
+        }
+        if (!FULL) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = KC ? (mn0 + mn < mn_end && k0 + k + j < k_end) : (k0 + k < k_end && mn0 + mn + j < mn_end);
+                v[j] = ok ? v[j] : 0.f;
+            }
+        }
+        if (KC) {
+            s[(k + 0) * LD + mn] = v[0]; s[(k + 1) * LD + mn] = v[1];
+            s[(k + 2) * LD + mn] = v[2]; s[(k + 3) * LD + mn] = v[3];
+        } else {
+            *reinterpret_cast<float4*>(s + k * LD + mn) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC, int XA, int XB, bool FULL>
+__device__ __forceinline__ void gemm_kloop(const GemmArgs& a, const GemmProb& pr, float* As, float* Bs, int m0, int n0,
+                                           int kb, int ke, const float* sca, const float* sha, const float* scb,
+                                           const float* shb, f32x16& acc, int wm, int wn, int li, int lk) {
+    constexpr int LDA = A_KC ? LDT : LDD, LDB = B_KC ? LDT : LDD;
+    constexpr int SA = BK * LDA, SB = BK * LDB;
+    const int M = a.M, N = a.N;
+    float4 ra[2], rb[2];
+    tile_load<A_KC, FULL>(ra, pr.A, a.lda, m0, M, kb, ke);
+    tile_load<B_KC, FULL>(rb, pr.B, a.ldb, n0, N, kb, ke);
+    tile_store<A_KC, FULL, XA>(ra, As, m0, M, kb, ke, kb, pr.xa.rs, pr.xa.rs_stride, sca, sha);
+    tile_store<B_KC, FULL, XB>(rb, Bs, n0, N, kb, ke, kb, pr.xb.rs, pr.xb.rs_stride, scb, shb);
+    __syncthreads();
+    int st = 0;
+    for (int k0 = kb; k0 < ke; k0 += BK) {
+        const bool more = k0 + BK < ke;
+        if (more) {
+            tile_load<A_KC, FULL>(ra, pr.A, a.lda, m0, M, k0 + BK, ke);
+            tile_load<B_KC, FULL>(rb, pr.B, a.ldb, n0, N, k0 + BK, ke);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float* as = As + st * SA + wm + li;
+        const float* bs = Bs + st * SB + wn + li;
+        float av[BK / 2], bv[BK / 2];
+#pragma unroll
+        for (int i = 0; i < BK / 2; ++i) {
+            av[i] = as[(2 * i + lk) * LDA];
+            bv[i] = bs[(2 * i + lk) * LDB];
+        }
+#pragma unroll
+        for (int i = 0; i < BK / 2; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            tile_store<A_KC, FULL, XA>(ra, As + (st ^ 1) * SA, m0, M, k0 + BK, ke, kb, pr.xa.rs, pr.xa.rs_stride, sca, sha);
+            tile_store<B_KC, FULL, XB>(rb, Bs + (st ^ 1) * SB, n0, N, k0 + BK, ke, kb, pr.xb.rs, pr.xb.rs_stride, scb, shb);
+        }
+        __syncthreads();
+        st ^= 1;
+    }
+}
+
+template <bool A_KC, bool B_KC, int XA, int XB>
 __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) float As[BK * Loader<A_KC>::LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * Loader<B_KC>::LD];
+    __shared__ __attribute__((aligned(16))) float As[2 * BK * (A_KC ? LDT : LDD)];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * (B_KC ? LDT : LDD)];
     __shared__ float xsc[2][A_KC || B_KC ? XMAX : BM];
     __shared__ float xsh[2][A_KC || B_KC ? XMAX : BM];
     __shared__ double red[4][2][32];
@@ -123,51 +152,36 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int li = lane & 31, lk = lane >> 5;
+    // interior tile: no bounds handling, unconditional 16 B loads
+    const bool full = vecA && vecB && m0 + BM <= M && n0 + BN <= N && ((ke - kb) % BK) == 0;
 
-    // BN scale/shift of the transformed operands into LDS; one block also updates running stats
-    const float *sca = nullptr, *sha = nullptr, *scb = nullptr, *shb = nullptr;
-    if (pr.xa.has_bn) {
+    // BN scale/shift tables of the transformed operands; one block also updates the running stats
+    if (XA > 0) {
         const int cnt = A_KC ? (ke - kb) : min(BM, M - m0);
         const int c0 = A_KC ? kb : m0;
         for (int t = threadIdx.x; t < cnt; t += 256) {
             bn_scale_shift(pr.xa.bn, c0 + t, xsc[0][t], xsh[0][t]);
             if (pr.xa.bn.update && blockIdx.y == 0 && split == 0 && (A_KC ? blockIdx.x == 0 : true)) bn_update_running(pr.xa.bn, c0 + t);
         }
-        sca = xsc[0]; sha = xsh[0];
+        if (!A_KC) for (int t = cnt + threadIdx.x; t < BM; t += 256) { xsc[0][t] = 0.f; xsh[0][t] = 0.f; }
     }
-    if (pr.xb.has_bn) {
+    if (XB > 0) {
         const int cnt = B_KC ? (ke - kb) : min(BN, N - n0);
         const int c0 = B_KC ? kb : n0;
         for (int t = threadIdx.x; t < cnt; t += 256) {
             bn_scale_shift(pr.xb.bn, c0 + t, xsc[1][t], xsh[1][t]);
             if (pr.xb.bn.update && blockIdx.x == 0 && split == 0 && (B_KC ? blockIdx.y == 0 : true)) bn_update_running(pr.xb.bn, c0 + t);
         }
-        scb = xsc[1]; shb = xsh[1];
+        if (!B_KC) for (int t = cnt + threadIdx.x; t < BN; t += 256) { xsc[1][t] = 0.f; xsh[1][t] = 0.f; }
     }
-    if (pr.xa.has_bn || pr.xb.has_bn) __syncthreads();
+    if (XA > 0 || XB > 0) __syncthreads();
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    Loader<A_KC> la;
-    Loader<B_KC> lb;
-    la.load(pr.A, a.lda, m0, M, kb, ke, kb, vecA, pr.xa, sca, sha);
-    lb.load(pr.B, a.ldb, n0, N, kb, ke, kb, vecB, pr.xb, scb, shb);
-    for (int k0 = kb; k0 < ke; k0 += BK) {
-        la.store(As);
-        lb.store(Bs);
-        __syncthreads();
-        if (k0 + BK < ke) {
-            la.load(pr.A, a.lda, m0, M, k0 + BK, ke, kb, vecA, pr.xa, sca, sha);
-            lb.load(pr.B, a.ldb, n0, N, k0 + BK, ke, kb, vecB, pr.xb, scb, shb);
-        }
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float av = As[(kk + lk) * Loader<A_KC>::LD + wm + li];
-            float bv = Bs[(kk + lk) * Loader<B_KC>::LD + wn + li];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-        }
-        __syncthreads();
+    if (ke > kb) {
+        if (full) gemm_kloop<A_KC, B_KC, XA, XB, true>(a, pr, As, Bs, m0, n0, kb, ke, xsc[0], xsh[0], xsc[1], xsh[1], acc, wm, wn, li, lk);
+        else gemm_kloop<A_KC, B_KC, XA, XB, false>(a, pr, As, Bs, m0, n0, kb, ke, xsc[0], xsh[0], xsc[1], xsh[1], acc, wm, wn, li, lk);
     }
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int col = n0 + wn + li;
@@ -175,20 +189,28 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
     const float bv = (pr.bias && cok) ? pr.bias[col] : 0.f;
     const bool want_st = pr.st_sum != nullptr, want_dot = pr.dot_sum != nullptr;
     float amean = 0.f, arstd = 0.f;
-    if (want_dot && cok && pr.has_aux) bn_mean_rstd(pr.aux_bn, col, amean, arstd);
+    float aux[16];
+    if (want_dot && cok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk, M - 1);
+            float x = pr.aux[(size_t)row * N + col];
+            if (pr.aux_rs) x *= pr.aux_rs[(size_t)row * pr.aux_rs_stride];
+            aux[r] = x;
+        }
+        bn_mean_rstd(pr.aux_bn, col, amean, arstd);
+    }
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (row < M && cok) {
             float v = acc[r] + bv;
             if (a.relu) v = fmaxf(v, 0.f);
             if (C) C[(size_t)row * a.ldc + col] = v;
             if (want_st) { s1 += (double)v; s2 += (double)v * (double)v; }
             if (want_dot) {
-                float x = pr.aux[(size_t)row * N + col];
-                if (pr.aux_rs) x *= pr.aux_rs[(size_t)row * pr.aux_rs_stride];
-                float xn = (x - amean) * arstd;
+                const float xn = (aux[r] - amean) * arstd;
                 s1 += (double)v;
                 s2 += (double)v * (double)xn;
             }
@@ -200,12 +222,15 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
         if (lk == 0) { red[wave][0][li] = s1; red[wave][1][li] = s2; }
         __syncthreads();
         if (wave < 2 && lk == 0 && cok) {      // waves 0,1 own columns wn = 0 / 32; add the wm = 32 partner
-            double t1 = red[wave][0][li] + red[wave + 2][0][li];
-            double t2 = red[wave][1][li] + red[wave + 2][1][li];
-            double* d1 = want_st ? pr.st_sum : pr.dot_sum;
-            double* d2 = want_st ? pr.st_sq : pr.dot_prod;
-            atomicAdd(d1 + col, t1);
-            atomicAdd(d2 + col, t2);
+            const double t1 = red[wave][0][li] + red[wave + 2][0][li];
+            const double t2 = red[wave][1][li] + red[wave + 2][1][li];
+            if (pr.parts) {                     // one partial row per row tile: [gridDim.x][2][N]
+                pr.parts[((size_t)blockIdx.x * 2 + 0) * N + col] = t1;
+                pr.parts[((size_t)blockIdx.x * 2 + 1) * N + col] = t2;
+            } else {
+                atomicAdd((want_st ? pr.st_sum : pr.dot_sum) + col, t1);
+                atomicAdd((want_st ? pr.st_sq : pr.dot_prod) + col, t2);
+            }
         }
     }
 }
@@ -221,33 +246,63 @@ __global__ void k_splitk_reduce(const float* __restrict__ part, float* __restric
     out[i] = accumulate ? out[i] + (s0 + s1) : (s0 + s1);
 }
 
+int gemm_row_tiles(int M) { return cdiv(M, BM); }
+
+template <bool A_KC, bool B_KC, int XA, int XB>
+static void launch_one(const GemmArgs& a, dim3 grid, int vecA, int vecB, hipStream_t stream) {
+    hipLaunchKernelGGL((k_gemm<A_KC, B_KC, XA, XB>), grid, dim3(256), 0, stream, a, vecA, vecB);
+}
+
 int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStream_t stream) {
     if (a.M == 0 || a.N == 0 || nbatch == 0) return 0;
     int vecA = (a.lda % 4 == 0), vecB = (a.ldb % 4 == 0);
+    const bool a_kc = !transA, b_kc = transB;
+    int xa = -1, xb = -1;
     for (int b = 0; b < nbatch; ++b) {
         vecA = vecA && aligned16(a.p[b].A);
         vecB = vecB && aligned16(a.p[b].B);
-        const bool a_kc = !transA, b_kc = transB;
-        if ((a.p[b].xa.has_bn && a_kc) || (a.p[b].xb.has_bn && b_kc)) {
+        const int ma = a.p[b].xa.has_bn ? (a.p[b].xa.rs ? 2 : 1) : 0, mb = a.p[b].xb.has_bn ? (a.p[b].xb.rs ? 2 : 1) : 0;
+        if ((a.p[b].xa.rs && !a.p[b].xa.has_bn) || (a.p[b].xb.rs && !a.p[b].xb.has_bn)) { set_error("launch_gemm: row scale without BN is not instantiated"); return 2; }
+        if ((xa >= 0 && xa != ma) || (xb >= 0 && xb != mb)) { set_error("launch_gemm: mixed operand transforms in one batch"); return 2; }
+        xa = ma; xb = mb;
+        if ((ma && a_kc) || (mb && b_kc)) {
             if (a.kchunk > XMAX) { set_error("launch_gemm: BN-transformed operand wider than %d", XMAX); return 2; }
         }
     }
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), nbatch * a.nsplit);
-    if (!transA && !transB) hipLaunchKernelGGL((k_gemm<true, false>), grid, dim3(256), 0, stream, a, vecA, vecB);
-    else if (!transA && transB) hipLaunchKernelGGL((k_gemm<true, true>), grid, dim3(256), 0, stream, a, vecA, vecB);
-    else if (transA && !transB) hipLaunchKernelGGL((k_gemm<false, false>), grid, dim3(256), 0, stream, a, vecA, vecB);
-    else hipLaunchKernelGGL((k_gemm<false, true>), grid, dim3(256), 0, stream, a, vecA, vecB);
+    bool ok = true;
+    if (a_kc && !b_kc) {          // NN
+        if (xb != 0) ok = false;
+        else if (xa == 0) launch_one<true, false, 0, 0>(a, grid, vecA, vecB, stream);
+        else if (xa == 1) launch_one<true, false, 1, 0>(a, grid, vecA, vecB, stream);
+        else launch_one<true, false, 2, 0>(a, grid, vecA, vecB, stream);
+    } else if (a_kc && b_kc) {    // NT
+        if (xb != 0 || xa == 2) ok = false;
+        else if (xa == 0) launch_one<true, true, 0, 0>(a, grid, vecA, vecB, stream);
+        else launch_one<true, true, 1, 0>(a, grid, vecA, vecB, stream);
+    } else if (!a_kc && !b_kc) {  // TN
+        if (xb == 0 && xa == 0) launch_one<false, false, 0, 0>(a, grid, vecA, vecB, stream);
+        else if (xb == 0 && xa == 1) launch_one<false, false, 1, 0>(a, grid, vecA, vecB, stream);
+        else if (xb == 0 && xa == 2) launch_one<false, false, 2, 0>(a, grid, vecA, vecB, stream);
+        else if (xb == 1 && xa == 0) launch_one<false, false, 0, 1>(a, grid, vecA, vecB, stream);
+        else ok = false;
+    } else {                      // TT
+        if (xa != 0 || xb != 0) ok = false;
+        else launch_one<false, true, 0, 0>(a, grid, vecA, vecB, stream);
+    }
+    if (!ok) { set_error("launch_gemm: operand-transform combination (%d,%d) not instantiated for this layout", xa, xb); return 2; }
     CAL_CHECK_LAUNCH("k_gemm");
     return 0;
 }
 
+// split-K factor for a weight-gradient GEMM: aim at ~256 workgroups, >= 4 K tiles per slice
 int splitk_for(int64_t M, int64_t N, int64_t K, int nbatch) {
     int64_t tiles = (int64_t)cdiv(M, BM) * cdiv(N, BN) * nbatch;
-    if (tiles >= 128 || K <= 4 * BK) return 1;
-    int64_t s = 512 / tiles;
-    int64_t maxs = K / (2 * BK);
+    if (tiles >= 128 || K <= 8 * BK) return 1;
+    int64_t s = 256 / tiles;
+    int64_t maxs = K / (4 * BK);
     if (s > maxs) s = maxs;
-    if (s > 256) s = 256;
+    if (s > 128) s = 128;
     return (int)(s < 1 ? 1 : s);
 }
 

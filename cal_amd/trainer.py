@@ -50,6 +50,28 @@ class _Captured:
     __slots__ = ("graph", "perm", "stats")
 
 
+class _PinnedRing:
+    """Pinned staging buffers for the per-step permutation upload: a pageable-memory H2D copy is
+    synchronous and would serialise the host with the previous step's GPU work."""
+
+    def __init__(self, n: int, slots: int = 8):
+        self.bufs = [torch.empty(n, dtype=torch.long).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.i = 0
+
+    def stage(self, perm: torch.Tensor, dst: torch.Tensor):
+        k = self.i
+        self.i = (self.i + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        buf = self.bufs[k][:perm.numel()]
+        buf.copy_(perm)
+        dst.copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+
+
 class CausalTrainer:
     def __init__(self, model, args, lr: float = 1e-3, weight_decay: float = 0.0,
                  use_graph: bool = True, world_size: int = 1, rebuild_plan: bool = True,
@@ -78,6 +100,8 @@ class CausalTrainer:
         self._pool = torch.cuda.graph_pool_handle() if use_graph else None
         self._opt_graph: Optional[torch.cuda.CUDAGraph] = None
         self.stats = torch.zeros(5, dtype=torch.float32, device=self.flat_p.device)
+        self._ring: Optional[_PinnedRing] = None
+        self._eager_perm: Optional[torch.Tensor] = None
         # with one GPU the optimizer update rides in the same graph as forward/backward
         self.fused_opt = self.engine is not None and world_size == 1
         self.model.train()
@@ -227,6 +251,14 @@ class CausalTrainer:
             if self._opt_graph is None and not self.fused_opt:
                 self._build_opt_graph()
 
+    def _upload_perm(self, perm: torch.Tensor, dst: torch.Tensor):
+        if perm.is_cuda:
+            dst.copy_(perm)
+            return
+        if self._ring is None or self._ring.bufs[0].numel() < perm.numel():
+            self._ring = _PinnedRing(max(perm.numel(), 1024))
+        self._ring.stage(perm, dst)
+
     def step(self, batch, perm: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One train step on a device-resident batch; returns the device stats
         tensor [loss, c_loss, o_loss, co_loss, correct_o] (no host sync)."""
@@ -237,11 +269,18 @@ class CausalTrainer:
             if cap is None:
                 self.prepare(batch)
                 cap = self._graphs[id(batch)]
-            cap.perm.copy_(perm, non_blocking=True)
+            self._upload_perm(perm, cap.perm)
             cap.graph.replay()
             stats = cap.stats
         else:
-            self._fwd_bwd(batch, perm.to(self.flat_p.device, non_blocking=True), self.stats)
+            if perm.is_cuda:
+                dperm = perm
+            else:
+                if self._eager_perm is None or self._eager_perm.numel() < perm.numel():
+                    self._eager_perm = torch.empty(perm.numel(), dtype=torch.long, device=self.flat_p.device)
+                dperm = self._eager_perm[:perm.numel()]
+                self._upload_perm(perm, dperm)
+            self._fwd_bwd(batch, dperm, self.stats)
             stats = self.stats
         self._allreduce()
         self._opt_step()

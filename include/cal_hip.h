@@ -140,6 +140,8 @@ CAL_API int cal_engine_step(void* engine, const float* x0, const int64_t* edge_i
                             int64_t E, int64_t B, float wc, float wo, float wco, int mode,
                             void* stream);
 CAL_API int cal_engine_adam(void* engine, void* stream);
+/* profiling aid: make cal_engine_step return after its k-th launch site (0 = run everything) */
+CAL_API int cal_engine_debug_stop(int k);
 
 #ifdef __cplusplus
 }

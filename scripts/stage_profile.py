@@ -1,0 +1,40 @@
+"""Real (un-profiled) cumulative GPU time of the engine step after each launch site, measured by
+truncating the step (cal_engine_debug_stop) and replaying it from a hipGraph."""
+import argparse, os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cal_amd import _lib, model as M, spmotif
+from cal_amd.data import Batch
+from cal_amd.engine import StepEngine
+args = argparse.Namespace(layers=3, hidden=128, with_random=True, without_node_attention=False,
+                          without_edge_attention=False, fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
+torch.manual_seed(0)
+m = M.CausalGCN(10, 4, args).cuda().train()
+eng = StepEngine(m)
+b = Batch.from_data_list(spmotif.train_mix(128, seed=5)).to("cuda")
+perm = torch.randperm(128, device="cuda")
+eng.train_step(b, perm, adam=False)
+torch.cuda.synchronize()
+def timed(stop, reps=30, inner=10):
+    _lib.lib().cal_engine_debug_stop(stop)
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        eng.train_step(b, perm, adam=False)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(inner): eng.train_step(b, perm, adam=False)
+    for _ in range(3): g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps / inner * 1e6
+nst = int(sys.argv[1]) if len(sys.argv) > 1 else 70
+prev = 0.0
+full = timed(0)
+for k in range(2, nst):
+    t = timed(k)
+    print("after launch site %2d: %7.1f us  (+%5.1f)" % (k - 1, t, t - prev))
+    if abs(t - full) < 1e-9 or (k > 5 and t >= full * 0.999 and t - prev < 0.05): pass
+    prev = t
+print("full step (no adam): %.1f us" % full)
