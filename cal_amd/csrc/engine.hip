@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "engine_kernels.hpp"
 
@@ -378,6 +379,23 @@ int grad_gemm(Ctx& c, GemmArgs& a, int nbatch, float** dst, FinishArgs& fa, size
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+// live kernel timing for bench.py's roofline block: when enabled, HIP events are recorded on the
+// launch stream around every node-level dense GEMM ([N,H]x[H,H], class 0) and every aggregation
+// (k_espmm, class 1) of the step.  Events are created here (never in a normal step).
+struct ProfRec { hipEvent_t e0, e1; int cls; double work; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+struct ProfScope {
+    hipStream_t st; bool on; ProfRec r;
+    ProfScope(hipStream_t s, int cls, double work) : st(s), on(g_prof_on) {
+        if (!on) return;
+        r.cls = cls; r.work = work;
+        hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+        hipEventRecord(r.e0, st);
+    }
+    ~ProfScope() { if (on) { hipEventRecord(r.e1, st); g_prof.push_back(r); } }
+};
+
 // profiling aid: cal_engine_debug_stop(k) makes the step return after its k-th launch site (0 = run all)
 static int g_stop_after = 0;
 static int g_stage = 0;
@@ -422,16 +440,19 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         GemmArgs a = gemm_args(N, H, H, false, false, 0);
         a.p[0].A = e->h + (size_t)(i - 1) * NH; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->z;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 1);
-        RC(launch_gemm(false, false, a, 1, st)); STAGE();
+        { ProfScope ps(st, 0, 2.0 * N * H * H); RC(launch_gemm(false, false, a, 1, st)); } STAGE();
         SpmmBranch br{e->z, e->h + (size_t)i * NH, e->P + e->o_conv_b[i - 1], nullptr, e->dis_unit, Acc(), Acc()};
         const bool wst = c.training && i < L;
         const int rpb = spmm_rpb(H, wst);
         if (wst) { br.st_sum = spmm_acc(c, bn_stsum(c, i + 1), H, rpb); br.st_sq = spmm_acc(c, bn_stsq(c, i + 1), H, rpb); }
-        RC(with_g(H, [&](auto g) {
-            constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, rpb), 1), dim3(256), 0, st, gd, br, br, 1, e->loop_w, N, H, rpb);
-            return 0;
-        }));
+        {
+            ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0);
+            RC(with_g(H, [&](auto g) {
+                constexpr int G = decltype(g)::value;
+                hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, rpb), 1), dim3(256), 0, st, gd, br, br, 1, e->loop_w, N, H, rpb);
+                return 0;
+            }));
+        }
         CAL_CHECK_LAUNCH("k_espmm"); STAGE();
         RC(flush_finals(c)); STAGE();
     }
@@ -829,6 +850,29 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
 }
 
 CAL_EXPORT int cal_engine_debug_stop(int k) { g_stop_after = k; return 0; }
+
+// Live timing (bench.py roofline): enable, run steps eagerly, synchronise, read.
+CAL_EXPORT int cal_engine_profile(int on) {
+    g_prof_on = on != 0;
+    if (on) {
+        for (auto& r : g_prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+        g_prof.clear();
+    }
+    return 0;
+}
+// Fills out[3*i + {0,1,2}] = (class, milliseconds, algorithmic work: flops for class 0, bytes for
+// class 1) for up to cap records; returns the number of records.  Call after a stream sync.
+CAL_EXPORT int64_t cal_engine_profile_read(double* out, int64_t cap) {
+    int64_t n = 0;
+    for (auto& r : g_prof) {
+        if (n >= cap) break;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.f;
+        out[3 * n] = r.cls; out[3 * n + 1] = ms; out[3 * n + 2] = r.work;
+        ++n;
+    }
+    return n;
+}
 
 // Adam alone (after an external gradient all-reduce)
 CAL_EXPORT int cal_engine_adam(void* h, void* stream_) {

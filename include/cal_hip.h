@@ -142,6 +142,10 @@ CAL_API int cal_engine_step(void* engine, const float* x0, const int64_t* edge_i
 CAL_API int cal_engine_adam(void* engine, void* stream);
 /* profiling aid: make cal_engine_step return after its k-th launch site (0 = run everything) */
 CAL_API int cal_engine_debug_stop(int k);
+/* live HIP-event timing of the node-level GEMMs (class 0, work = flops) and aggregations (class 1,
+ * work = algorithmic bytes) inside the step, for bench.py's roofline block; `out` is a HOST array */
+CAL_API int cal_engine_profile(int on);
+CAL_API int64_t cal_engine_profile_read(double* out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,194 @@
+"""GPU parity of the native CausalGCN step engine (cal_amd/csrc/engine.hip) against the CPU oracle:
+golden fixture, BASELINE.json config-2 scale (128 SPMotif graphs, hidden 128, 3 layers), eval-mode
+forward, multi-step training, and size-independent properties at full size."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cal_oracle as O
+from tests.helpers import GOLDEN, ref_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+LOGIT_TOL = 1e-4
+
+
+def _args(**kw):
+    d = dict(layers=3, hidden=128, with_random=True, without_node_attention=False,
+             without_edge_attention=False, fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def _engine(sd, args, nfeat=10, ncls=4, lr=1e-3):
+    from cal_amd import model as M
+    from cal_amd.engine import StepEngine
+    m = M.CausalGCN(nfeat, ncls, args)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    return m, StepEngine(m, lr=lr)
+
+
+def _close(a, b, atol, rtol):
+    return np.allclose(a, b, atol=atol, rtol=rtol)
+
+
+def test_golden_fixture_train_step():
+    fx = np.load(os.path.join(GOLDEN, "causal_gcn_batch8.npz"))
+    sd = {k[3:]: torch.from_numpy(fx[k]).clone() for k in fx.files if k.startswith("sd.")}
+    m, eng = _engine(sd, _args(layers=2, hidden=32))
+    bd = ref_batch(list(fx["ids"])).to(DEV)
+    perm = torch.from_numpy(fx["perm"]).to(DEV)
+    # eval-mode forward first (running statistics, no updates)
+    ev = eng.forward(bd, perm, training=False)
+    for n, t in zip(("c", "o", "co"), ev):
+        assert np.abs(t.cpu().numpy() - fx[f"eval_logits_{n}"]).max() < LOGIT_TOL, n
+    stats = eng.train_step(bd, perm, adam=True).cpu().numpy()
+    lp = eng.buffer("logp", 3 * 8 * 4).view(3, 8, 4).cpu().numpy()
+    for i, n in enumerate(("c", "o", "co")):
+        assert np.abs(lp[i] - fx[f"train_logits_{n}"]).max() < LOGIT_TOL, n
+    assert np.allclose(stats[:4], fx["loss"], atol=1e-4)
+    assert m.conv_feat.bias.grad.abs().max().item() == 0          # never receives a gradient
+    for k, p in m.named_parameters():
+        g = fx[f"grad.{k}"]
+        if g.size:
+            assert _close(p.grad.cpu().numpy(), g, 2e-5, 1e-3), k
+    post = m.state_dict()
+    for k in post:
+        if f"post.{k}" in fx.files and "running" in k:
+            assert _close(post[k].cpu().numpy(), fx[f"post.{k}"], 1e-4, 1e-4), k
+    # Adam: compare where the gradient is not numerically zero (sign of ~1e-8 grads is noise)
+    for k, p in m.named_parameters():
+        g = fx[f"grad.{k}"]
+        if g.size:
+            mask = np.abs(g) > 1e-6
+            assert _close(post[k].cpu().numpy()[mask], fx[f"post.{k}"][mask], 2e-5, 1e-4), k
+
+
+def _config2_batch(n_graphs=128, seed=11):
+    from cal_amd import spmotif
+    from cal_amd.data import Batch
+    gs = spmotif.train_mix(n_graphs, seed=seed)
+    return Batch.from_data_list(gs), Batch.from_data_list(gs).to(DEV)
+
+
+def test_config2_scale_step_matches_oracle():
+    """Full headline shape: N ~ 7.3k nodes, E ~ 25k edges, B = 128 (partial-row reductions, split-K
+    weight gradients, edge tiles all exercised)."""
+    b, bd = _config2_batch()
+    torch.manual_seed(5)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=128, layers=3)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args())
+    perm = torch.randperm(128)
+    tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=3)
+    loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
+    lp = eng.buffer("logp", 3 * 128 * 4).view(3, 128, 4).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    correct = (logits[1].argmax(1) == b.y).sum().item()
+    assert int(stats[4]) == correct
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is not None:
+            assert torch.allclose(p.grad.cpu(), gref, atol=5e-5, rtol=2e-3), k
+    post = m.state_dict()
+    for k in post:
+        if "running" in k:
+            assert torch.allclose(post[k].cpu(), tr.sd[k], atol=1e-3, rtol=1e-4), k
+
+
+def test_eval_forward_and_module_path_agree():
+    b, bd = _config2_batch(64, seed=3)
+    torch.manual_seed(9)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=2)
+    for k in sd:                       # non-trivial running statistics
+        if k.endswith("running_mean"):
+            sd[k] = torch.randn_like(sd[k]) * 0.1
+        if k.endswith("running_var"):
+            sd[k] = torch.rand_like(sd[k]) + 0.5
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(layers=2, hidden=64))
+    perm = torch.randperm(64)
+    ref = O.causal_forward("CausalGCN", {k: v.clone() for k, v in sd.items()}, b.feat, b.edge_index, b.batch,
+                           perm=perm, training=False, layers=2)
+    out = eng.forward(bd, perm.to(DEV), training=False)
+    for r, t in zip(ref, out):
+        assert (r - t.cpu()).abs().max().item() < LOGIT_TOL
+    m.eval()
+    with torch.no_grad():
+        mod = m(bd, eval_random=False, perm=perm)          # operator-level path on the same weights
+    for r, t in zip(mod, out):
+        assert (r - t).abs().max().item() < LOGIT_TOL
+    # eval forward must not touch running statistics
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(v.cpu(), sd[k])
+
+
+def test_three_steps_track_the_oracle():
+    b, bd = _config2_batch(32, seed=21)
+    torch.manual_seed(2)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=32, layers=3)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(hidden=32), lr=1e-2)
+    tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-2, layers=3)
+    g = torch.Generator().manual_seed(0)
+    for step in range(3):
+        perm = torch.randperm(32, generator=g)
+        loss, *_ = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+        stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu()
+        assert abs(stats[0].item() - loss.item()) < 2e-3 * (step + 1), step
+    assert int(eng.step_count.item()) == 3
+    assert int(m.bn_feat.num_batches_tracked.item()) == 3
+
+
+def test_trainer_graph_replay_matches_eager_engine():
+    from cal_amd import model as M
+    from cal_amd.trainer import CausalTrainer
+    _, b1 = _config2_batch(32, seed=1)
+    _, b2 = _config2_batch(32, seed=2)
+    torch.manual_seed(4)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=32, layers=2)
+    outs = []
+    for use_graph in (False, True):
+        m = M.CausalGCN(10, 4, _args(layers=2, hidden=32))
+        m.load_state_dict(sd)
+        tr = CausalTrainer(m.to(DEV), _args(layers=2, hidden=32), lr=1e-2, use_graph=use_graph)
+        tr.reserve_for([b1, b2])
+        losses = []
+        for i in range(6):
+            perm = torch.arange(32).roll(i)
+            losses.append(tr.step(b1 if i % 2 == 0 else b2, perm)[0].item())
+        outs.append((losses, tr.flat_p.clone()))
+    assert np.allclose(outs[0][0], outs[1][0], atol=1e-6)
+    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-6)
+    assert outs[0][0][-1] < outs[0][0][0]            # it trains
+
+
+def test_properties_at_full_size():
+    """Size-independent invariants on the headline batch: masks partition, log-probs normalise,
+    identity permutation makes the co head per-graph, run-to-run determinism."""
+    b, bd = _config2_batch()
+    torch.manual_seed(1)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=128, layers=3)
+    m, eng = _engine(sd, _args())
+    N, E = bd.feat.size(0), bd.edge_index.size(1)
+    perm = torch.randperm(128, device=DEV)
+    out1 = [t.clone() for t in eng.forward(bd, perm, training=True)]
+    att = eng.buffer("att", 2 * E).view(2, E)
+    nsl = bd.edge_index[0] != bd.edge_index[1]
+    assert torch.allclose(att[:, nsl].sum(0), torch.ones(int(nsl.sum()), device=DEV), atol=1e-6)
+    an = eng.buffer("anode", 2 * N).view(N, 2)
+    assert torch.allclose(an.sum(1), torch.ones(N, device=DEV), atol=1e-6)
+    for t in out1:
+        assert torch.allclose(t.exp().sum(1), torch.ones(128, device=DEV), atol=1e-5)
+    # deterministic: partial-row reductions have a fixed order (hot-column atomics only touch fp64)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    out2 = eng.forward(bd, perm, training=True)
+    for u, v in zip(out1, out2):
+        assert torch.allclose(u, v, atol=1e-6)
+    m.load_state_dict(state)
