@@ -326,10 +326,16 @@ Acc node_acc(Ctx& c, double* dst, int cols) {
     final_task(c, p, P, cols, cols, dst);
     return Acc(dst, p, cols);
 }
+// activation x weight products: the K-split kernel wins on latency for few rows (readouts, 4.6 vs
+// 6.9 us at 128 rows), the 64x64 tiled kernel on throughput for node-level row counts
+bool use_ks(int M) { return M <= 2048; }
+int fwd_gemm(Ctx& c, bool transB, const GemmArgs& a, int nbatch) {
+    return use_ks(a.M) ? launch_gemm_ks(transB, a, nbatch, c.st) : launch_gemm(false, transB, a, nbatch, c.st);
+}
 // same for a GEMM epilogue (two sums per column, P = row tiles)
 void gemm_stats(Ctx& c, GemmProb& pr, int M, int N, double* d0, double* d1, bool dot) {
     if (dot) { pr.dot_sum = d0; pr.dot_prod = d1; } else { pr.st_sum = d0; pr.st_sq = d1; }
-    const int P = gemm_row_tiles(M);
+    const int P = use_ks(M) ? gemm_ks_row_tiles(M) : gemm_row_tiles(M);
     if ((size_t)P * N * 2 <= 4096) return;
     double* p = parts_alloc(c, (size_t)P * 2 * N);
     if (!p) return;
@@ -432,7 +438,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         a.p[0].A = x0; a.p[0].B = e->P + e->o_feat_w; a.p[0].C = e->h;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 1);
         if (c.training && L > 0) gemm_stats(c, a.p[0], N, H, bn_stsum(c, 1), bn_stsq(c, 1), false);
-        RC(launch_gemm(false, false, a, 1, st)); STAGE();
+        RC(fwd_gemm(c, false, a, 1)); STAGE();
         RC(flush_finals(c)); STAGE();
     }
     // 4. backbone: h_i = relu(A_hat (BN_i(h_{i-1}) @ W_i) + b_i)   (model.py:93-95)
@@ -440,7 +446,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         GemmArgs a = gemm_args(N, H, H, false, false, 0);
         a.p[0].A = e->h + (size_t)(i - 1) * NH; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->z;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 1);
-        { ProfScope ps(st, 0, 2.0 * N * H * H); RC(launch_gemm(false, false, a, 1, st)); } STAGE();
+        { ProfScope ps(st, 0, 2.0 * N * H * H); RC(fwd_gemm(c, false, a, 1)); } STAGE();
         SpmmBranch br{e->z, e->h + (size_t)i * NH, e->P + e->o_conv_b[i - 1], nullptr, e->dis_unit, Acc(), Acc()};
         const bool wst = c.training && i < L;
         const int rpb = spmm_rpb(H, wst);
@@ -482,7 +488,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             a.p[k].xa.rs = e->anode + k; a.p[k].xa.rs_stride = 2;
             a.p[k].xa.has_bn = 1; a.p[k].xa.bn = bnref(c, L + 1 + k, N, 1);
         }
-        RC(launch_gemm(false, false, a, 2, st)); STAGE();
+        RC(fwd_gemm(c, false, a, 2)); STAGE();
     }
     // 8. h_k = relu(A_hat_k z_k + b_k)
     {
@@ -520,7 +526,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             a.p[hd].xa.has_bn = 1; a.p[hd].xa.bn = bnref(c, bn_fc1 + 2 * hd, B, 1);
             if (c.training) gemm_stats(c, a.p[hd], B, H, bn_stsum(c, bn_fc2 + 2 * hd), bn_stsq(c, bn_fc2 + 2 * hd), false);
         }
-        RC(launch_gemm(false, true, a, 3, st)); STAGE();
+        RC(fwd_gemm(c, true, a, 3)); STAGE();
         RC(flush_finals(c)); STAGE();
     }
     {
@@ -530,7 +536,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             a.p[hd].C = e->zl + (size_t)hd * B * C;
             a.p[hd].xa.has_bn = 1; a.p[hd].xa.bn = bnref(c, bn_fc2 + 2 * hd, B, 1);
         }
-        RC(launch_gemm(false, true, a, 3, st)); STAGE();
+        RC(fwd_gemm(c, true, a, 3)); STAGE();
     }
     hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, st, e->zl, y, e->logp, e->dzl, e->stats, e->arena + e->a_db2, B, C, wc, wo,
                        wco, want_grad);
@@ -585,7 +591,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[hd].aux = e->y1 + hd * BH; a.p[hd].has_aux = 1; a.p[hd].aux_bn = bnref(c, bn_fc2 + 2 * hd, B, 0);
             gemm_stats(c, a.p[hd], B, H, bn_dsum(c, bn_fc2 + 2 * hd), bn_dprod(c, bn_fc2 + 2 * hd), true);
         }
-        RC(launch_gemm(false, false, a, 3, st)); STAGE();
+        RC(fwd_gemm(c, false, a, 3)); STAGE();
         RC(flush_finals(c)); STAGE();
     }
     // R3. BN2 backward + ReLU mask + fc1 bias gradients
@@ -620,7 +626,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[hd].aux = xin[hd]; a.p[hd].has_aux = 1; a.p[hd].aux_bn = bnref(c, bn_fc1 + 2 * hd, B, 0);
             gemm_stats(c, a.p[hd], B, H, bn_dsum(c, bn_fc1 + 2 * hd), bn_dprod(c, bn_fc1 + 2 * hd), true);
         }
-        RC(launch_gemm(false, false, a, 3, st)); STAGE();
+        RC(fwd_gemm(c, false, a, 3)); STAGE();
         RC(flush_finals(c)); STAGE();
     }
     // R6. BN1 backward + un-permute the random intervention -> d pooled
@@ -688,7 +694,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[k].aux_bn = bnref(c, L + 1 + k, N, 0);
             gemm_stats(c, a.p[k], N, H, bn_dsum(c, L + 1 + k), bn_dprod(c, L + 1 + k), true);
         }
-        RC(launch_gemm(false, true, a, 2, st)); STAGE();
+        RC(fwd_gemm(c, true, a, 2)); STAGE();
         RC(flush_finals(c)); STAGE();
     }
     // P8. everything between the last backbone conv and the two causal convs
@@ -731,7 +737,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[0].A = e->dzi; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->dXh;
             a.p[0].aux = hin; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, i, N, 0);
             gemm_stats(c, a.p[0], N, H, bn_dsum(c, i), bn_dprod(c, i), true);
-            RC(launch_gemm(false, true, a, 1, st)); STAGE();
+            RC(fwd_gemm(c, true, a, 1)); STAGE();
             RC(flush_finals(c)); STAGE();
         }
         {
@@ -759,13 +765,13 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         a.p[0].aux = x0; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, 0, N, 0);
         a.p[0].dot_sum = bn_dsum(c, 0); a.p[0].dot_prod = bn_dprod(c, 0);
         {   // bn_feat's sums are only needed by the commit: keep the partial rows, no finalise launch
-            const int P0 = gemm_row_tiles(N);
+            const int P0 = use_ks(N) ? gemm_ks_row_tiles(N) : gemm_row_tiles(N);
             if ((size_t)P0 * F * 2 > 4096) {
                 d_bn0.p = parts_alloc(c, (size_t)P0 * 2 * F); d_bn0.P = P0; d_bn0.stride = 2 * F;
                 a.p[0].parts = d_bn0.p;
             }
         }
-        RC(launch_gemm(false, true, a, 1, st)); STAGE();
+        RC(fwd_gemm(c, true, a, 1)); STAGE();
     }
     // commits: fp64 arena -> fp32 gradients
     for (int k = 0; k < e->nbn; ++k) {

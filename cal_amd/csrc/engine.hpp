@@ -115,6 +115,9 @@ int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStre
 int splitk_for(int64_t M, int64_t N, int64_t K, int nbatch);
 void gemm_set_split(GemmArgs& a, int S);
 int gemm_row_tiles(int M);
+// latency-oriented variant (gemm_ks.hip): 32x32 tiles, K split across the four waves
+int launch_gemm_ks(bool transB, const GemmArgs& a, int nbatch, hipStream_t stream);
+int gemm_ks_row_tiles(int M);
 
 
 }  // namespace cal

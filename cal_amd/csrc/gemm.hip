@@ -317,6 +317,17 @@ void gemm_set_split(GemmArgs& a, int S) {
 
 using namespace cal;
 
+// experiment hook: same contract as cal_gemm (transA must be 0, no split-K) through the K-split kernel
+CAL_EXPORT int cal_gemm_ks(int transB, const float* A, const float* B, float* C, const float* bias, int relu,
+                           int64_t M, int64_t N, int64_t K, void* stream_) {
+    GemmArgs a = {};
+    a.M = (int)M; a.N = (int)N; a.K = (int)K;
+    a.lda = (int)K; a.ldb = (int)(transB ? K : N); a.ldc = (int)N;
+    a.relu = relu; a.kchunk = (int)K; a.nsplit = 1;
+    a.p[0].A = A; a.p[0].B = B; a.p[0].bias = bias; a.p[0].C = C;
+    return launch_gemm_ks(transB != 0, a, 1, (hipStream_t)stream_);
+}
+
 CAL_EXPORT int64_t cal_gemm_ws(int64_t M, int64_t N, int64_t K) {
     int s = splitk_for(M, N, K, 1);
     return s > 1 ? (int64_t)(s + 1) * M * N : 0;

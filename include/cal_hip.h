@@ -79,6 +79,10 @@ CAL_API int cal_gemm(int transA, int transB, const float* A, const float* B, flo
                      const float* bias, int relu, float* ws, int64_t M, int64_t N, int64_t K,
                      void* stream);
 
+/* K-split (latency-oriented) variant, A not transposed, K <= 512 recommended */
+CAL_API int cal_gemm_ks(int transB, const float* A, const float* B, float* C, const float* bias,
+                        int relu, int64_t M, int64_t N, int64_t K, void* stream);
+
 /* ---- causal / trivial soft masks (model.py:97-111) ------------------------- */
 CAL_API int cal_edge_att_fwd(const float* x, const float* W, const float* b, const int32_t* row32,
                              const int32_t* col32, float* pq, float* att, int64_t N, int64_t E,

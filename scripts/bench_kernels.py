@@ -28,7 +28,13 @@ def gemm(M, N, K, ta=0, tb=0):
     f = lambda: _lib.call("cal_gemm", ta, tb, _p(A), _p(B), _p(C), None, 0, _p(ws), M, N, K, _stream())
     t = graph_time(f)
     t2 = graph_time(lambda: torch.matmul(A.t() if ta else A, B.t() if tb else B, out=C))
-    print("gemm M=%d N=%d K=%d ta=%d tb=%d: %.2f us/launch (%.1f TF)   rocBLAS %.2f us" % (M, N, K, ta, tb, t, 2*M*N*K/t/1e6, t2))
+    t3 = float("nan")
+    if not ta:
+        C2 = torch.empty_like(C)
+        f3 = lambda: _lib.call("cal_gemm_ks", tb, _p(A), _p(B), _p(C2), None, 0, M, N, K, _stream())
+        t3 = graph_time(f3)
+        assert torch.allclose(C2, (A @ (B.t() if tb else B)), atol=1e-3, rtol=1e-3)
+    print("gemm M=%d N=%d K=%d ta=%d tb=%d: %.2f us/launch (%.1f TF)   ks %.2f us   rocBLAS %.2f us" % (M, N, K, ta, tb, t, 2*M*N*K/t/1e6, t3, t2))
 
 def spmm(N, H, deg):
     import numpy as np
