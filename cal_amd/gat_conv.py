@@ -48,7 +48,7 @@ class GATConv(torch.nn.Module):
         return int(torch.initial_seed() * 1000003 + id(self) % 65521 * 7919 + self._calls) & ((1 << 63) - 1)
 
     def forward(self, x, edge_index, *, plan: Optional[GraphPlan] = None, relu: bool = False):
-        z = torch.matmul(x, self.weight)
+        z = ops.matmul(x, self.weight)
         if plan is None:
             plan = GraphPlan(edge_index, x.size(0))
         p = float(self.dropout) if self.training else 0.0

@@ -59,9 +59,9 @@ class GCNConv(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_weight=None, *, plan: Optional[GraphPlan] = None,
                 relu: bool = False):
-        x = torch.matmul(x, self.weight)                        # gcn_conv.py:75
+        x = ops.matmul(x, self.weight, relu=relu and self.gfn)  # gcn_conv.py:75 (fp32 MFMA GEMM)
         if self.gfn:                                            # gcn_conv.py:76-77
-            return torch.relu(x) if relu else x
+            return x
         if not self.edge_norm:
             raise NotImplementedError("edge_norm=False is never used by the CAL models")
         if plan is None:

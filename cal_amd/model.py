@@ -104,18 +104,16 @@ class _CausalBase(torch.nn.Module):
 
     def context_readout_layer(self, x):
         x = self.fc1_bn_c(x)
-        x = self.fc1_c(x)
-        x = F.relu(x)
+        x = ops.linear(x, self.fc1_c.weight, self.fc1_c.bias, relu=True)     # Linear + ReLU on the MFMA GEMM
         x = self.fc2_bn_c(x)
-        x = self.fc2_c(x)
+        x = ops.linear(x, self.fc2_c.weight, self.fc2_c.bias)
         return F.log_softmax(x, dim=-1)
 
     def objects_readout_layer(self, x):
         x = self.fc1_bn_o(x)
-        x = self.fc1_o(x)
-        x = F.relu(x)
+        x = ops.linear(x, self.fc1_o.weight, self.fc1_o.bias, relu=True)     # Linear + ReLU on the MFMA GEMM
         x = self.fc2_bn_o(x)
-        x = self.fc2_o(x)
+        x = ops.linear(x, self.fc2_o.weight, self.fc2_o.bias)
         return F.log_softmax(x, dim=-1)
 
     def intervention_index(self, num, eval_random):
@@ -136,10 +134,9 @@ class _CausalBase(torch.nn.Module):
         else:
             x = xc[random_idx] + xo
         x = self.fc1_bn_co(x)
-        x = self.fc1_co(x)
-        x = F.relu(x)
+        x = ops.linear(x, self.fc1_co.weight, self.fc1_co.bias, relu=True)     # Linear + ReLU on the MFMA GEMM
         x = self.fc2_bn_co(x)
-        x = self.fc2_co(x)
+        x = ops.linear(x, self.fc2_co.weight, self.fc2_co.bias)
         return F.log_softmax(x, dim=-1)
 
 
@@ -213,10 +210,18 @@ class GINConv(torch.nn.Module):
     def __init__(self, nn_module, eps=0.0):
         super().__init__()
         self.nn = nn_module
-        self.eps = eps
+        self.initial_eps = float(eps)
+        self.register_buffer("eps", torch.tensor([float(eps)]))     # PyG keeps eps in the state dict
 
     def forward(self, x, edge_index, *, plan=None):
-        raise NotImplementedError("CausalGIN backbone lands with the GIN aggregation kernel (SURVEY 8f)")
+        from .plan import GraphPlan
+        if plan is None:
+            plan = GraphPlan(edge_index, x.size(0))
+        out = ops.gin_aggregate(x, plan, self.initial_eps)
+        lin1, bn, _, lin2, _ = self.nn                               # model.py:189-194
+        out = ops.linear(out, lin1.weight, lin1.bias)
+        out = torch.relu(bn(out))
+        return ops.linear(out, lin2.weight, lin2.bias, relu=True)
 
 
 class CausalGIN(_CausalBase):

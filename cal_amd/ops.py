@@ -246,3 +246,94 @@ def gat_dropout_mask(seed: int, plan: GraphPlan, heads: int, p: float) -> torch.
     m = torch.empty(plan.E + plan.N, heads, dtype=torch.float32, device=plan.device)
     _lib.call("cal_gat_dropout_mask", seed, plan.E, plan.N, heads, p, _p(m), _stream())
     return m
+
+
+class _Linear(Function):
+    """Dense layer on the fp32 MFMA GEMM (cal_gemm): y = x @ W (+b) for a GCN-style weight
+    [in, out] (gcn_conv.py:75) or y = x @ W^T (+b) for an nn.Linear weight [out, in]
+    (model.py:46-75), optional fused ReLU."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_in: bool, relu: bool):
+        x, weight = _f32(x, "x"), _f32(weight, "weight")
+        M, K = x.shape
+        N = weight.size(0) if out_in else weight.size(1)
+        if (weight.size(1) if out_in else weight.size(0)) != K:
+            raise ValueError("weight shape does not match the input width")
+        if bias is not None:
+            bias = _f32(bias, "bias")
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _lib.call("cal_gemm", 0, 1 if out_in else 0, _p(x), _p(weight), _p(y), _p(bias), int(relu), None, M, N, K, _stream())
+        ctx.out_in, ctx.relu, ctx.has_bias = out_in, relu, bias is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        gy = _f32(gy, "grad")
+        M, N = gy.shape
+        K = x.size(1)
+        dev = gy.device
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        g = torch.empty_like(gy) if ctx.relu else gy
+        db = torch.empty(N, dtype=torch.float32, device=dev) if need_b else None
+        if ctx.relu or need_b:
+            part = _empty(_lib.query("cal_colsum_parts", M) * N, dev) if need_b else None
+            _lib.call("cal_relu_bwd_colsum", _p(gy), _p(y) if ctx.relu else None, _p(g) if ctx.relu else None,
+                      _p(db), _p(part), M, N, _stream())
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            # out_in: dx = g @ W ([N,K] as stored);  else dx = g @ W^T (W stored [K,N])
+            _lib.call("cal_gemm", 0, 0 if ctx.out_in else 1, _p(g), _p(weight), _p(dx), None, 0, None, M, K, N, _stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            if ctx.out_in:      # dW [N,K] = g^T @ x
+                ws = _empty(_lib.query("cal_gemm_ws", N, K, M), dev)
+                _lib.call("cal_gemm", 1, 0, _p(g), _p(x), _p(dw), None, 0, _p(ws), N, K, M, _stream())
+            else:               # dW [K,N] = x^T @ g
+                ws = _empty(_lib.query("cal_gemm_ws", K, N, M), dev)
+                _lib.call("cal_gemm", 1, 0, _p(x), _p(g), _p(dw), None, 0, _p(ws), K, N, M, _stream())
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None, relu: bool = False):
+    """nn.Linear semantics (weight [out, in]) on the MFMA GEMM."""
+    return _Linear.apply(x, weight, bias, True, relu)
+
+
+def matmul(x, weight, relu: bool = False):
+    """x @ weight with weight [in, out] (gcn_conv.py:75) on the MFMA GEMM."""
+    return _Linear.apply(x, weight, None, False, relu)
+
+
+class _GINAggregate(Function):
+    """PyG GINConv's aggregation, (1 + eps) * x + sum_{j -> i} x_j (self loops of the input dropped),
+    on the CSR aggregation kernel with unit coefficients (call site model.py:188)."""
+
+    @staticmethod
+    def forward(ctx, x, plan: GraphPlan, eps: float):
+        x = _f32(x, "x")
+        N, H = x.shape
+        ones_n, ones_e = plan.ones()
+        out = torch.empty_like(x)
+        _lib.call("cal_spmm_fwd", _p(plan.rowptr_dst), _p(plan.nbr_dst), _p(plan.eid_dst), _p(ones_e), _p(ones_n),
+                  1.0 + eps, _p(x), None, 0, _p(out), N, H, _stream())
+        ctx.plan, ctx.eps = plan, eps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32(g, "grad")
+        N, H = g.shape
+        plan = ctx.plan
+        ones_n, ones_e = plan.ones()
+        dx = torch.empty_like(g)
+        _lib.call("cal_spmm_fwd", _p(plan.rowptr_src), _p(plan.nbr_src), _p(plan.eid_src), _p(ones_e), _p(ones_n),
+                  1.0 + ctx.eps, _p(g), None, 0, _p(dx), N, H, _stream())
+        return dx, None, None
+
+
+def gin_aggregate(x, plan: GraphPlan, eps: float = 0.0):
+    return _GINAggregate.apply(x, plan, eps)

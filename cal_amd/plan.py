@@ -91,6 +91,13 @@ class GraphPlan:
             self._unit[key] = (dis, norm)
         return self._unit[key]
 
+    def ones(self):
+        """(ones[N], ones[E]): unit coefficients for plain-sum aggregation (GINConv)."""
+        if getattr(self, "_ones", None) is None:
+            self._ones = (torch.ones(max(self.N, 1), dtype=torch.float32, device=self.device),
+                          torch.ones(max(self.E, 1), dtype=torch.float32, device=self.device))
+        return self._ones
+
     def pool_splits(self) -> int:
         if self.B == 0:
             return 1

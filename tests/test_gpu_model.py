@@ -143,3 +143,61 @@ def test_ablation_flags_and_random_perm_path():
                            layers=2, without_node_attention=True, without_edge_attention=True)
     for r, t in zip(ref, out):
         assert (r - t.cpu()).abs().max().item() < LOGIT_TOL
+
+
+def test_causal_gin_matches_oracle():
+    ids = list(range(12))
+    b = ref_batch(ids)
+    torch.manual_seed(11)
+    sd = O.init_state("CausalGIN", 10, 4, hidden=64, layers=2)
+    args = _args(layers=2, hidden=64)
+    from cal_amd import model as M
+    m = M.CausalGIN(10, 4, args)
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith(".eps") for k in missing.missing_keys)
+    m = m.to(DEV)
+    perm = torch.randperm(len(ids))
+    for training in (True, False):
+        sdc = {k: v.clone() for k, v in sd.items()}
+        ref = O.causal_forward("CausalGIN", sdc, b.feat, b.edge_index, b.batch, perm=perm, training=training, layers=2)
+        m.load_state_dict(sd, strict=False)
+        m.train(training)
+        out = m(ref_batch(ids).to(DEV), eval_random=True, perm=perm)
+        for r, t in zip(ref, out):
+            assert (r - t.detach().cpu()).abs().max().item() < LOGIT_TOL
+    # gradients through the GIN aggregation + MFMA linears
+    m.load_state_dict(sd, strict=False)
+    m.train()
+    tr = O.CpuTrainer("CausalGIN", {k: v.clone() for k, v in sd.items()}, 4, layers=2)
+    loss_ref, *_ = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    bd = ref_batch(ids).to(DEV)
+    logits = m(bd, eval_random=True, perm=perm)
+    loss, *_ = O.causal_loss(*logits, bd.y, 4)
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4
+    for k, p in m.named_parameters():
+        g = tr.sd[k].grad
+        if g is not None:
+            assert torch.allclose(p.grad.cpu(), g, atol=1e-4, rtol=2e-3), k
+
+
+def test_linear_op_matches_torch():
+    from cal_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for (M_, K, N) in [(130, 10, 128), (7000, 128, 128), (64, 128, 4), (257, 96, 33)]:
+        x = torch.randn(M_, K, generator=g).to(DEV).requires_grad_(True)
+        w = (torch.randn(N, K, generator=g) * 0.1).to(DEV).requires_grad_(True)
+        b = torch.randn(N, generator=g).to(DEV).requires_grad_(True)
+        y = ops.linear(x, w, b, relu=True)
+        ref = torch.relu(torch.nn.functional.linear(x.detach().cpu(), w.detach().cpu(), b.detach().cpu()))
+        assert torch.allclose(y.detach().cpu(), ref, atol=1e-4, rtol=1e-4)
+        gy = torch.randn(M_, N, generator=g)
+        y.backward(gy.to(DEV))
+        xr, wr, br = (t.detach().cpu().requires_grad_(True) for t in (x, w, b))
+        torch.relu(torch.nn.functional.linear(xr, wr, br)).backward(gy)
+        assert torch.allclose(x.grad.cpu(), xr.grad, atol=2e-4, rtol=1e-3)
+        assert torch.allclose(w.grad.cpu(), wr.grad, atol=2e-3, rtol=2e-3)
+        assert torch.allclose(b.grad.cpu(), br.grad, atol=2e-3, rtol=2e-3)
+        w2 = w.detach().t().contiguous().requires_grad_(True)
+        y2 = ops.matmul(x.detach(), w2)
+        assert torch.allclose(y2.detach().cpu(), x.detach().cpu() @ w2.detach().cpu(), atol=1e-4, rtol=1e-4)
