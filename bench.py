@@ -188,11 +188,19 @@ def engine_roofline(trainer, batches, iters=20):
         work = r[:, 2].mean()
         out[key] = (dur, work, len(r) / iters)
     roof = {}
+    # HBM-side traffic per launch from the PMC passes (separate rocprofv3 --pmc runs of this command;
+    # committed under profiles/): null when the summary is absent
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        pass
     if "gemm" in out:
         dur, work, per_step = out["gemm"]
         ach = work / dur / 1e12
         roof["roofline"] = dict(bound="mfma", kernel="k_gemm<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers)",
-                                achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3, traffic=None,
+                                achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3,
+                                traffic=pmc.get("k_gemm_backbone", {}).get("bytes_per_launch"),
                                 avg_launch_us=dur * 1e6, algorithmic_flops_per_launch=work, timed_launches_per_step=per_step,
                                 note="config-2 working set (3.7 MB activations) is cache-resident: the step is "
                                      "launch/latency-bound by construction (SURVEY.md 8d); event pairs include the launch gap")
@@ -200,7 +208,8 @@ def engine_roofline(trainer, batches, iters=20):
         dur, work, per_step = out["spmm"]
         ach = work / dur / 1e9
         roof["roofline_aggregation"] = dict(bound="hbm", kernel="k_espmm (CSR aggregation + bias + ReLU + BN statistics)",
-                                            achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None,
+                                            achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
+                                            traffic=pmc.get("k_espmm", {}).get("bytes_per_launch"),
                                             avg_launch_us=dur * 1e6, algorithmic_bytes_per_launch=work,
                                             timed_launches_per_step=per_step)
     return roof
