@@ -95,6 +95,8 @@ struct Engine {
     size_t slab_floats;
     double* arena;
     double* parts; size_t parts_doubles;
+    // side stream for the weight-gradient GEMMs (off the critical path until the final commit)
+    hipStream_t side; hipEvent_t ev_fork[24], ev_join[24];
     int *rowptr_dst, *nbr_dst, *eid_dst, *rowptr_src, *nbr_src, *eid_src, *row32, *col32, *work, *status, *gptr, *iperm;
 };
 
@@ -118,10 +120,21 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     e->F = (int)F; e->H = (int)H; e->C = (int)C; e->L = (int)L;
     e->loop_w = 1.f;
     e->nbn = (int)L + 9;
+    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { set_error("cal_engine_create: side stream"); delete e; return nullptr; }
+    for (int i = 0; i < 24; ++i) {
+        hipEventCreateWithFlags(&e->ev_fork[i], hipEventDisableTiming);
+        hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming);
+    }
     return e;
 }
 
-CAL_EXPORT void cal_engine_destroy(void* h) { delete (Engine*)h; }
+CAL_EXPORT void cal_engine_destroy(void* h) {
+    Engine* e = (Engine*)h;
+    if (!e) return;
+    for (int i = 0; i < 24; ++i) { hipEventDestroy(e->ev_fork[i]); hipEventDestroy(e->ev_join[i]); }
+    hipStreamDestroy(e->side);
+    delete e;
+}
 
 CAL_EXPORT int64_t cal_engine_num_param_slots(void* h) { Engine* e = (Engine*)h; return 3 + 4 * e->L + 12 + 24; }
 CAL_EXPORT int64_t cal_engine_num_bn(void* h) { return ((Engine*)h)->nbn; }
@@ -196,7 +209,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     F32(e->stats, 8);
     F32(e->dzl, 3 * B * C); F32(e->dyh1, 3 * B * H); F32(e->dy1, 3 * B * H); F32(e->dxh, 3 * B * H); F32(e->dpool, 2 * B * H);
     F32(e->dZco, 2 * N * H); F32(e->gn, 2 * E); F32(e->gself, 2 * N); F32(e->ddeg, 2 * N); F32(e->dl, E);
-    F32(e->dzco, 2 * N * H); F32(e->dXhco, 2 * N * H); F32(e->dZ, N * H); F32(e->dzi, N * H); F32(e->dXh, N * H);
+    F32(e->dzco, 2 * N * H); F32(e->dXhco, 2 * N * H); F32(e->dZ, N * H); F32(e->dzi, (L > 0 ? L : 1) * N * H); F32(e->dXh, N * H);
     // split-K slabs: worst case per weight gradient (S <= 256, but S*tiles ~ 512 => S*M*N <= ~512*64*64 + M*N)
     size_t slab = 0;
     auto slab_of = [&](size_t M, size_t Nn) { return (size_t)(512 * 64 * 64 + 2 * M * Nn); };
@@ -261,6 +274,7 @@ struct Ctx {
     int64_t E;
     int training;
     int rpb_n, rpb_b;   // rows per block for node-level / graph-level row walkers
+    int nfork;          // weight-gradient GEMMs forked to the side stream so far
     size_t parts_off;   // bump allocator over Engine::parts
     FinalArgs fin;      // pending k_stats_final tasks
 };
@@ -381,7 +395,25 @@ int grad_gemm(Ctx& c, GemmArgs& a, int nbatch, float** dst, FinishArgs& fa, size
     } else {
         for (int b = 0; b < nbatch; ++b) a.p[b].C = dst[b];
     }
-    return launch_gemm(true, false, a, nbatch, c.st);
+    // fork: everything enqueued on the main stream so far (the producers of A and B) precedes it
+    hipStream_t s = c.st;
+    // Measured on MI355X / ROCm 7.2: forking the 9 dW GEMMs costs more than it hides (graph replay
+    // 514 -> 648 us per step, eager 523 -> 554 us: cross-stream edges serialise through heavier
+    // barrier packets), so the fork is compiled in but disabled.
+    constexpr bool kForkWeightGrads = false;
+    if (kForkWeightGrads && c.nfork < 24) {
+        hipEventRecord(c.e->ev_fork[c.nfork], c.st);
+        hipStreamWaitEvent(c.e->side, c.e->ev_fork[c.nfork], 0);
+        s = c.e->side;
+    }
+    int rc = launch_gemm(true, false, a, nbatch, s);
+    if (s != c.st) { hipEventRecord(c.e->ev_join[c.nfork], s); c.nfork++; }
+    return rc;
+}
+// the main stream waits for every forked GEMM (before the final commit, and on any early exit)
+void join_side(Ctx& c) {
+    for (int i = 0; i < c.nfork; ++i) hipStreamWaitEvent(c.st, c.e->ev_join[i], 0);
+    c.nfork = 0;
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -717,7 +749,8 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     }
     // Q. backbone layers, last to first
     for (int i = L; i >= 1; --i) {
-        SpmmBranch br{e->dZ, e->dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
+        float* dzi = e->dzi + (size_t)(i - 1) * NH;     // per layer: the side-stream dW GEMM reads it later
+        SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
             hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, br, br, 0, e->loop_w, N, H, spmm_rpb(H, false));
@@ -727,14 +760,14 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         const float* hin = e->h + (size_t)(i - 1) * NH;
         {
             GemmArgs a = gemm_args(H, H, N, true, false, 0);
-            a.p[0].A = hin; a.p[0].B = e->dzi;
+            a.p[0].A = hin; a.p[0].B = dzi;
             a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 0);
             float* dst[1] = {e->G + e->o_conv_w[i - 1]};
             RC(grad_gemm(c, a, 1, dst, fa, slab_off)); STAGE();
         }
         {
             GemmArgs a = gemm_args(N, H, H, false, true, 0);
-            a.p[0].A = e->dzi; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->dXh;
+            a.p[0].A = dzi; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->dXh;
             a.p[0].aux = hin; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, i, N, 0);
             gemm_stats(c, a.p[0], N, H, bn_dsum(c, i), bn_dprod(c, i), true);
             RC(fwd_gemm(c, true, a, 1)); STAGE();
@@ -804,6 +837,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         commit(e->a_db2 + hd * C, e->o_fc2_b[hd], C, 1.f);
     }
     if (fa.nct > MAX_COMMITS) { set_error("engine: too many commit tasks"); return 2; }
+    join_side(c);
     hipLaunchKernelGGL(k_finish, dim3(64, fa.nst + fa.nct), dim3(256), 0, st, fa, e->G);
     CAL_CHECK_LAUNCH("k_finish"); STAGE();
     return 0;
@@ -832,6 +866,7 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     c.rpb_b = std::max(32, cdiv(B, 64));
     c.parts_off = 0;
     c.fin.nt = 0;
+    c.nfork = 0;
     const int want_grad = (mode & 2) ? 1 : 0;
     CAL_REQUIRE(!want_grad || c.training, "backward needs a training-mode forward");
     g_stage = 0;
@@ -841,6 +876,7 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
         if (rc) return rc;
         if (want_grad) {
             rc = engine_backward(c, x0, batch);
+            if (rc) join_side(c);
             if (rc == -12345) return 0;
             if (rc) return rc;
         }
