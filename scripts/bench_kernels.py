@@ -56,3 +56,32 @@ if __name__ == "__main__":
                   (7315, 128, 32, 0, 0), (7315, 128, 512, 0, 0), (160000, 256, 256, 0, 0)]:
         gemm(*shape)
     spmm(7315, 128, 4); spmm(160000, 256, 5)
+
+
+def gat(N, H, K, deg):
+    import numpy as np
+    rng = np.random.default_rng(0)
+    per = max(N // 32, 1)
+    dst = np.repeat(np.arange(N), deg); src = (dst // per) * per + rng.integers(0, per, N * deg)
+    p = GraphPlan(torch.from_numpy(np.stack([src, dst])).cuda(), N)
+    D = H // K
+    z = torch.randn(N, H, device="cuda"); att = torch.randn(K, 2 * D, device="cuda") * 0.2
+    out = torch.empty_like(z)
+    bufs = [torch.empty(N * K, device="cuda") for _ in range(4)]
+    f = lambda: _lib.call("cal_gat_fwd", _p(p.rowptr_dst), _p(p.nbr_dst), _p(p.eid_dst), _p(z), _p(att), None, 1, 0.2, 0.0, 0,
+                          _p(out), _p(bufs[0]), _p(bufs[1]), _p(bufs[2]), _p(bufs[3]), N, p.E, K, D, _stream())
+    t = graph_time(f, n=20)
+    Ep = N * deg + N
+    byts = 2 * N * H * 4 + Ep * 8 + (N + 1) * 4 + 3 * Ep * K * 4
+    print("gat_fwd N=%d H=%d K=%d deg=%d: %.2f us/launch  (%.0f GB/s algorithmic)" % (N, H, K, deg, t, byts / t / 1e3))
+    g = torch.randn_like(z); dz = torch.empty_like(z); datt = torch.empty(K * 2 * D, device="cuda")
+    ws = torch.empty(_lib.query("cal_gat_bwd_ws", N, p.E, K, D), device="cuda")
+    fb = lambda: _lib.call("cal_gat_bwd", _p(p.rowptr_dst), _p(p.nbr_dst), _p(p.eid_dst), _p(p.rowptr_src), _p(p.nbr_src), _p(p.eid_src),
+                           _p(z), _p(att), _p(bufs[0]), _p(bufs[1]), _p(bufs[2]), _p(bufs[3]), _p(g), 0.2, 0.0, 0, _p(dz), _p(datt), _p(ws),
+                           N, p.E, K, D, _stream())
+    tb = graph_time(fb, n=20)
+    print("gat_bwd (5 kernels)          : %.2f us/call" % tb)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gat":
+    gat(1148, 128, 4, 2); gat(7315, 128, 4, 4); gat(160000, 256, 4, 5)

@@ -219,3 +219,63 @@ def test_gat_aggregate_fwd_bwd(relu, p_drop):
         assert torch.allclose(zd.grad.cpu(), z.grad, atol=1e-4, rtol=1e-3), name
         assert torch.allclose(ad.grad.cpu(), att.grad, atol=5e-4, rtol=1e-3), name
         assert torch.allclose(bd.grad.cpu(), bias.grad, atol=2e-4, rtol=1e-3), name
+
+
+def _big_plan(N, deg, seed=0):
+    from cal_amd.plan import GraphPlan
+    g = torch.Generator().manual_seed(seed)
+    # block-diagonal random graph: 32 graphs, neighbours inside the own graph (like a mini-batch)
+    per = N // 32
+    dst = torch.arange(N).repeat_interleave(deg)
+    src = (dst // per) * per + torch.randint(0, per, (N * deg,), generator=g)
+    batch = (torch.arange(N) // per).clamp(max=31)
+    return GraphPlan(torch.stack([src, dst]).to(DEV), N, batch.to(DEV), 32)
+
+
+def test_full_size_properties_config5_shape():
+    """BASELINE.json config-5 per-GPU shape (160k nodes, ~800k edges, H = 256): size-independent
+    checks where the CPU oracle would be too slow -- linearity, adjointness of the forward and
+    transposed aggregation (<A x, y> == <x, A^T y>), row sums, pooling conservation, GAT attention
+    rows summing to one (out = z when all z rows are equal)."""
+    from cal_amd import _lib, ops
+    from cal_amd.plan import _p, _stream
+    N, H, deg = 160000, 256, 5
+    p = _big_plan(N, deg)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, H, generator=g).to(DEV)
+    y = torch.randn(N, H, generator=g).to(DEV)
+    w = (torch.rand(p.E, generator=g) + 0.1).to(DEV)
+    ax = ops.gcn_aggregate(x, p, w)
+    ay = ops.gcn_aggregate(y, p, w)
+    # linearity
+    axy = ops.gcn_aggregate(2.0 * x - 0.5 * y, p, w)
+    assert torch.allclose(axy, 2.0 * ax - 0.5 * ay, atol=2e-4, rtol=1e-4)
+    # adjointness through autograd: d/dx <A x, y> = A^T y
+    xg = x.clone().requires_grad_(True)
+    (ops.gcn_aggregate(xg, p, w) * y).sum().backward()
+    lhs = (ax.double() * y.double()).sum()
+    rhs = (x.double() * xg.grad.double()).sum()
+    assert abs(lhs - rhs).item() < 1e-6 * max(1.0, abs(lhs).item())
+    # unweighted: A 1 has the analytic value sum_e dis_r dis_c + dis_i^2
+    ones = torch.ones(N, 4, device=DEV)
+    a1 = ops.gcn_aggregate(ones, p, None)[:, 0]
+    dis, norm = p.unit_norm()
+    ref = torch.zeros(N, device=DEV).index_add_(0, p.col32.long(), norm[:p.E]) + dis[:N] ** 2
+    assert torch.allclose(a1, ref, atol=1e-5)
+    # pooling conserves the column sums
+    pooled = ops.add_pool(x, p)
+    assert torch.allclose(pooled.sum(0), x.sum(0), atol=5e-2, rtol=1e-4)
+    # GAT: attention coefficients of a row sum to one -> constant z is reproduced (+ bias 0)
+    K, D = 4, 64
+    zc = torch.randn(1, H, generator=g).to(DEV).expand(N, H).contiguous()
+    att = (torch.randn(1, K, 2 * D, generator=g) * 0.2).to(DEV)
+    out = ops.gat_aggregate(zc, att, None, p, K)
+    assert torch.allclose(out, zc, atol=1e-4, rtol=1e-4)
+    # and the GAT backward is the adjoint of the (fixed-alpha) forward in z for uniform attention
+    att0 = torch.zeros(1, K, 2 * D, device=DEV)
+    zg = x.clone().requires_grad_(True)
+    (ops.gat_aggregate(zg, att0, None, p, K) * y).sum().backward()
+    out0 = ops.gat_aggregate(x, att0, None, p, K)
+    lhs = (out0.double() * y.double()).sum()
+    rhs = (x.double() * zg.grad.double()).sum()
+    assert abs(lhs - rhs).item() < 1e-5 * max(1.0, abs(lhs).item())
