@@ -34,7 +34,9 @@ __global__ void __launch_bounds__(256) k_gemm_ks(const GemmArgs a) {
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int li = lane & 31, lk = lane >> 5;
-    const bool vecA = (a.lda % 4 == 0), vecB = (a.ldb % 4 == 0);
+    const bool vecA = (a.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(pr.A) & 15) == 0);
+    const bool vecB = (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(pr.B) & 15) == 0);
+    const bool vecC = (a.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(pr.C) & 15) == 0);
 
     if (XA > 0) {
         for (int t = threadIdx.x; t < K; t += 256) {
@@ -152,7 +154,7 @@ __global__ void __launch_bounds__(256) k_gemm_ks(const GemmArgs a) {
     }
     if (pr.C && rok) {
         float* dst = pr.C + (size_t)grow * a.ldc + gcol;
-        if (gcol + 3 < N && (a.ldc % 4 == 0)) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        if (gcol + 3 < N && vecC) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
         else
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (gcol + j < N) dst[j] = o[j];
@@ -206,7 +208,6 @@ int launch_gemm_ks(bool transB, const GemmArgs& a, int nbatch, hipStream_t strea
         if (a.p[b].xb.has_bn || a.p[b].xb.rs || (a.p[b].xa.rs && !a.p[b].xa.has_bn)) { set_error("launch_gemm_ks: unsupported operand transform"); return 2; }
         if (xa >= 0 && xa != ma) { set_error("launch_gemm_ks: mixed operand transforms in one batch"); return 2; }
         xa = ma;
-        if (!aligned16(a.p[b].A) || !aligned16(a.p[b].B)) { set_error("launch_gemm_ks: operands must be 16 B aligned"); return 2; }
     }
     if (xa > 0 && a.K > KS_XMAX) { set_error("launch_gemm_ks: K > %d with a BN-transformed operand", KS_XMAX); return 2; }
     dim3 grid(cdiv(a.M, TM), cdiv(a.N, TN), nbatch);

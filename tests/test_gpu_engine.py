@@ -192,3 +192,59 @@ def test_properties_at_full_size():
     for u, v in zip(out1, out2):
         assert torch.allclose(u, v, atol=1e-6)
     m.load_state_dict(state)
+
+
+def _ragged_batch(seed, nfeat, sizes):
+    """Graphs of very different sizes: single node, no edges, a star, random ones, explicit self loops."""
+    from cal_amd.data import Batch, Data
+    g = torch.Generator().manual_seed(seed)
+    ds = []
+    for i, n in enumerate(sizes):
+        if n == 1:
+            ei = torch.zeros(2, 0, dtype=torch.long)
+        elif i % 4 == 1:
+            ei = torch.zeros(2, 0, dtype=torch.long)                      # edgeless graph
+        elif i % 4 == 2:
+            leaves = torch.arange(1, n)
+            ei = torch.cat([torch.stack([torch.zeros_like(leaves), leaves]), torch.stack([leaves, torch.zeros_like(leaves)])], 1)
+        else:
+            a = torch.rand(n, n, generator=g) < 0.2
+            a = a | a.t()
+            a.fill_diagonal_(False)
+            a[0, 0] = True                                               # explicit self loop: dropped by the convs
+            ei = a.nonzero().t().contiguous()
+        ds.append(Data(x=torch.randn(n, nfeat, generator=g), edge_index=ei, y=torch.randint(0, 3, (1,), generator=g)))
+    return Batch.from_data_list(ds)
+
+
+@pytest.mark.parametrize("hidden,layers,nfeat,ncls,sizes", [
+    (64, 1, 7, 3, [1, 5, 9, 33, 2, 17, 64, 3]),
+    (256, 2, 10, 2, [40, 1, 70, 12, 90]),
+    (32, 4, 3, 5, [6, 6, 6]),
+    (128, 0, 10, 4, [20, 30, 25, 8]),
+])
+def test_ragged_and_odd_shapes(hidden, layers, nfeat, ncls, sizes):
+    torch.manual_seed(hidden + layers)
+    b = _ragged_batch(hidden, nfeat, sizes)
+    bd = _ragged_batch(hidden, nfeat, sizes).to(DEV)
+    b.y = b.y % ncls
+    bd.y = bd.y % ncls
+    sd = O.init_state("CausalGCN", nfeat, ncls, hidden=hidden, layers=layers)
+    g = torch.Generator().manual_seed(7)
+    for k in list(sd):
+        if k.endswith(".bias") or ("bn" in k and k.endswith(".weight")):
+            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=g)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(hidden=hidden, layers=layers), nfeat, ncls)
+    B = len(sizes)
+    perm = torch.randperm(B)
+    tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, ncls, lr=1e-3, layers=layers)
+    loss, lc, lo, lco, logits = tr.step(b.x, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=False).cpu().numpy()
+    lp = eng.buffer("logp", 3 * B * ncls).view(3, B, ncls).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is not None:
+            assert torch.allclose(p.grad.cpu(), gref, atol=1e-4, rtol=3e-3), k
