@@ -23,7 +23,8 @@ namespace cal {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int BM = 64, BN = 64, BK = 32;   // BK = 64 measured slower (9.6 vs 8.8 us at K = 128)
+constexpr int NQ = BM * BK / 4 / 256;   // float4 per thread per operand tile
 constexpr int LDT = 65;   // LDS row stride (floats) for tiles filled by transposing scalar stores
 constexpr int LDD = 68;   // LDS row stride for tiles filled by direct 16B stores
 constexpr int XMAX = 512; // max feature width of a BN-transformed k-contiguous operand
@@ -34,10 +35,10 @@ constexpr int XMAX = 512; // max feature width of a BN-transformed k-contiguous 
 // FULL = interior tile: unconditional 16 B loads.  Otherwise every element is loaded from a clamped
 // (always valid) address and zeroed at store time -- no divergent control flow either way.
 template <bool KC, bool FULL>
-__device__ __forceinline__ void tile_load(float4 (&r)[2], const float* __restrict__ p, int ld, int mn0, int mn_end,
+__device__ __forceinline__ void tile_load(float4 (&r)[NQ], const float* __restrict__ p, int ld, int mn0, int mn_end,
                                           int k0, int k_end) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int f = threadIdx.x + q * 256;
         const int mn = KC ? f / (BK / 4) : (f % (BM / 4)) * 4;
         const int k = KC ? (f % (BK / 4)) * 4 : f / (BM / 4);
@@ -59,12 +60,12 @@ __device__ __forceinline__ void tile_load(float4 (&r)[2], const float* __restric
 // XF: 0 = plain, 1 = BN scale/shift on the feature axis, 2 = per-storage-row scale, then BN.
 // sc/sh: LDS tables indexed by (k - kb) for KC operands and by the tile-local mn for !KC ones.
 template <bool KC, bool FULL, int XF>
-__device__ __forceinline__ void tile_store(const float4 (&r)[2], float* __restrict__ s, int mn0, int mn_end, int k0,
+__device__ __forceinline__ void tile_store(const float4 (&r)[NQ], float* __restrict__ s, int mn0, int mn_end, int k0,
                                            int k_end, int kb, const float* __restrict__ rsp, int rs_stride,
                                            const float* sc, const float* sh) {
     constexpr int LD = KC ? LDT : LDD;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int f = threadIdx.x + q * 256;
         const int mn = KC ? f / (BK / 4) : (f % (BM / 4)) * 4;
         const int k = KC ? (f % (BK / 4)) * 4 : f / (BM / 4);
@@ -101,7 +102,7 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& a, const GemmProb& pr
     constexpr int LDA = A_KC ? LDT : LDD, LDB = B_KC ? LDT : LDD;
     constexpr int SA = BK * LDA, SB = BK * LDB;
     const int M = a.M, N = a.N;
-    float4 ra[2], rb[2];
+    float4 ra[NQ], rb[NQ];
     tile_load<A_KC, FULL>(ra, pr.A, a.lda, m0, M, kb, ke);
     tile_load<B_KC, FULL>(rb, pr.B, a.ldb, n0, N, kb, ke);
     tile_store<A_KC, FULL, XA>(ra, As, m0, M, kb, ke, kb, pr.xa.rs, pr.xa.rs_stride, sca, sha);

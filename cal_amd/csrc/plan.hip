@@ -44,7 +44,9 @@ __global__ void k_plan_count(const int64_t* __restrict__ ei, int64_t E, int N,
     }
 }
 
-// Single-workgroup exclusive scan of n counters into n+1 offsets; block y picks the array.
+// Single-workgroup exclusive scan of n counters into n+1 offsets; blockIdx.x picks the array.
+// Each thread owns 8 consecutive counters (serial prefix in registers), the 1024 thread totals are
+// scanned with wave shuffles + one LDS step: one pass (3 barriers) per 8192 elements.
 __global__ void __launch_bounds__(1024) k_plan_scan(const int* __restrict__ cnt_a, int* __restrict__ ptr_a,
                                                     const int* __restrict__ cnt_b, int* __restrict__ ptr_b,
                                                     int n) {
@@ -52,13 +54,16 @@ __global__ void __launch_bounds__(1024) k_plan_scan(const int* __restrict__ cnt_
     int* ptr = blockIdx.x == 0 ? ptr_a : ptr_b;
     __shared__ int wave_tot[16];
     __shared__ int carry_s;
-    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        int i = base + threadIdx.x;
-        int v = i < n ? cnt[i] : 0;
-        int x = v;
+    for (int base = 0; base < n; base += 8192) {
+        const int i0 = base + threadIdx.x * 8;
+        int v[8];
+        int tsum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = (i0 + j < n) ? cnt[i0 + j] : 0; tsum += v[j]; }
+        int x = tsum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             int y = __shfl_up(x, o, 64);
@@ -66,10 +71,12 @@ __global__ void __launch_bounds__(1024) k_plan_scan(const int* __restrict__ cnt_
         }
         if (lane == 63) wave_tot[wid] = x;
         __syncthreads();
-        int carry = carry_s;
+        const int carry = carry_s;
         int woff = 0;
         for (int w = 0; w < wid; ++w) woff += wave_tot[w];
-        if (i < n) ptr[i] = carry + woff + x - v;
+        int run = carry + woff + x - tsum;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { if (i0 + j < n) ptr[i0 + j] = run; run += v[j]; }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + woff + x;
         __syncthreads();
