@@ -891,6 +891,29 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     return 0;
 }
 
+// Backward from an external gradient (autograd surface): `dlogp` [3,B,C] = d loss / d log-probs of
+// the LAST training-mode forward of the same batch (cal_engine_step with mode = 1); fills the flat
+// gradient buffer exactly like mode bit 2.  The forward's activations, plan and statistics are
+// taken from the workspace, so no other step may run in between.
+CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t* batch, const float* dlogp, int64_t N,
+                                        int64_t E, int64_t B, void* stream_) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e && e->ws, "engine has no workspace");
+    CAL_REQUIRE(N <= e->capN && E <= e->capE && B <= e->capB && N > 0 && B > 0, "bad batch sizes");
+    Ctx c;
+    c.e = e; c.st = (hipStream_t)stream_; c.N = (int)N; c.B = (int)B; c.E = E;
+    c.training = 1;
+    c.rpb_n = std::max(32, cdiv(N, 1024));
+    c.rpb_b = std::max(32, cdiv(B, 64));
+    c.parts_off = 0; c.fin.nt = 0; c.nfork = 0;
+    hipLaunchKernelGGL(k_logsoftmax_bwd, dim3(1), dim3(256), 0, c.st, e->logp, dlogp, e->dzl, e->arena + e->a_db2, (int)B, e->C);
+    CAL_CHECK_LAUNCH("k_logsoftmax_bwd");
+    g_stage = 0;
+    int rc = engine_backward(c, x0, batch);
+    if (rc) join_side(c);
+    return rc == -12345 ? 0 : rc;
+}
+
 CAL_EXPORT int cal_engine_debug_stop(int k) { g_stop_after = k; return 0; }
 
 // Live timing (bench.py roofline): enable, run steps eagerly, synchronise, read.

@@ -438,6 +438,33 @@ __global__ void __launch_bounds__(256) k_loss(const float* __restrict__ z, const
     }
 }
 
+// log_softmax backward for an EXTERNAL loss (the nn.Module / autograd surface): given d loss / d logp
+// for the three heads, dz = g - exp(logp) * rowsum(g), plus the fc2 bias gradients.  One workgroup.
+__global__ void __launch_bounds__(256) k_logsoftmax_bwd(const float* __restrict__ logp, const float* __restrict__ g,
+                                                        float* __restrict__ dz, double* __restrict__ db2, int B, int C) {
+    __shared__ double red[256];
+    for (int t = threadIdx.x; t < 3 * B; t += 256) {
+        float rs = 0.f;
+        for (int k = 0; k < C; ++k) rs += g[(size_t)t * C + k];
+        for (int k = 0; k < C; ++k) dz[(size_t)t * C + k] = g[(size_t)t * C + k] - expf(logp[(size_t)t * C + k]) * rs;
+    }
+    __syncthreads();
+    const int nc = 3 * C, nl = 256 / nc;
+    const int cidx = threadIdx.x % nc, pl = threadIdx.x / nc;
+    double sacc = 0.0;
+    if (pl < nl) {
+        const int hd = cidx / C, k = cidx % C;
+        for (int b = pl; b < B; b += nl) sacc += (double)dz[((size_t)hd * B + b) * C + k];
+    }
+    red[threadIdx.x] = sacc;
+    __syncthreads();
+    if (threadIdx.x < nc) {
+        double tsum = 0.0;
+        for (int q = 0; q < nl; ++q) tsum += red[q * nc + threadIdx.x];
+        db2[threadIdx.x] = tsum;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // BatchNorm backward (elementwise part) + ReLU mask of the producer + bias-gradient column sums.
 //   dy = gamma*rstd*(dyh - m1 - x_n*m2) * [relu ? (x > 0) : 1],  x_n = (x - mean)*rstd,

@@ -134,6 +134,7 @@ class StepEngine:
         if x.dtype != torch.float32 or x.size(1) != self.F:
             raise ValueError("features must be float32 [N, %d]" % self.F)
         self.reserve(N, E, B)
+        self._last_B = B
         if perm is None:
             perm = torch.arange(B, device=self.device)
         if y is None:
@@ -155,3 +156,53 @@ class StepEngine:
 
     def adam(self):
         _lib.call("cal_engine_adam", self._h, _stream())
+
+    def backward_from(self, batch, dlogp: torch.Tensor):
+        """Backward of the LAST training-mode ``forward`` of ``batch`` from an external
+        gradient w.r.t. its three log-prob outputs (``dlogp`` [3, B, C]); fills ``flat_g``."""
+        x = batch.x if getattr(batch, "x", None) is not None else batch.feat
+        N, E, B = x.size(0), batch.edge_index.size(1), int(batch.num_graphs)
+        dlogp = dlogp.contiguous()
+        assert dlogp.shape == (3, B, self.C) and dlogp.dtype == torch.float32 and dlogp.is_cuda
+        _lib.call("cal_engine_backward_from", self._h, _p(x.contiguous()), _p(batch.batch.contiguous()), _p(dlogp),
+                  N, E, B, _stream())
+
+
+class _EngineAutograd(torch.autograd.Function):
+    """The whole CausalGCN forward as ONE autograd node on the native engine (nn.Module surface):
+    forward = cal_engine_step(mode 1), backward = cal_engine_backward_from.  The parameter gradients
+    land in the engine's flat gradient buffer, of which every ``p.grad`` is (re)made a view."""
+
+    @staticmethod
+    def forward(ctx, eng: "StepEngine", batch, perm, anchor):
+        c, o, co = eng.forward(batch, perm, training=True)
+        ctx.eng, ctx.batch = eng, batch
+        eng._fwd_token = getattr(eng, "_fwd_token", 0) + 1
+        ctx.token = eng._fwd_token
+        return c.clone(), o.clone(), co.clone()
+
+    @staticmethod
+    def backward(ctx, gc, go, gco):
+        eng = ctx.eng
+        if ctx.token != eng._fwd_token:
+            raise RuntimeError("cal_amd engine: another forward ran before this backward "
+                               "(the engine keeps one step's activations)")
+        B, C = eng._last_B, eng.C
+        z = torch.zeros(B, C, dtype=torch.float32, device=eng.device)
+        g = torch.stack([t if t is not None else z for t in (gc, go, gco)]).to(torch.float32)
+        eng.backward_from(ctx.batch, g)
+        eng._fwd_token += 1                                   # a second backward would double-count
+        off = 0
+        for p in eng.model.parameters():                      # hand the gradients to autograd's owners
+            n = p.numel()
+            view = eng.flat_g[off:off + n].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                p.grad = view if p.grad is None else p.grad.add_(view)
+            off += n
+        return None, None, None, None
+
+
+def engine_forward_autograd(eng: "StepEngine", batch, perm):
+    """(c, o, co) log-probs with autograd support through the native engine."""
+    anchor = next(eng.model.parameters())       # any leaf that requires grad: makes the node differentiable
+    return _EngineAutograd.apply(eng, batch, perm, anchor)

@@ -11,6 +11,7 @@ built per batch and shared by every layer.
 """
 from __future__ import annotations
 
+import os
 import random
 from functools import partial
 
@@ -72,8 +73,36 @@ class _CausalBase(torch.nn.Module):
     def _backbone(self, x, edge_index, plan):
         raise NotImplementedError
 
+    #: CausalGCN only: run forward/backward on the native step engine (cal_amd/csrc/engine.hip)
+    #: behind this same nn.Module / autograd surface.  Set False for the operator-level path.
+    use_engine = os.environ.get("CAL_AMD_ENGINE", "1") != "0"
+
+    def _engine_for(self, x):
+        from . import engine as eng_mod
+        if not (self.use_engine and x.is_cuda and isinstance(self, CausalGCN) and eng_mod.supported(self)):
+            return None
+        eng = getattr(self, "_engine", None)
+        p0 = next(self.parameters())
+        if eng is not None:
+            lo = eng.flat_p.data_ptr()
+            if not (lo <= p0.data_ptr() < lo + 4 * eng.flat_p.numel()):
+                eng = None                                   # parameters were moved (.to/.cuda): rebuild
+        if eng is None:
+            eng = eng_mod.StepEngine(self)
+            object.__setattr__(self, "_engine", eng)
+        return eng
+
     def forward(self, data, eval_random=True, perm=None):
         x = data.x if data.x is not None else data.feat
+        eng = self._engine_for(x)
+        if eng is not None:
+            from .engine import engine_forward_autograd
+            if perm is None:
+                perm = self.intervention_index(int(data.num_graphs), eval_random)
+            perm = perm.to(x.device)
+            if self.training and torch.is_grad_enabled():
+                return engine_forward_autograd(eng, data, perm)
+            return tuple(t.clone() for t in eng.forward(data, perm, training=self.training))
         edge_index = data.edge_index
         plan = plan_of(data)
         x = self.bn_feat(x)

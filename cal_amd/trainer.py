@@ -86,6 +86,7 @@ class CausalTrainer:
         if use_engine is None:
             use_engine = eng_mod.supported(model)
         self.engine = None
+        model.use_engine = False        # the trainer drives the engine itself; the module path stays op-level
         if use_engine:
             self.engine = eng_mod.StepEngine(model, lr=lr, weight_decay=weight_decay,
                                              flat=(self.flat_p, self.flat_g))

@@ -144,6 +144,9 @@ CAL_API int cal_engine_step(void* engine, const float* x0, const int64_t* edge_i
                             int64_t E, int64_t B, float wc, float wo, float wco, int mode,
                             void* stream);
 CAL_API int cal_engine_adam(void* engine, void* stream);
+/* backward from an external d loss / d log-probs [3,B,C] of the last training-mode forward (autograd surface) */
+CAL_API int cal_engine_backward_from(void* engine, const float* x0, const int64_t* batch,
+                                     const float* dlogp, int64_t N, int64_t E, int64_t B, void* stream);
 /* profiling aid: make cal_engine_step return after its k-th launch site (0 = run everything) */
 CAL_API int cal_engine_debug_stop(int k);
 /* live HIP-event timing of the node-level GEMMs (class 0, work = flops) and aggregations (class 1,

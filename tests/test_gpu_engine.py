@@ -248,3 +248,40 @@ def test_ragged_and_odd_shapes(hidden, layers, nfeat, ncls, sizes):
         gref = tr.sd[k].grad
         if gref is not None:
             assert torch.allclose(p.grad.cpu(), gref, atol=1e-4, rtol=3e-3), k
+
+
+def test_module_surface_reference_loop_on_engine():
+    """The reference's own loop shape (train_causal.py:162-200): model(data) -> torch loss ->
+    loss.backward() -> torch Adam -> zero_grad(), with CausalGCN running on the engine behind the
+    autograd surface; must track the oracle trainer step by step, and eval must not train."""
+    from cal_amd import model as M
+    from cal_amd.train_causal import causal_loss
+    b, bd = _config2_batch(48, seed=8)
+    torch.manual_seed(12)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=2)
+    args = _args(layers=2, hidden=64)
+    m = M.CausalGCN(10, 4, args)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-2, layers=2)
+    g = torch.Generator().manual_seed(1)
+    for step in range(3):
+        perm = torch.randperm(48, generator=g)
+        ref_loss, *_ = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+        m.train()
+        opt.zero_grad()                                   # set_to_none: the views are re-attached in backward
+        c, o, co = m(bd, eval_random=True, perm=perm)
+        assert getattr(m, "_engine", None) is not None and c.requires_grad
+        loss, *_ = causal_loss(c, o, co, bd.y, 4, args)
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - ref_loss.item()) < 3e-3 * (step + 1), step
+        m.eval()
+        with torch.no_grad():
+            ev = m(bd, eval_random=False)
+        ref_ev = O.causal_forward("CausalGCN", {k: v.clone() for k, v in tr.sd.items()}, b.feat, b.edge_index, b.batch,
+                                  training=False, layers=2)
+        for r, t in zip(ref_ev, ev):
+            assert (r.detach() - t.cpu()).abs().max().item() < 5e-3
+    assert int(m.bn_feat.num_batches_tracked.item()) == 3

@@ -24,22 +24,27 @@ def _args(**kw):
     return argparse.Namespace(**d)
 
 
-def _build(name, nfeat, ncls, args, sd=None):
+def _build(name, nfeat, ncls, args, sd=None, use_engine=None):
     from cal_amd import model as M
     m = getattr(M, name)(nfeat, ncls, args)
+    if use_engine is not None:
+        m.use_engine = use_engine
     if sd is not None:
         m.load_state_dict(sd)
     return m.to(DEV)
 
 
-@pytest.mark.parametrize("name,fname", [("CausalGCN", "causal_gcn_batch8.npz"),
-                                        ("CausalGAT", "causal_gat_batch8.npz")])
-def test_golden_fixture_eval_and_train_step(name, fname):
+@pytest.mark.parametrize("name,fname,use_engine", [("CausalGCN", "causal_gcn_batch8.npz", False),
+                                                   ("CausalGCN", "causal_gcn_batch8.npz", True),
+                                                   ("CausalGAT", "causal_gat_batch8.npz", False)])
+def test_golden_fixture_eval_and_train_step(name, fname, use_engine):
+    """nn.Module surface + torch loss + torch Adam, on the operator-level path and (CausalGCN) on the
+    native engine behind the same autograd surface."""
     fx = np.load(os.path.join(GOLDEN, fname))
     b = ref_batch(list(fx["ids"]))
     sd = {k[3:]: torch.from_numpy(fx[k]).clone() for k in fx.files if k.startswith("sd.")}
     perm = torch.from_numpy(fx["perm"])
-    m = _build(name, 10, 4, _args(layers=2, hidden=32), sd)
+    m = _build(name, 10, 4, _args(layers=2, hidden=32), sd, use_engine)
     bd = ref_batch(list(fx["ids"])).to(DEV)
     m.eval()
     with torch.no_grad():
@@ -59,7 +64,7 @@ def test_golden_fixture_eval_and_train_step(name, fname):
     loss, lc, lo, lco = O.causal_loss(*logits, bd.y, 4)
     assert np.allclose([loss.item(), lc.item(), lo.item(), lco.item()], fx["loss"], atol=1e-4)
     loss.backward()
-    assert m.conv_feat.bias.grad is None
+    assert m.conv_feat.bias.grad is None or m.conv_feat.bias.grad.abs().max().item() == 0
     for k, p in m.named_parameters():
         g = fx[f"grad.{k}"]
         if g.size == 0:
@@ -69,7 +74,11 @@ def test_golden_fixture_eval_and_train_step(name, fname):
     post = m.state_dict()
     for k in post:
         if f"post.{k}" in fx.files:
-            assert np.allclose(post[k].cpu().numpy(), fx[f"post.{k}"], atol=2e-4, rtol=1e-3), k
+            a, b = post[k].cpu().numpy(), fx[f"post.{k}"]
+            if f"grad.{k}" in fx.files and fx[f"grad.{k}"].size:      # Adam's first step is +-lr where |g| ~ 0
+                keep = np.abs(fx[f"grad.{k}"]) > 1e-6
+                a, b = a[keep], b[keep]
+            assert np.allclose(a, b, atol=2e-4, rtol=1e-3), k
 
 
 @pytest.mark.parametrize("name", ["CausalGCN", "CausalGAT"])
