@@ -121,6 +121,14 @@ CAL_API int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const
 CAL_API int cal_gat_dropout_mask(uint64_t seed, int64_t E, int64_t N, int64_t K, float p,
                                  float* mask, void* stream);
 
+/* ---- on-device mini-batch assembly (PyG DataLoader / Batch collate, train_causal.py:13-15,171-174)
+ * over a device-resident concatenated dataset; offsets of the selected graphs computed by the host */
+CAL_API int cal_collate(const float* X, const int64_t* EI, int64_t sumE, int64_t F,
+                        const int64_t* node_ptr, const int64_t* edge_ptr, const int64_t* Y,
+                        const int64_t* sel, const int64_t* out_node_off, const int64_t* out_edge_off,
+                        float* xo, int64_t* eio, int64_t Eout, int64_t* batcho, int64_t* yo, int64_t B,
+                        void* stream);
+
 /* ---- native CausalGCN step engine ------------------------------------------------
  * The whole train step of train_causal.py:173-192 on model.py:85-164 (forward, 3-term loss,
  * backward, Adam) as one call enqueuing ~55 fused kernels; see cal_amd/csrc/engine.hip for the
