@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (batch assembly included) figure")
     ap.add_argument("--no-engine", action="store_true", help="operator-level autograd path instead of the native step engine")
     return ap.parse_args()
 
@@ -215,6 +216,49 @@ def engine_roofline(trainer, batches, iters=20):
     return roof
 
 
+def end_to_end(wl, margs, steps=60):
+    """Secondary figure: graphs/s of real epochs INCLUDING batch assembly --
+    shuffled permutation, on-device collate of a device-resident dataset (cal_collate), eager
+    engine step (shapes change every step, so no graph replay) -- next to the same loop fed by the
+    host-side Python collate the reference's DataLoader does."""
+    from cal_amd import model as M, spmotif
+    from cal_amd.data import DataLoader
+    from cal_amd.device_data import DeviceDataset, DeviceLoader
+    from cal_amd.trainer import CausalTrainer
+    gs = spmotif.train_mix(16 * wl["batch"], bias=0.9, node_num=wl["node_num"], seed=4242)
+    res = {}
+    for kind in ("device_collate", "host_collate"):
+        torch.manual_seed(1)
+        model = getattr(M, wl["model"])(10, 4, margs).cuda()
+        tr = CausalTrainer(model, margs, lr=1e-3, use_graph=False)
+        ds = DeviceDataset(gs) if kind == "device_collate" else None
+
+        def loader(epoch):
+            g = torch.Generator().manual_seed(epoch)
+            if ds is not None:
+                return DeviceLoader(ds, wl["batch"], shuffle=True, generator=g)
+            return DataLoader(gs, wl["batch"], shuffle=True, generator=g)
+
+        n_steps, n_graphs, epoch = 0, 0, 0
+        for b in loader(0):                      # warm-up epoch (workspace sizing, code paths)
+            tr.step(b if ds is not None else b.to("cuda"))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while n_steps < steps:
+            epoch += 1
+            for b in loader(epoch):
+                tr.step(b if ds is not None else b.to("cuda"))
+                n_steps += 1
+                n_graphs += b.num_graphs
+                if n_steps >= steps:
+                    break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[kind] = {"graphs_per_s": n_graphs / dt, "ms_per_step": 1e3 * dt / n_steps}
+    res["note"] = "epochs over a 2048-graph dataset, shuffled, eager engine step; includes batch assembly"
+    return res
+
+
 def main():
     a = parse()
     wl = WORKLOADS[a.workload]
@@ -316,6 +360,11 @@ def main():
                     out["roofline"] = spmm_roofline(trainer, batches, wl)
             except Exception as exc:
                 out["roofline"] = {"error": repr(exc)}
+        if not a.no_e2e:
+            try:
+                out["end_to_end"] = end_to_end(wl, margs)
+            except Exception as exc:
+                out["end_to_end"] = {"error": repr(exc)}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, batches_cpu, a.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

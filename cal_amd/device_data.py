@@ -37,7 +37,8 @@ class DeviceDataset:
         self.node_ptr = torch.from_numpy(self.node_ptr_h).to(dev)
         self.edge_ptr = torch.from_numpy(self.edge_ptr_h).to(dev)
         self.device = dev
-        self._pin = None
+        self._pin = []          # ring of (pinned buffer, event): the async H2D copy of step k may still be
+        self._pin_i = 0         # pending when the host prepares step k+1
 
     def __len__(self):
         return self.G
@@ -52,13 +53,19 @@ class DeviceDataset:
         N, E = int(noff[-1]), int(eoff[-1])
         # one pinned staging buffer for [sel | node offsets | edge offsets]
         need = 3 * B + 2
-        if self._pin is None or self._pin.numel() < need:
-            self._pin = torch.empty(max(need, 4096), dtype=torch.long).pin_memory()
-        host = self._pin[:need]
-        host[:B] = torch.from_numpy(idx)
+        if not self._pin or self._pin[0][0].numel() < need:
+            self._pin = [[torch.empty(max(need, 4096), dtype=torch.long).pin_memory(), None] for _ in range(16)]
+        slot = self._pin[self._pin_i]
+        self._pin_i = (self._pin_i + 1) % len(self._pin)
+        if slot[1] is not None:
+            slot[1].synchronize()                     # the copy that last used this buffer has run
+        host = slot[0][:need]
+        host[:B] = torch.from_numpy(np.ascontiguousarray(idx))
         host[B:2 * B + 1] = torch.from_numpy(noff)
         host[2 * B + 1:] = torch.from_numpy(eoff)
         meta = host.to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
         b = Batch()
         xo = torch.empty(N, self.F, dtype=torch.float32, device=self.device)
         b.edge_index = torch.empty(2, E, dtype=torch.long, device=self.device)

@@ -52,3 +52,27 @@ def test_epoch_on_device_loader_trains():
             first = tot / n
         last = tot / n
     assert n == 256 and last < first
+
+
+def test_device_collate_back_to_back_without_syncs():
+    """The host runs ahead of the GPU: staging buffers must not be overwritten before their async
+    copy has executed (regression test for a pinned-buffer race)."""
+    from cal_amd import spmotif
+    from cal_amd.data import Batch
+    from cal_amd.device_data import DeviceDataset
+    gs = spmotif.train_mix(512, seed=9)
+    ds = DeviceDataset(gs)
+    big = torch.randn(4096, 4096, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    outs, idxs = [], []
+    for i in range(64):
+        if i % 8 == 0:
+            big = big @ big * 1e-4          # keep the GPU busy so copies queue up behind it
+        idx = torch.randperm(512, generator=g)[:128].numpy()
+        outs.append(ds.collate(idx))
+        idxs.append(idx)
+    torch.cuda.synchronize()
+    for out, idx in zip(outs[-20:], idxs[-20:]):
+        ref = Batch.from_data_list([gs[i] for i in idx])
+        assert torch.equal(out.edge_index.cpu(), ref.edge_index) and torch.equal(out.feat.cpu(), ref.feat)
+        assert torch.equal(out.batch.cpu(), ref.batch) and torch.equal(out.y.cpu(), ref.y)
