@@ -20,6 +20,7 @@ LIB = os.path.join(LIBDIR, "libcalhip.so")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-ffp-contract=on", "-munsafe-fp-atomics"]
+FLAGS += os.environ.get("CAL_HIPCC_EXTRA", "").split()      # e.g. -DCAL_RO_CLOCKS (profiling builds)
 
 
 def _hipcc() -> str:

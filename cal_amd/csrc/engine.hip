@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "engine_kernels.hpp"
+#include "engine_readout.hpp"
 
 namespace cal {
 
@@ -31,9 +32,13 @@ struct FinishArgs {
     SlabTask st[MAX_SLABS];
     CommitTask ct[MAX_COMMITS];
     int nst, nct;
+    float* stats;            // fused readout: stats[0] = wc*stats[1] + wo*stats[2] + wco*stats[3]
+    float wc, wo, wco;
 };
 __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __restrict__ grad) {
     const int task = blockIdx.y;
+    if (fa.stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        fa.stats[0] = fa.wc * fa.stats[1] + fa.wo * fa.stats[2] + fa.wco * fa.stats[3];
     if (task < fa.nst) {
         const SlabTask t = fa.st[task];
         for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n; i += gridDim.x * 256) {
@@ -275,6 +280,7 @@ struct Ctx {
     int training;
     int rpb_n, rpb_b;   // rows per block for node-level / graph-level row walkers
     int nfork;          // weight-gradient GEMMs forked to the side stream so far
+    const int64_t* y; const int64_t* perm; float wc, wo, wco; int want_grad;
     size_t parts_off;   // bump allocator over Engine::parts
     FinalArgs fin;      // pending k_stats_final tasks
 };
@@ -416,6 +422,37 @@ void join_side(Ctx& c) {
     c.nfork = 0;
 }
 
+bool use_ro(const Ctx& c) {
+    const int B = c.B, H = c.e->H, C = c.e->C;
+    const int B4 = (B + 15) & ~15;
+    return (size_t)B4 * (H + 4) <= (size_t)RO_LDS && B * H <= 16384 && H % RO_CW == 0 && B4 <= 256 && H <= 256 &&
+           B * C <= 2048 && C <= 64;
+}
+RoArgs make_ro(const Ctx& c) {
+    Engine* e = c.e;
+    const int L = e->L, H = e->H, C = e->C, B = c.B;
+    RoArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int hd = 0; hd < 3; ++hd) {
+        RoHead& h = a.h[hd];
+        const int k1 = L + 3 + 2 * hd, k2 = L + 4 + 2 * hd;
+        h.W1 = e->P + e->o_fc1_w[hd]; h.b1 = e->P + e->o_fc1_b[hd];
+        h.W2 = e->P + e->o_fc2_w[hd]; h.b2 = e->P + e->o_fc2_b[hd];
+        h.bn1 = bnref(c, k1, B, 1); h.bn2 = bnref(c, k2, B, 1);
+        h.st2_sum = bn_stsum(c, k2); h.st2_sq = bn_stsq(c, k2);
+        h.d1_sum = bn_dsum(c, k1); h.d1_prod = bn_dprod(c, k1);
+        h.d2_sum = bn_dsum(c, k2); h.d2_prod = bn_dprod(c, k2);
+        h.db1 = e->arena + e->a_db1 + hd * H; h.db2 = e->arena + e->a_db2 + hd * C;
+        h.gW1 = e->G + e->o_fc1_w[hd]; h.gW2 = e->G + e->o_fc2_w[hd];
+    }
+    a.pooled = e->pooled; a.perm = c.perm; a.iperm = e->iperm; a.xco = e->xco; a.y1 = e->y1;
+    a.zl = e->zl; a.logp = e->logp; a.dzl = e->dzl; a.dy1 = e->dy1; a.dxin = e->dxh;
+    a.rowloss = e->dyh1;                  // [4,B] scratch: the unfused path's dyh1 is idle here
+    a.y = c.y; a.stats = e->stats; a.B = B; a.H = H; a.C = C;
+    a.wc = c.wc; a.wo = c.wo; a.wco = c.wco; a.training = c.training; a.want_grad = c.want_grad;
+    return a;
+}
+
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 // live kernel timing for bench.py's roofline block: when enabled, HIP events are recorded on the
 // launch stream around every node-level dense GEMM ([N,H]x[H,H], class 0) and every aggregation
@@ -541,6 +578,18 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         CAL_CHECK_LAUNCH("k_pool2"); STAGE();
     }
     // 10. readouts (model.py:125-164)
+    if (use_ro(c)) {
+        const RoArgs ra = make_ro(c);
+        hipLaunchKernelGGL(k_ro_fwd_a, dim3(3, H / RO_CW), dim3(256), 0, st, ra);
+        CAL_CHECK_LAUNCH("k_ro_fwd_a"); STAGE();
+        hipLaunchKernelGGL(k_ro_fwd_b, dim3(3, cdiv(B, RO_RB)), dim3(256), 0, st, ra);
+        CAL_CHECK_LAUNCH("k_ro_fwd_b"); STAGE();
+        if (!want_grad) {                  // no backward to finish the loss sums
+            hipLaunchKernelGGL(k_ro_loss, dim3(3), dim3(256), 0, st, ra);
+            CAL_CHECK_LAUNCH("k_ro_loss");
+        }
+        return 0;
+    }
     const int bn_fc1 = L + 3, bn_fc2 = L + 4;   // + 2*head
     {
         int tc = std::min(256, pow2ceil(H));
@@ -604,8 +653,17 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     memset(d_convb, 0, sizeof(d_convb));
     d_bn0.p = nullptr;
 
+    const bool ro = use_ro(c);
+    if (ro) {
+        const RoArgs ra = make_ro(c);
+        hipLaunchKernelGGL(k_ro_bwd_a, dim3(3, H / RO_CW), dim3(256), 0, st, ra);
+        CAL_CHECK_LAUNCH("k_ro_bwd_a"); STAGE();
+        hipLaunchKernelGGL(k_ro_bwd_b, dim3(3, H / RO_CW), dim3(256), 0, st, ra);
+        CAL_CHECK_LAUNCH("k_ro_bwd_b"); STAGE();
+        fa.stats = e->stats; fa.wc = c.wc; fa.wo = c.wo; fa.wco = c.wco;
+    }
     // R1. dW2_h = dz_h^T @ BN2(y1_h)
-    {
+    if (!ro) {
         GemmArgs a = gemm_args(C, H, B, true, false, 0);
         float* dst[3];
         for (int hd = 0; hd < 3; ++hd) {
@@ -616,7 +674,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         RC(grad_gemm(c, a, 3, dst, fa, slab_off)); STAGE();
     }
     // R2. d(BN2 out)_h = dz_h @ W2_h, with the BN2-backward sums
-    {
+    if (!ro) {
         GemmArgs a = gemm_args(B, H, C, false, false, 0);
         for (int hd = 0; hd < 3; ++hd) {
             a.p[hd].A = e->dzl + (size_t)hd * B * C; a.p[hd].B = e->P + e->o_fc2_w[hd]; a.p[hd].C = e->dyh1 + hd * BH;
@@ -627,7 +685,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         RC(flush_finals(c)); STAGE();
     }
     // R3. BN2 backward + ReLU mask + fc1 bias gradients
-    {
+    if (!ro) {
         BnBwdProb p[3];
         for (int hd = 0; hd < 3; ++hd)
             p[hd] = BnBwdProb{e->dyh1 + hd * BH, e->y1 + hd * BH, e->dy1 + hd * BH, bnref(c, bn_fc2 + 2 * hd, B, 0),
@@ -640,7 +698,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         CAL_CHECK_LAUNCH("k_bn_bwd(readout)"); STAGE();
     }
     // R4. dW1_h = dy1_h^T @ BN1(xin_h)
-    {
+    if (!ro) {
         GemmArgs a = gemm_args(H, H, B, true, false, 0);
         float* dst[3];
         for (int hd = 0; hd < 3; ++hd) {
@@ -651,7 +709,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         RC(grad_gemm(c, a, 3, dst, fa, slab_off)); STAGE();
     }
     // R5. d(BN1 out)_h = dy1_h @ W1_h with the BN1-backward sums
-    {
+    if (!ro) {
         GemmArgs a = gemm_args(B, H, H, false, false, 0);
         for (int hd = 0; hd < 3; ++hd) {
             a.p[hd].A = e->dy1 + hd * BH; a.p[hd].B = e->P + e->o_fc1_w[hd]; a.p[hd].C = e->dxh + hd * BH;
@@ -662,7 +720,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         RC(flush_finals(c)); STAGE();
     }
     // R6. BN1 backward + un-permute the random intervention -> d pooled
-    {
+    if (!ro) {
         BnIn in[3];
         for (int hd = 0; hd < 3; ++hd)
             in[hd] = BnIn{e->dxh + hd * BH, xin[hd], bnref(c, bn_fc1 + 2 * hd, B, 0), bn_dsum(c, bn_fc1 + 2 * hd), bn_dprod(c, bn_fc1 + 2 * hd)};
@@ -675,8 +733,12 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         if (!acb.on() || !aob.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_pool_bwd_relu<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, e->dpool, batch, e->hco, e->hco + NH,
-                               e->dZco, e->dZco + NH, acb, aob, N, B, H, c.rpb_n);
+            if (ro)
+                hipLaunchKernelGGL((k_pool_bwd_relu_ro<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, e->dxh, e->iperm, batch,
+                                   e->hco, e->hco + NH, e->dZco, e->dZco + NH, acb, aob, N, B, H, c.rpb_n);
+            else
+                hipLaunchKernelGGL((k_pool_bwd_relu<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, e->dpool, batch, e->hco, e->hco + NH,
+                                   e->dZco, e->dZco + NH, acb, aob, N, B, H, c.rpb_n);
             return 0;
         }));
     }
@@ -868,6 +930,7 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     c.fin.nt = 0;
     c.nfork = 0;
     const int want_grad = (mode & 2) ? 1 : 0;
+    c.y = y; c.perm = perm; c.wc = wc; c.wo = wo; c.wco = wco; c.want_grad = want_grad;
     CAL_REQUIRE(!want_grad || c.training, "backward needs a training-mode forward");
     g_stage = 0;
     {
@@ -906,6 +969,7 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
     c.rpb_n = std::max(32, cdiv(N, 1024));
     c.rpb_b = std::max(32, cdiv(B, 64));
     c.parts_off = 0; c.fin.nt = 0; c.nfork = 0;
+    c.y = nullptr; c.perm = nullptr; c.wc = c.wo = c.wco = 0.f; c.want_grad = 1;
     hipLaunchKernelGGL(k_logsoftmax_bwd, dim3(1), dim3(256), 0, c.st, e->logp, dlogp, e->dzl, e->arena + e->a_db2, (int)B, e->C);
     CAL_CHECK_LAUNCH("k_logsoftmax_bwd");
     g_stage = 0;
@@ -915,6 +979,11 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
 }
 
 CAL_EXPORT int cal_engine_debug_stop(int k) { g_stop_after = k; return 0; }
+#ifdef CAL_RO_CLOCKS
+CAL_EXPORT int cal_debug_ro_clocks(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cal::g_ro_clk), sizeof(long long) * 64);
+}
+#endif
 
 // Live timing (bench.py roofline): enable, run steps eagerly, synchronise, read.
 CAL_EXPORT int cal_engine_profile(int on) {

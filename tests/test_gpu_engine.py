@@ -222,6 +222,11 @@ def _ragged_batch(seed, nfeat, sizes):
     (256, 2, 10, 2, [40, 1, 70, 12, 90]),
     (32, 4, 3, 5, [6, 6, 6]),
     (128, 0, 10, 4, [20, 30, 25, 8]),
+    # fused-readout corner cases: B not a multiple of 16 (several 16-graph row blocks, clamped MFMA tiles),
+    # hidden/4 not a divisor of 256 (LDS statistics pass), many classes (large fc2 tile, one lane per score)
+    (48, 1, 5, 3, [4, 2, 7] * 12 + [5]),
+    (80, 2, 4, 40, [3, 5] * 50),
+    (16, 1, 6, 2, [2, 3] * 100),
 ])
 def test_ragged_and_odd_shapes(hidden, layers, nfeat, ncls, sizes):
     torch.manual_seed(hidden + layers)
