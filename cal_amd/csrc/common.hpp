@@ -104,8 +104,11 @@ template <> struct Vec<1> {
 
 }  // namespace cal
 
+namespace cal { inline const char* g_last_launch = ""; }     // name of the latest launch site (profiling aid)
+
 #define CAL_CHECK_LAUNCH(name)                                               \
     do {                                                                     \
+        cal::g_last_launch = name;                                           \
         hipError_t e_ = hipGetLastError();                                   \
         if (e_ != hipSuccess) {                                              \
             cal::set_error("%s: %s", name, hipGetErrorString(e_));           \

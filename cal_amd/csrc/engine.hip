@@ -319,8 +319,9 @@ int flush_finals(Ctx& c) {
     if (c.fin.nt == 0) return 0;
     int nmax = 0;
     for (int i = 0; i < c.fin.nt; ++i) nmax = std::max(nmax, c.fin.t[i].n);
-    hipLaunchKernelGGL(k_stats_final, dim3(cdiv(nmax, 16), c.fin.nt), dim3(256), 0, c.st, c.fin);
+    hipLaunchKernelGGL(k_stats_final, dim3(cdiv(nmax, 8), c.fin.nt), dim3(256), 0, c.st, c.fin);
     c.fin.nt = 0;
+    cal::g_last_launch = "k_stats_final";
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) { set_error("k_stats_final: %s", hipGetErrorString(e_)); return 1; }
     return 0;
@@ -474,7 +475,9 @@ struct ProfScope {
 // profiling aid: cal_engine_debug_stop(k) makes the step return after its k-th launch site (0 = run all)
 static int g_stop_after = 0;
 static int g_stage = 0;
-#define STAGE() do { if (g_stop_after > 0 && ++g_stage >= g_stop_after) return -12345; } while (0)
+static std::vector<const char*> g_stage_names;      // launch-site names of the latest full step
+#define STAGE() do { if (g_stop_after == 0) g_stage_names.push_back(cal::g_last_launch); \
+                     if (g_stop_after > 0 && ++g_stage >= g_stop_after) return -12345; } while (0)
 
 int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int64_t* batch, const int64_t* y,
                    const int64_t* perm, float wc, float wo, float wco, int want_grad) {
@@ -492,7 +495,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     hipLaunchKernelGGL(k_gptr_dis, dim3(cdiv(N + 1, 256)), dim3(256), 0, st, batch, N, B, e->gptr, e->rowptr_src, e->loop_w,
                        e->dis_unit, e->status);
     CAL_CHECK_LAUNCH("k_gptr_dis"); STAGE();
-    const CSR gd{e->rowptr_dst, e->nbr_dst, e->eid_dst}, gs{e->rowptr_src, e->nbr_src, e->eid_src};
+    const CSR gd{e->rowptr_dst, e->nbr_dst, e->eid_dst, (int)c.E}, gs{e->rowptr_src, e->nbr_src, e->eid_src, (int)c.E};
     (void)gs;
     // 2. bn_feat statistics (model.py:90)
     if (c.training) {
@@ -631,7 +634,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     const int64_t E = c.E;
     hipStream_t st = c.st;
     const size_t NH = (size_t)N * H, BH = (size_t)B * H;
-    const CSR gd{e->rowptr_dst, e->nbr_dst, e->eid_dst}, gs{e->rowptr_src, e->nbr_src, e->eid_src};
+    const CSR gd{e->rowptr_dst, e->nbr_dst, e->eid_dst, (int)c.E}, gs{e->rowptr_src, e->nbr_src, e->eid_src, (int)c.E};
     const int bn_fc1 = L + 3, bn_fc2 = L + 4;
     const float* xin[3] = {e->pooled, e->pooled + BH, e->xco};
     FinishArgs fa;
@@ -933,6 +936,7 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     c.y = y; c.perm = perm; c.wc = wc; c.wo = wo; c.wco = wco; c.want_grad = want_grad;
     CAL_REQUIRE(!want_grad || c.training, "backward needs a training-mode forward");
     g_stage = 0;
+    g_stage_names.clear();
     {
         int rc = engine_forward(c, x0, edge_index, batch, y, perm, wc, wo, wco, want_grad);
         if (rc == -12345) return 0;
@@ -979,6 +983,10 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
 }
 
 CAL_EXPORT int cal_engine_debug_stop(int k) { g_stop_after = k; return 0; }
+// name of launch site k (1-based, as counted by cal_engine_debug_stop) in the latest untruncated step; "" past the end
+CAL_EXPORT const char* cal_engine_stage_name(int k) {
+    return k >= 1 && k <= (int)g_stage_names.size() ? g_stage_names[k - 1] : "";
+}
 #ifdef CAL_RO_CLOCKS
 CAL_EXPORT int cal_debug_ro_clocks(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cal::g_ro_clk), sizeof(long long) * 64);

@@ -28,13 +28,28 @@ constexpr int NQ = BM * BK / 4 / 256;   // float4 per thread per operand tile
 constexpr int LDT = 65;   // LDS row stride (floats) for tiles filled by transposing scalar stores
 constexpr int LDD = 68;   // LDS row stride for tiles filled by direct 16B stores
 constexpr int XMAX = 512; // max feature width of a BN-transformed k-contiguous operand
+#ifdef CAL_GEMM_CLOCKS                    // profiling aid: phase timestamps (100 MHz) of workgroup (1,0,0)
+__device__ long long g_gemm_clk[16];
+__device__ long long g_gemm_blk[2 * 2048];    // start / end timestamp of every workgroup (x + gridDim.x * y)
+#define GEMM_CLK(k) do { if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0) g_gemm_clk[k] = wall_clock64(); } while (0)
+#else
+#define GEMM_CLK(k) do {} while (0)
+#endif
+constexpr int PRE_T = 4;  // K tiles a workgroup can preload at once (K chunk <= 128): see gemm_preloaded
 
 // Operand tiles.  The operand is logically T[mn][k] (mn = row of A / column of B).
 //   KC = true : memory is [mn][k] row-major (k contiguous)  -> transposing LDS store
 //   KC = false: memory is [k][mn] row-major (mn contiguous) -> direct 16 B LDS store
-// FULL = interior tile: unconditional 16 B loads.  Otherwise every element is loaded from a clamped
-// (always valid) address and zeroed at store time -- no divergent control flow either way.
-template <bool KC, bool FULL>
+// MODE 0 = interior tile: unconditional 16 B loads.
+// MODE 1 = ragged in mn only (last row / column tile; K range whole, 16 B aligned, and for !KC
+//          operands mn_end % 4 == 0): 16 B loads from a CLAMPED row / column group.  The rows or
+//          columns past the end then hold copies of valid data, which only ever reach accumulator
+//          rows / columns the epilogue never stores -- no zeroing, same speed as an interior tile
+//          (the scalar path made the one ragged workgroup of a [7315,128] launch the critical path:
+//          18 us against 5.6 us for its 229 neighbours).
+// MODE 2 = anything else: every element from a clamped (always valid) address, zeroed at store time.
+// No divergent control flow in any mode.
+template <bool KC, int MODE>
 __device__ __forceinline__ void tile_load(float4 (&r)[NQ], const float* __restrict__ p, int ld, int mn0, int mn_end,
                                           int k0, int k_end) {
 #pragma unroll
@@ -42,9 +57,12 @@ __device__ __forceinline__ void tile_load(float4 (&r)[NQ], const float* __restri
         const int f = threadIdx.x + q * 256;
         const int mn = KC ? f / (BK / 4) : (f % (BM / 4)) * 4;
         const int k = KC ? (f % (BK / 4)) * 4 : f / (BM / 4);
-        if (FULL) {
+        if (MODE == 0) {
             r[q] = KC ? *reinterpret_cast<const float4*>(p + (size_t)(mn0 + mn) * ld + k0 + k)
                       : *reinterpret_cast<const float4*>(p + (size_t)(k0 + k) * ld + mn0 + mn);
+        } else if (MODE == 1) {
+            r[q] = KC ? *reinterpret_cast<const float4*>(p + (size_t)min(mn0 + mn, mn_end - 1) * ld + k0 + k)
+                      : *reinterpret_cast<const float4*>(p + (size_t)(k0 + k) * ld + min(mn0 + mn, mn_end - 4));
         } else if (KC) {
             const float* row = p + (size_t)min(mn0 + mn, mn_end - 1) * ld;
             const int kl = k_end - 1;
@@ -59,7 +77,7 @@ __device__ __forceinline__ void tile_load(float4 (&r)[NQ], const float* __restri
 
 // XF: 0 = plain, 1 = BN scale/shift on the feature axis, 2 = per-storage-row scale, then BN.
 // sc/sh: LDS tables indexed by (k - kb) for KC operands and by the tile-local mn for !KC ones.
-template <bool KC, bool FULL, int XF>
+template <bool KC, int MODE, int XF>
 __device__ __forceinline__ void tile_store(const float4 (&r)[NQ], float* __restrict__ s, int mn0, int mn_end, int k0,
                                            int k_end, int kb, const float* __restrict__ rsp, int rs_stride,
                                            const float* sc, const float* sh) {
@@ -79,7 +97,7 @@ __device__ __forceinline__ void tile_store(const float4 (&r)[NQ], float* __restr
                 v[j] = fmaf(XF == 2 ? rs * v[j] : v[j], sc[fi], sh[fi]);
             }
         }
-        if (!FULL) {
+        if (MODE == 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool ok = KC ? (mn0 + mn < mn_end && k0 + k + j < k_end) : (k0 + k < k_end && mn0 + mn + j < mn_end);
@@ -95,7 +113,7 @@ __device__ __forceinline__ void tile_store(const float4 (&r)[NQ], float* __restr
     }
 }
 
-template <bool A_KC, bool B_KC, int XA, int XB, bool FULL>
+template <bool A_KC, bool B_KC, int XA, int XB, int MODE>
 __device__ __forceinline__ void gemm_kloop(const GemmArgs& a, const GemmProb& pr, float* As, float* Bs, int m0, int n0,
                                            int kb, int ke, const float* sca, const float* sha, const float* scb,
                                            const float* shb, f32x16& acc, int wm, int wn, int li, int lk) {
@@ -103,17 +121,17 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& a, const GemmProb& pr
     constexpr int SA = BK * LDA, SB = BK * LDB;
     const int M = a.M, N = a.N;
     float4 ra[NQ], rb[NQ];
-    tile_load<A_KC, FULL>(ra, pr.A, a.lda, m0, M, kb, ke);
-    tile_load<B_KC, FULL>(rb, pr.B, a.ldb, n0, N, kb, ke);
-    tile_store<A_KC, FULL, XA>(ra, As, m0, M, kb, ke, kb, pr.xa.rs, pr.xa.rs_stride, sca, sha);
-    tile_store<B_KC, FULL, XB>(rb, Bs, n0, N, kb, ke, kb, pr.xb.rs, pr.xb.rs_stride, scb, shb);
+    tile_load<A_KC, MODE>(ra, pr.A, a.lda, m0, M, kb, ke);
+    tile_load<B_KC, MODE>(rb, pr.B, a.ldb, n0, N, kb, ke);
+    tile_store<A_KC, MODE, XA>(ra, As, m0, M, kb, ke, kb, pr.xa.rs, pr.xa.rs_stride, sca, sha);
+    tile_store<B_KC, MODE, XB>(rb, Bs, n0, N, kb, ke, kb, pr.xb.rs, pr.xb.rs_stride, scb, shb);
     __syncthreads();
     int st = 0;
     for (int k0 = kb; k0 < ke; k0 += BK) {
         const bool more = k0 + BK < ke;
         if (more) {
-            tile_load<A_KC, FULL>(ra, pr.A, a.lda, m0, M, k0 + BK, ke);
-            tile_load<B_KC, FULL>(rb, pr.B, a.ldb, n0, N, k0 + BK, ke);
+            tile_load<A_KC, MODE>(ra, pr.A, a.lda, m0, M, k0 + BK, ke);
+            tile_load<B_KC, MODE>(rb, pr.B, a.ldb, n0, N, k0 + BK, ke);
         }
         __builtin_amdgcn_sched_barrier(0);
         const float* as = As + st * SA + wm + li;
@@ -128,18 +146,49 @@ __device__ __forceinline__ void gemm_kloop(const GemmArgs& a, const GemmProb& pr
         for (int i = 0; i < BK / 2; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            tile_store<A_KC, FULL, XA>(ra, As + (st ^ 1) * SA, m0, M, k0 + BK, ke, kb, pr.xa.rs, pr.xa.rs_stride, sca, sha);
-            tile_store<B_KC, FULL, XB>(rb, Bs + (st ^ 1) * SB, n0, N, k0 + BK, ke, kb, pr.xb.rs, pr.xb.rs_stride, scb, shb);
+            tile_store<A_KC, MODE, XA>(ra, As + (st ^ 1) * SA, m0, M, k0 + BK, ke, kb, pr.xa.rs, pr.xa.rs_stride, sca, sha);
+            tile_store<B_KC, MODE, XB>(rb, Bs + (st ^ 1) * SB, n0, N, k0 + BK, ke, kb, pr.xb.rs, pr.xb.rs_stride, scb, shb);
         }
         __syncthreads();
         st ^= 1;
     }
 }
 
+__device__ __forceinline__ void pin4(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
+// Short reductions (K chunk <= PRE_T * BK = 128: every node-level GEMM of the hot path and the
+// 128-deep slices of the split-K weight gradients).  The streaming loop above pays one dependent
+// global round trip per K tile (4 x ~1 us at K = 128, nothing else is resident on the CU to hide
+// it); here ALL operand tiles are requested before anything waits -- even before the BatchNorm
+// tables are built -- then staged into PRE_T LDS stages at once and multiplied back to back.
+template <bool A_KC, bool B_KC, int MODE>
+__device__ __forceinline__ void pre_issue(const GemmArgs& a, const GemmProb& pr, int m0, int n0, int kb, int ke, int nt,
+                                          float4 (&ra)[PRE_T][NQ], float4 (&rb)[PRE_T][NQ]) {
+#pragma unroll
+    for (int t = 0; t < PRE_T; ++t)
+        if (t < nt) {
+            tile_load<A_KC, MODE>(ra[t], pr.A, a.lda, m0, a.M, kb + t * BK, ke);
+            tile_load<B_KC, MODE>(rb[t], pr.B, a.ldb, n0, a.N, kb + t * BK, ke);
+        }
+    asm volatile("" ::: "memory");      // the loads stay here (not sunk next to their LDS stores), and nothing waits yet
+}
+template <bool A_KC, bool B_KC, int XA, int XB, int MODE>
+__device__ __forceinline__ void pre_commit(const GemmArgs& a, const GemmProb& pr, float* As, float* Bs, int m0, int n0,
+                                           int kb, int ke, int nt, const float* sca, const float* sha, const float* scb,
+                                           const float* shb, const float4 (&ra)[PRE_T][NQ], const float4 (&rb)[PRE_T][NQ]) {
+    constexpr int SA = BK * (A_KC ? LDT : LDD), SB = BK * (B_KC ? LDT : LDD);
+#pragma unroll
+    for (int t = 0; t < PRE_T; ++t)
+        if (t < nt) {
+            tile_store<A_KC, MODE, XA>(ra[t], As + t * SA, m0, a.M, kb + t * BK, ke, kb, pr.xa.rs, pr.xa.rs_stride, sca, sha);
+            tile_store<B_KC, MODE, XB>(rb[t], Bs + t * SB, n0, a.N, kb + t * BK, ke, kb, pr.xb.rs, pr.xb.rs_stride, scb, shb);
+        }
+}
+
 template <bool A_KC, bool B_KC, int XA, int XB>
 __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) float As[2 * BK * (A_KC ? LDT : LDD)];
-    __shared__ __attribute__((aligned(16))) float Bs[2 * BK * (B_KC ? LDT : LDD)];
+    __shared__ __attribute__((aligned(16))) float As[PRE_T * BK * (A_KC ? LDT : LDD)];
+    __shared__ __attribute__((aligned(16))) float Bs[PRE_T * BK * (B_KC ? LDT : LDD)];
     __shared__ float xsc[2][A_KC || B_KC ? XMAX : BM];
     __shared__ float xsh[2][A_KC || B_KC ? XMAX : BM];
     __shared__ double red[4][2][32];
@@ -154,7 +203,23 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     const int li = lane & 31, lk = lane >> 5;
     // interior tile: no bounds handling, unconditional 16 B loads
-    const bool full = vecA && vecB && m0 + BM <= M && n0 + BN <= N && ((ke - kb) % BK) == 0;
+    const bool kwhole = vecA && vecB && ((ke - kb) % BK) == 0;
+    const bool full = kwhole && m0 + BM <= M && n0 + BN <= N;
+    // ragged in mn only: !KC operands are read 4 columns at a time, so their extent must be a multiple of 4
+    const bool clampable = kwhole && (A_KC || (M % 4 == 0 && M >= 4)) && (B_KC || (N % 4 == 0 && N >= 4));
+    const int mode = full ? 0 : (clampable ? 1 : 2);
+    const int nt = (ke - kb + BK - 1) / BK;
+    const bool pre = nt >= 1 && nt <= PRE_T;
+    GEMM_CLK(0);
+#ifdef CAL_GEMM_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) g_gemm_blk[2 * (blockIdx.x + gridDim.x * blockIdx.y)] = wall_clock64();
+#endif
+    float4 ra[PRE_T][NQ], rb[PRE_T][NQ];
+    if (pre) {
+        if (mode == 0) pre_issue<A_KC, B_KC, 0>(a, pr, m0, n0, kb, ke, nt, ra, rb);
+        else if (mode == 1) pre_issue<A_KC, B_KC, 1>(a, pr, m0, n0, kb, ke, nt, ra, rb);
+        else pre_issue<A_KC, B_KC, 2>(a, pr, m0, n0, kb, ke, nt, ra, rb);
+    }
 
     // BN scale/shift tables of the transformed operands; one block also updates the running stats
     if (XA > 0) {
@@ -176,21 +241,60 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
         if (!B_KC) for (int t = cnt + threadIdx.x; t < BN; t += 256) { xsc[1][t] = 0.f; xsh[1][t] = 0.f; }
     }
     if (XA > 0 || XB > 0) __syncthreads();
+    GEMM_CLK(1);
 
-    f32x16 acc;
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    if (ke > kb) {
-        if (full) gemm_kloop<A_KC, B_KC, XA, XB, true>(a, pr, As, Bs, m0, n0, kb, ke, xsc[0], xsh[0], xsc[1], xsh[1], acc, wm, wn, li, lk);
-        else gemm_kloop<A_KC, B_KC, XA, XB, false>(a, pr, As, Bs, m0, n0, kb, ke, xsc[0], xsh[0], xsc[1], xsh[1], acc, wm, wn, li, lk);
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+    if (pre) {
+        constexpr int LDA = A_KC ? LDT : LDD, LDB = B_KC ? LDT : LDD;
+        if (mode == 0) pre_commit<A_KC, B_KC, XA, XB, 0>(a, pr, As, Bs, m0, n0, kb, ke, nt, xsc[0], xsh[0], xsc[1], xsh[1], ra, rb);
+        else if (mode == 1) pre_commit<A_KC, B_KC, XA, XB, 1>(a, pr, As, Bs, m0, n0, kb, ke, nt, xsc[0], xsh[0], xsc[1], xsh[1], ra, rb);
+        else pre_commit<A_KC, B_KC, XA, XB, 2>(a, pr, As, Bs, m0, n0, kb, ke, nt, xsc[0], xsh[0], xsc[1], xsh[1], ra, rb);
+        GEMM_CLK(2);
+        __syncthreads();
+        GEMM_CLK(3);
+        // operands of tile t+1 are read while tile t multiplies; the sched_barriers keep hipcc from
+        // re-interleaving "2 reads, wait, 2 MFMAs" (which exposes one LDS latency per MFMA pair);
+        // two accumulator chains, since a dependent 32x32x2 MFMA cannot issue back to back
+        float av[2][BK / 2], bv[2][BK / 2];
+        auto read_ops = [&](int t, float (&ao)[BK / 2], float (&bo)[BK / 2]) {
+            const float* as = As + t * BK * LDA + wm + li;
+            const float* bs = Bs + t * BK * LDB + wn + li;
+#pragma unroll
+            for (int i = 0; i < BK / 2; ++i) {
+                ao[i] = as[(2 * i + lk) * LDA];
+                bo[i] = bs[(2 * i + lk) * LDB];
+            }
+        };
+        read_ops(0, av[0], bv[0]);
+#pragma unroll
+        for (int t = 0; t < PRE_T; ++t)
+            if (t < nt) {
+                if (t + 1 < nt) read_ops(t + 1, av[(t + 1) & 1], bv[(t + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < BK / 2; i += 2) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][i], bv[t & 1][i], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][i + 1], bv[t & 1][i + 1], acc2, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+    } else if (ke > kb) {
+        if (mode == 0) gemm_kloop<A_KC, B_KC, XA, XB, 0>(a, pr, As, Bs, m0, n0, kb, ke, xsc[0], xsh[0], xsc[1], xsh[1], acc, wm, wn, li, lk);
+        else if (mode == 1) gemm_kloop<A_KC, B_KC, XA, XB, 1>(a, pr, As, Bs, m0, n0, kb, ke, xsc[0], xsh[0], xsc[1], xsh[1], acc, wm, wn, li, lk);
+        else gemm_kloop<A_KC, B_KC, XA, XB, 2>(a, pr, As, Bs, m0, n0, kb, ke, xsc[0], xsh[0], xsc[1], xsh[1], acc, wm, wn, li, lk);
     }
+    GEMM_CLK(4);
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int col = n0 + wn + li;
     const bool cok = col < N;
     const float bv = (pr.bias && cok) ? pr.bias[col] : 0.f;
     const bool want_st = pr.st_sum != nullptr, want_dot = pr.dot_sum != nullptr;
     float amean = 0.f, arstd = 0.f;
-    float aux[16];
+    float aux[16] = {};
     if (want_dot && cok) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -201,22 +305,38 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
         }
         bn_mean_rstd(pr.aux_bn, col, amean, arstd);
     }
-    double s1 = 0.0, s2 = 0.0;
+    // hipcc re-inserts `s_waitcnt vmcnt(0)` at the head of every guarded block below while a load issued
+    // before them may still be pending on some path; on gfx9 stores count in vmcnt too, so each store then
+    // waits for the previous one's acknowledgement (16 x 125 ns measured).  Consume the loads here, once.
+    asm volatile("" :: "v"(bv), "v"(amean), "v"(arstd));
+    if (want_dot) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (row < M && cok) {
-            float v = acc[r] + bv;
-            if (a.relu) v = fmaxf(v, 0.f);
-            if (C) C[(size_t)row * a.ldc + col] = v;
-            if (want_st) { s1 += (double)v; s2 += (double)v * (double)v; }
-            if (want_dot) {
-                const float xn = (aux[r] - amean) * arstd;
-                s1 += (double)v;
-                s2 += (double)v * (double)xn;
-            }
+        for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(aux[r]));
+    }
+    double s1 = 0.0, s2 = 0.0;
+    GEMM_CLK(6);
+    auto emit = [&](int r, int row) {
+        float v = acc[r] + bv;
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (C) C[(size_t)row * a.ldc + col] = v;
+        if (want_st) { s1 += (double)v; s2 += (double)v * (double)v; }
+        if (want_dot) {
+            const float xn = (aux[r] - amean) * arstd;
+            s1 += (double)v;
+            s2 += (double)v * (double)xn;
+        }
+    };
+    if (m0 + BM <= M && n0 + BN <= N) {        // interior tile: no per-element guards, the 16 stores stream out
+#pragma unroll
+        for (int r = 0; r < 16; ++r) emit(r, m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (row < M && cok) emit(r, row);
         }
     }
+    GEMM_CLK(7);
     if (want_st || want_dot) {
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
@@ -234,6 +354,10 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
             }
         }
     }
+    GEMM_CLK(5);
+#ifdef CAL_GEMM_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) g_gemm_blk[2 * (blockIdx.x + gridDim.x * blockIdx.y) + 1] = wall_clock64();
+#endif
 }
 
 __global__ void k_splitk_reduce(const float* __restrict__ part, float* __restrict__ out, int64_t n, int S,
@@ -310,6 +434,8 @@ int splitk_for(int64_t M, int64_t N, int64_t K, int nbatch) {
 void gemm_set_split(GemmArgs& a, int S) {
     int kchunk = (int)((((int64_t)a.K + S - 1) / S + BK - 1) / BK * BK);
     if (kchunk == 0) kchunk = BK;
+    // a slice just over PRE_T tiles would fall back to the streaming loop: cut it at PRE_T tiles instead
+    if (S > 1 && kchunk > PRE_T * BK && kchunk <= (PRE_T + 2) * BK) kchunk = PRE_T * BK;
     a.kchunk = kchunk;
     a.nsplit = a.K == 0 ? 1 : cdiv(a.K, kchunk);
 }
@@ -317,6 +443,15 @@ void gemm_set_split(GemmArgs& a, int S) {
 }  // namespace cal
 
 using namespace cal;
+
+#ifdef CAL_GEMM_CLOCKS
+CAL_EXPORT int cal_debug_gemm_clocks(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cal::g_gemm_clk), sizeof(long long) * 16);
+}
+CAL_EXPORT int cal_debug_gemm_blocks(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cal::g_gemm_blk), sizeof(long long) * 4096);
+}
+#endif
 
 // experiment hook: same contract as cal_gemm (transA must be 0, no split-K) through the K-split kernel
 CAL_EXPORT int cal_gemm_ks(int transB, const float* A, const float* B, float* C, const float* bias, int relu,

@@ -157,6 +157,8 @@ CAL_API int cal_engine_backward_from(void* engine, const float* x0, const int64_
                                      const float* dlogp, int64_t N, int64_t E, int64_t B, void* stream);
 /* profiling aid: make cal_engine_step return after its k-th launch site (0 = run everything) */
 CAL_API int cal_engine_debug_stop(int k);
+/* name of launch site k (1-based) of the latest untruncated cal_engine_step; "" past the end */
+CAL_API const char* cal_engine_stage_name(int k);
 /* live HIP-event timing of the node-level GEMMs (class 0, work = flops) and aggregations (class 1,
  * work = algorithmic bytes) inside the step, for bench.py's roofline block; `out` is a HOST array */
 CAL_API int cal_engine_profile(int on);

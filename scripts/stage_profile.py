@@ -32,9 +32,15 @@ def timed(stop, reps=30, inner=10):
 nst = int(sys.argv[1]) if len(sys.argv) > 1 else 70
 prev = 0.0
 full = timed(0)
-for k in range(2, nst):
+_lib.lib().cal_engine_debug_stop(0)
+eng.train_step(b, perm, adam=False)                      # eager, untruncated: records the launch-site names
+torch.cuda.synchronize()
+names = [_lib.lib().cal_engine_stage_name(k).decode() for k in range(1, 200)]
+names = [n for n in names if n]
+nst = min(nst, len(names) + 1)
+for k in range(1, nst):
     t = timed(k)
-    print("after launch site %2d: %7.1f us  (+%5.1f)" % (k - 1, t, t - prev))
+    print("after launch site %2d: %7.1f us  (+%5.1f)  %s" % (k, t, t - prev, names[k - 1] if k - 1 < len(names) else ""))
     if abs(t - full) < 1e-9 or (k > 5 and t >= full * 0.999 and t - prev < 0.05): pass
     prev = t
 print("full step (no adam): %.1f us" % full)
