@@ -36,6 +36,50 @@ __global__ void __launch_bounds__(256) k_collate(const float* __restrict__ X, co
     if (threadIdx.x == 0) yo[b] = Y[g];
 }
 
+// Random-intervention permutation (model.py:147-152: `random.shuffle(list(range(num)))`) drawn ON the
+// device inside the captured step, so that a step needs no host RNG, no pinned staging and no H2D
+// copy in front of its hipGraph: graph b gets the key splitmix64(seed, *counter, b) and the
+// permutation is the argsort of the keys (bitonic network in LDS, one workgroup, B <= 4096).
+// *counter is advanced by the kernel itself, so replaying the same graph draws a fresh permutation.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+constexpr int PERM_MAX = 4096;
+__global__ void __launch_bounds__(1024) k_randperm(int64_t* __restrict__ perm, int B, unsigned long long seed,
+                                                    unsigned long long* __restrict__ counter) {
+    __shared__ unsigned long long key[PERM_MAX];
+    __shared__ int idx[PERM_MAX];
+    int n = 1;
+    while (n < B) n <<= 1;
+    const unsigned long long cnt = *counter;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        // padding keys sort to the end; real keys keep 63 random bits
+        key[i] = i < B ? (splitmix64(splitmix64(seed ^ (cnt * 0xD1342543DE82EF95ull)) + (unsigned long long)i) >> 1)
+                       : 0xFFFFFFFFFFFFFFFFull;
+        idx[i] = i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = key[i], b = key[p];
+                    // ties (probability ~B^2 / 2^64) broken by index so the result is always a permutation
+                    const bool gt = a > b || (a == b && idx[i] > idx[p]);
+                    if (gt == up) { key[i] = b; key[p] = a; const int t = idx[i]; idx[i] = idx[p]; idx[p] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < B; i += 1024) perm[i] = idx[i];
+    if (threadIdx.x == 0) *counter = cnt + 1;
+}
+
 }  // namespace cal
 
 using namespace cal;
@@ -49,5 +93,15 @@ CAL_EXPORT int cal_collate(const float* X, const int64_t* EI, int64_t sumE, int6
     hipLaunchKernelGGL(k_collate, dim3((unsigned)B), dim3(256), 0, stream, X, EI, sumE, (int)F, node_ptr, edge_ptr, Y, sel,
                        out_node_off, out_edge_off, xo, eio, Eout, batcho, yo);
     CAL_CHECK_LAUNCH("k_collate");
+    return 0;
+}
+
+// perm[0..B) <- a uniformly random permutation keyed by (seed, *counter); *counter += 1.  B <= 4096.
+CAL_EXPORT int cal_randperm(int64_t* perm, int64_t B, uint64_t seed, uint64_t* counter, void* stream) {
+    if (B == 0) return 0;
+    CAL_REQUIRE(B > 0 && B <= cal::PERM_MAX, "cal_randperm supports 1..4096 graphs per batch");
+    hipLaunchKernelGGL(cal::k_randperm, dim3(1), dim3(1024), 0, (hipStream_t)stream, perm, (int)B,
+                       (unsigned long long)seed, (unsigned long long*)counter);
+    CAL_CHECK_LAUNCH("k_randperm");
     return 0;
 }

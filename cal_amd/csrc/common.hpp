@@ -88,6 +88,8 @@ template <> struct Vec<4> {
         return fmaf(v.w, x.v.w, fmaf(v.z, x.v.z, fmaf(v.y, x.v.y, v.x * x.v.x)));
     }
     __device__ __forceinline__ float get(int i) const { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+    // keep a batch of loads issued together: hipcc may not sink this value's load past the pin
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 };
 template <> struct Vec<1> {
     float v;
@@ -100,6 +102,7 @@ template <> struct Vec<1> {
     __device__ __forceinline__ void relu() { v = fmaxf(v, 0.f); }
     __device__ __forceinline__ float dot(const Vec& x) const { return v * x.v; }
     __device__ __forceinline__ float get(int) const { return v; }
+    __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v)); }
 };
 
 }  // namespace cal

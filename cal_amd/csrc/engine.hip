@@ -39,13 +39,25 @@ __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __re
     const int task = blockIdx.y;
     if (fa.stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         fa.stats[0] = fa.wc * fa.stats[1] + fa.wo * fa.stats[2] + fa.wco * fa.stats[3];
+    // Both task kinds are pure reductions over S slabs / P partial rows: the loops keep 8 loads in flight
+    // per lane (unconditional on a clamped index, pinned, masked when added) -- as dependent loops with
+    // two loads in flight the 58-slab weight-gradient sums made this kernel 11 us.
     if (task < fa.nst) {
         const SlabTask t = fa.st[task];
         for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n; i += gridDim.x * 256) {
             float s0 = 0.f, s1 = 0.f;
-            int z = 0;
-            for (; z + 1 < t.S; z += 2) { s0 += t.slabs[(size_t)z * t.n + i]; s1 += t.slabs[(size_t)(z + 1) * t.n + i]; }
-            if (z < t.S) s0 += t.slabs[(size_t)z * t.n + i];
+            for (int z0 = 0; z0 < t.S; z0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = t.slabs[(size_t)max(min(z0 + u, t.S - 1), 0) * t.n + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    s0 += z0 + u < t.S ? v[u] : 0.f;
+                    s1 += z0 + u + 1 < t.S ? v[u + 1] : 0.f;
+                }
+            }
             t.dst[i] = s0 + s1;
         }
     } else if (task - fa.nst < fa.nct) {
@@ -54,10 +66,17 @@ __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __re
         __shared__ double red[256];
         const int pl = threadIdx.x >> 4, cl = threadIdx.x & 15;
         for (int c0 = blockIdx.x * 16; c0 < t.n; c0 += gridDim.x * 16) {
-            const int c = c0 + cl;
+            const int c = c0 + cl, cc = min(c, t.n - 1);
             double sacc = 0.0;
-            if (c < t.n)
-                for (int q = pl; q < t.P; q += 16) sacc += t.src[(size_t)q * t.stride + c];
+            for (int q0 = pl; q0 < t.P; q0 += 16 * 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = t.src[(size_t)max(min(q0 + 16 * u, t.P - 1), 0) * t.stride + cc];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sacc += q0 + 16 * u < t.P ? v[u] : 0.0;
+            }
             red[threadIdx.x] = sacc;
             __syncthreads();
             if (pl == 0 && c < t.n) {
@@ -987,6 +1006,11 @@ CAL_EXPORT int cal_engine_debug_stop(int k) { g_stop_after = k; return 0; }
 CAL_EXPORT const char* cal_engine_stage_name(int k) {
     return k >= 1 && k <= (int)g_stage_names.size() ? g_stage_names[k - 1] : "";
 }
+#ifdef CAL_BLK_CLOCKS
+CAL_EXPORT int cal_debug_blk_clocks(long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cal::g_blk_clk), sizeof(long long) * 8192);
+}
+#endif
 #ifdef CAL_RO_CLOCKS
 CAL_EXPORT int cal_debug_ro_clocks(long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(cal::g_ro_clk), sizeof(long long) * 64);

@@ -10,6 +10,14 @@
 
 namespace cal {
 
+#ifdef CAL_BLK_CLOCKS                     // profiling aid: start / end timestamp (100 MHz) of every workgroup of one kernel
+__device__ long long g_blk_clk[2 * 4096];
+#define BLK_CLK(which) do { const int b_ = blockIdx.x + gridDim.x * blockIdx.y; \
+                            if (threadIdx.x == 0 && b_ < 4096) g_blk_clk[2 * b_ + (which)] = wall_clock64(); } while (0)
+#else
+#define BLK_CLK(which) do {} while (0)
+#endif
+
 struct CSR {
     const int* ptr;
     const int* nbr;
@@ -154,6 +162,7 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch b0,
     const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
     using V = Vec<VEC>;
     const bool want = br.st_sum.on();
+    BLK_CLK(0);
     for (int c = l * VEC; c - l * VEC < H; c += G * VEC) {
         const bool cok = c < H;
         double s1[VEC], s2[VEC];
@@ -199,6 +208,7 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch b0,
             }
         }
     }
+    BLK_CLK(1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -516,22 +526,39 @@ __global__ void __launch_bounds__(256) k_bn_bwd(const BnBwdProb p0, const BnBwdP
                 m2[j] = (float)(p.dot_prod[c + j] * (double)p.bn.inv_n);
             } else { mean[j] = rstd[j] = gs[j] = m1[j] = m2[j] = 0.f; }
         }
-        if (cok)
-            for (int r = rbeg + grp; r < rend; r += RPB) {
-                V d = V::ld(p.dyh + (size_t)r * W + c), xv = V::ld(p.x + (size_t)r * W + c);
+        // UR rows per pass with all their loads issued first: one row per iteration (load, wait, store --
+        // the store may alias the next row's loads as far as hipcc knows) is one memory round trip per row
+        constexpr int UR = 4;
+        const int cc = min(c, W - VEC);
+        for (int r0 = rbeg + grp; r0 < rend; r0 += RPB * UR) {
+            V d[UR], xv[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const size_t r = (size_t)min(r0 + u * RPB, rend - 1);
+                d[u] = V::ld(p.dyh + r * W + cc); xv[u] = V::ld(p.x + r * W + cc);
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) { d[u].pin(); xv[u].pin(); }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int r = r0 + u * RPB;
                 float o[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const float xn = (xv.get(j) - mean[j]) * rstd[j];
-                    float t = gs[j] * (d.get(j) - m1[j] - xn * m2[j]);
-                    if (relu && !(xv.get(j) > 0.f)) t = 0.f;
+                    const float xn = (xv[u].get(j) - mean[j]) * rstd[j];
+                    float t = gs[j] * (d[u].get(j) - m1[j] - xn * m2[j]);
+                    if (relu && !(xv[u].get(j) > 0.f)) t = 0.f;
                     o[j] = t;
-                    cs[j] += (double)t;
                 }
-                V ov;
-                if constexpr (VEC == 4) ov.v = make_float4(o[0], o[1], o[2], o[3]); else ov.v = o[0];
-                ov.st(p.dy + (size_t)r * W + c);
+                if (r < rend && cok) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) cs[j] += (double)o[j];
+                    V ov;
+                    if constexpr (VEC == 4) ov.v = make_float4(o[0], o[1], o[2], o[3]); else ov.v = o[0];
+                    ov.st(p.dy + (size_t)r * W + c);
+                }
             }
+        }
         if (p.colsum.on()) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
@@ -729,47 +756,80 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
             wn[j] = wp[j] = wq[j] = 0.f;
         }
     }
-    for (int v = rbeg + grp; v < rend; v += RPB) {
-        const float a0 = a.anode[2 * (size_t)v], a1 = a.anode[2 * (size_t)v + 1];
-        float xv[VEC], dxc[VEC], dxo[VEC];
-        float d0 = 0.f, d1 = 0.f;
-        if (cok) {
-            V x4 = V::ld(a.x + (size_t)v * H + c), hc4 = V::ld(a.dxhc + (size_t)v * H + c), ho4 = V::ld(a.dxho + (size_t)v * H + c);
+    // UR rows per pass, each dependent round of loads (row data + CSR extents -> edge ids -> edge
+    // gradients) issued for all of them at once: a row at a time this loop was 8 rows x 4 round trips
+    constexpr int UR = 4;
+    const int cc = min(c, H - VEC);
+    for (int v0 = rbeg + grp; v0 < rend; v0 += RPB * UR) {
+        float a0[UR], a1[UR];
+        V x4[UR], hc4[UR], ho4[UR];
+        int ps0[UR], ps1[UR], pd0[UR], pd1[UR];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const size_t v = (size_t)min(v0 + u * RPB, rend - 1);
+            a0[u] = a.anode[2 * v]; a1[u] = a.anode[2 * v + 1];
+            x4[u] = V::ld(a.x + v * H + cc); hc4[u] = V::ld(a.dxhc + v * H + cc); ho4[u] = V::ld(a.dxho + v * H + cc);
+            ps0[u] = a.gs.ptr[v]; ps1[u] = a.gs.ptr[v + 1]; pd0[u] = a.gd.ptr[v]; pd1[u] = a.gd.ptr[v + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            x4[u].pin(); hc4[u].pin(); ho4[u].pin();
+            asm volatile("" : "+v"(a0[u]), "+v"(a1[u]), "+v"(ps0[u]), "+v"(ps1[u]), "+v"(pd0[u]), "+v"(pd1[u]));
+        }
+        int es[UR], ed[UR];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {          // this lane's first edge of either list (clamped index, masked below)
+            es[u] = a.gs.eid[ps0[u] + l < ps1[u] ? ps0[u] + l : 0];
+            ed[u] = a.gd.eid[pd0[u] + l < pd1[u] ? pd0[u] + l : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) asm volatile("" : "+v"(es[u]), "+v"(ed[u]));
+        float sp[UR], sq[UR];
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const float vs = a.dl[ps0[u] + l < ps1[u] ? es[u] : 0], vd = a.dl[pd0[u] + l < pd1[u] ? ed[u] : 0];
+            sp[u] = ps0[u] + l < ps1[u] ? vs : 0.f;
+            sq[u] = pd0[u] + l < pd1[u] ? vd : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UR; ++u) {
+            const int v = v0 + u * RPB;
+            float xv[VEC], dxc[VEC], dxo[VEC];
+            float d0 = 0.f, d1 = 0.f;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                xv[j] = x4.get(j);
-                const float xcn = (a0 * xv[j] - mc[j]) * rc[j], xon = (a1 * xv[j] - mo[j]) * ro[j];
-                dxc[j] = gc[j] * (hc4.get(j) - m1c[j] - xcn * m2c[j]);
-                dxo[j] = go[j] * (ho4.get(j) - m1o[j] - xon * m2o[j]);
+                xv[j] = cok ? x4[u].get(j) : 0.f;
+                const float xcn = (a0[u] * xv[j] - mc[j]) * rc[j], xon = (a1[u] * xv[j] - mo[j]) * ro[j];
+                dxc[j] = cok ? gc[j] * (hc4[u].get(j) - m1c[j] - xcn * m2c[j]) : 0.f;
+                dxo[j] = cok ? go[j] * (ho4[u].get(j) - m1o[j] - xon * m2o[j]) : 0.f;
                 d0 = fmaf(dxc[j], xv[j], d0);
                 d1 = fmaf(dxo[j], xv[j], d1);
             }
-        } else {
+            d0 = group_sum<G>(d0); d1 = group_sum<G>(d1);
+            const float dl0 = a0[u] * a1[u] * (d0 - d1);
+            float spv = sp[u], sqv = sq[u];
+            for (int s = ps0[u] + l + G; s < ps1[u]; s += G) spv += a.dl[a.gs.eid[s]];      // rare: degree > G
+            for (int s = pd0[u] + l + G; s < pd1[u]; s += G) sqv += a.dl[a.gd.eid[s]];
+            spv = group_sum<G>(spv); sqv = group_sum<G>(sqv);
+            if (v < rend) {
+                if (l == 0) { sdl += (double)dl0; ssp += (double)spv; }
+                if (cok) {
+                    float o[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { xv[j] = dxc[j] = dxo[j] = 0.f; }
-        }
-        d0 = group_sum<G>(d0); d1 = group_sum<G>(d1);
-        const float dl0 = a0 * a1 * (d0 - d1);
-        float sp = 0.f, sq = 0.f;
-        for (int s = a.gs.ptr[v] + l; s < a.gs.ptr[v + 1]; s += G) sp += a.dl[a.gs.eid[s]];
-        for (int s = a.gd.ptr[v] + l; s < a.gd.ptr[v + 1]; s += G) sq += a.dl[a.gd.eid[s]];
-        sp = group_sum<G>(sp); sq = group_sum<G>(sq);
-        if (l == 0) { sdl += (double)dl0; ssp += (double)sp; }
-        if (cok) {
-            float o[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                float dx = a0 * dxc[j] + a1 * dxo[j] + dl0 * wn[j] + sp * wp[j] + sq * wq[j];
-                if (relu && !(xv[j] > 0.f)) dx = 0.f;
-                o[j] = dx;
-                cs_b[j] += (double)dx;
-                cs_n[j] += (double)(dl0 * xv[j]);
-                cs_p[j] += (double)(sp * xv[j]);
-                cs_q[j] += (double)(sq * xv[j]);
+                    for (int j = 0; j < VEC; ++j) {
+                        float dx = a0[u] * dxc[j] + a1[u] * dxo[j] + dl0 * wn[j] + spv * wp[j] + sqv * wq[j];
+                        if (relu && !(xv[j] > 0.f)) dx = 0.f;
+                        o[j] = dx;
+                        cs_b[j] += (double)dx;
+                        cs_n[j] += (double)(dl0 * xv[j]);
+                        cs_p[j] += (double)(spv * xv[j]);
+                        cs_q[j] += (double)(sqv * xv[j]);
+                    }
+                    V ov;
+                    if constexpr (VEC == 4) ov.v = make_float4(o[0], o[1], o[2], o[3]); else ov.v = o[0];
+                    ov.st(a.dZ + (size_t)v * H + c);
+                }
             }
-            V ov;
-            if constexpr (VEC == 4) ov.v = make_float4(o[0], o[1], o[2], o[3]); else ov.v = o[0];
-            ov.st(a.dZ + (size_t)v * H + c);
         }
     }
 #pragma unroll

@@ -26,6 +26,8 @@ from typing import Dict, Optional, Sequence
 import torch
 import torch.distributed as dist
 
+from . import _lib
+from .plan import _p, _stream
 from .train_causal import causal_loss
 
 
@@ -47,7 +49,9 @@ def flatten_parameters(model: torch.nn.Module):
 
 
 class _Captured:
-    __slots__ = ("graph", "perm", "stats")
+    """Captured step(s) of one resident batch: `graphs[True]` draws the intervention permutation on the
+    device inside the graph (cal_randperm), `graphs[False]` reads it from `perm` (uploaded by the host)."""
+    __slots__ = ("graphs", "perm", "stats")
 
 
 class _PinnedRing:
@@ -75,7 +79,7 @@ class _PinnedRing:
 class CausalTrainer:
     def __init__(self, model, args, lr: float = 1e-3, weight_decay: float = 0.0,
                  use_graph: bool = True, world_size: int = 1, rebuild_plan: bool = True,
-                 use_engine: Optional[bool] = None):
+                 use_engine: Optional[bool] = None, device_perm: bool = True):
         from . import engine as eng_mod
         self.model, self.args = model, args
         self.use_graph = use_graph
@@ -103,6 +107,12 @@ class CausalTrainer:
         self.stats = torch.zeros(5, dtype=torch.float32, device=self.flat_p.device)
         self._ring: Optional[_PinnedRing] = None
         self._eager_perm: Optional[torch.Tensor] = None
+        # model.py:147-152 draws the permutation with Python's RNG on the host; by default it is drawn on the
+        # device instead (keyed by a seed taken from Python's RNG here, so random.seed() still controls it):
+        # no host RNG, pinned staging or H2D copy in front of each step's hipGraph.  step(perm=...) overrides.
+        self.device_perm = bool(device_perm)
+        self._perm_seed = random.getrandbits(63)
+        self._perm_counter = torch.zeros(1, dtype=torch.int64, device=self.flat_p.device)
         # with one GPU the optimizer update rides in the same graph as forward/backward
         self.fused_opt = self.engine is not None and world_size == 1
         self.model.train()
@@ -115,13 +125,27 @@ class CausalTrainer:
             for g in self.opt.param_groups:
                 g["lr"] = lr
 
+    def _shuffles(self) -> bool:
+        return bool(self.args.with_random and (getattr(self.model, "with_random", True)
+                                               or not self.model._gate_on_with_random))
+
     def draw_perm(self, num: int) -> torch.Tensor:
         """model.py:147-152 on the host (Python RNG, like the reference)."""
         l = list(range(num))
-        if self.args.with_random and (getattr(self.model, "with_random", True)
-                                      or not self.model._gate_on_with_random):
+        if self._shuffles():
             random.shuffle(l)
         return torch.tensor(l, dtype=torch.long)
+
+    def _device_perm_into(self, dst: torch.Tensor, num: int):
+        """model.py:147-152 on the device: dst[:num] <- fresh random permutation (identity when the model
+        does not shuffle); enqueued on the current stream, capturable."""
+        if self._shuffles():
+            _lib.call("cal_randperm", _p(dst), num, self._perm_seed, _p(self._perm_counter), _stream())
+        else:
+            dst[:num].copy_(torch.arange(num, dtype=torch.long, device=dst.device))
+
+    def _use_device_perm(self, num: int) -> bool:
+        return self.device_perm and num <= 4096
 
     def reserve_for(self, batches: Sequence):
         """Size the engine workspace for the largest of `batches` BEFORE any graph is captured."""
@@ -167,16 +191,19 @@ class CausalTrainer:
             self.engine.exp_avg_sq.copy_(extra[1])
             self.engine.step_count.copy_(extra[2])
 
-    def _capture(self, batch) -> _Captured:
-        cap = _Captured()
+    def _capture(self, batch, dev_perm: bool, cap: Optional[_Captured] = None) -> _Captured:
         nb = batch.num_graphs
-        cap.perm = torch.arange(nb, dtype=torch.long, device=self.flat_p.device)
-        cap.stats = torch.zeros(5, dtype=torch.float32, device=self.flat_p.device)
+        if cap is None:
+            cap = _Captured()
+            cap.graphs = {}
+            cap.perm = torch.arange(nb, dtype=torch.long, device=self.flat_p.device)
+            cap.stats = torch.zeros(5, dtype=torch.float32, device=self.flat_p.device)
+        draws = dev_perm and self._shuffles()
         if self.engine is not None:
             x = batch.x if getattr(batch, "x", None) is not None else batch.feat
             cn, ce, cb = self.engine._cap
             if x.size(0) > cn or batch.edge_index.size(1) > ce or nb > cb:
-                if self._graphs:
+                if any(c.graphs for c in self._graphs.values()):
                     raise RuntimeError("engine workspace would be re-allocated under captured graphs: "
                                        "call reserve_for(all batches) before the first prepare()")
                 self.engine.reserve(x.size(0), batch.edge_index.size(1), nb)
@@ -186,13 +213,18 @@ class CausalTrainer:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
+                if draws:
+                    self._device_perm_into(cap.perm, nb)
                 self._fwd_bwd(batch, cap.perm, cap.stats)
         torch.cuda.current_stream().wait_stream(s)
         self._restore(snap)
-        cap.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(cap.graph, pool=self._pool):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._pool):
+            if draws:
+                self._device_perm_into(cap.perm, nb)
             self._fwd_bwd(batch, cap.perm, cap.stats)
         self._restore(snap)
+        cap.graphs[dev_perm] = g
         return cap
 
     def _reset_opt_state(self):
@@ -247,10 +279,16 @@ class CausalTrainer:
     def prepare(self, batch):
         """Capture the graphs for a resident batch ahead of the timed region."""
         if self.use_graph:
-            if id(batch) not in self._graphs:
-                self._graphs[id(batch)] = self._capture(batch)
+            self._captured(batch, self._use_device_perm(batch.num_graphs))
             if self._opt_graph is None and not self.fused_opt:
                 self._build_opt_graph()
+
+    def _captured(self, batch, dev_perm: bool) -> _Captured:
+        cap = self._graphs.get(id(batch))
+        if cap is None or dev_perm not in cap.graphs:
+            cap = self._capture(batch, dev_perm, cap)
+            self._graphs[id(batch)] = cap
+        return cap
 
     def _upload_perm(self, perm: torch.Tensor, dst: torch.Tensor):
         if perm.is_cuda:
@@ -263,24 +301,29 @@ class CausalTrainer:
     def step(self, batch, perm: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One train step on a device-resident batch; returns the device stats
         tensor [loss, c_loss, o_loss, co_loss, correct_o] (no host sync)."""
-        if perm is None:
-            perm = self.draw_perm(batch.num_graphs)
+        nb = batch.num_graphs
+        dev = perm is None and self._use_device_perm(nb)
+        if perm is None and not dev:
+            perm = self.draw_perm(nb)
         if self.use_graph:
-            cap = self._graphs.get(id(batch))
-            if cap is None:
+            if id(batch) not in self._graphs:
                 self.prepare(batch)
-                cap = self._graphs[id(batch)]
-            self._upload_perm(perm, cap.perm)
-            cap.graph.replay()
+            cap = self._captured(batch, dev)
+            if not dev:
+                self._upload_perm(perm, cap.perm)
+            cap.graphs[dev].replay()
             stats = cap.stats
         else:
-            if perm.is_cuda:
+            if not dev and perm.is_cuda:
                 dperm = perm
             else:
-                if self._eager_perm is None or self._eager_perm.numel() < perm.numel():
-                    self._eager_perm = torch.empty(perm.numel(), dtype=torch.long, device=self.flat_p.device)
-                dperm = self._eager_perm[:perm.numel()]
-                self._upload_perm(perm, dperm)
+                if self._eager_perm is None or self._eager_perm.numel() < nb:
+                    self._eager_perm = torch.empty(max(nb, 1), dtype=torch.long, device=self.flat_p.device)
+                dperm = self._eager_perm[:nb]
+                if dev:
+                    self._device_perm_into(dperm, nb)
+                else:
+                    self._upload_perm(perm, dperm)
             self._fwd_bwd(batch, dperm, self.stats)
             stats = self.stats
         self._allreduce()

@@ -129,6 +129,11 @@ CAL_API int cal_collate(const float* X, const int64_t* EI, int64_t sumE, int64_t
                         float* xo, int64_t* eio, int64_t Eout, int64_t* batcho, int64_t* yo, int64_t B,
                         void* stream);
 
+/* ---- random-intervention permutation (model.py:147-152, `random.shuffle(range(num))`) drawn on the
+ * device: perm[0..B) <- uniformly random permutation keyed by (seed, *counter); the kernel advances
+ * *counter (a device uint64), so a replayed hipGraph draws a fresh permutation every step.  B <= 4096 */
+CAL_API int cal_randperm(int64_t* perm, int64_t B, uint64_t seed, uint64_t* counter, void* stream);
+
 /* ---- native CausalGCN step engine ------------------------------------------------
  * The whole train step of train_causal.py:173-192 on model.py:85-164 (forward, 3-term loss,
  * backward, Adam) as one call enqueuing ~55 fused kernels; see cal_amd/csrc/engine.hip for the

@@ -290,3 +290,69 @@ def test_module_surface_reference_loop_on_engine():
         for r, t in zip(ref_ev, ev):
             assert (r.detach() - t.cpu()).abs().max().item() < 5e-3
     assert int(m.bn_feat.num_batches_tracked.item()) == 3
+
+
+def test_device_randperm_is_a_fresh_uniform_permutation():
+    """cal_randperm (model.py:147-152 on the device): always a permutation, a new one per call, reproducible
+    from (seed, counter), and unbiased enough that every position sees every value."""
+    from cal_amd import _lib
+    from cal_amd.plan import _p, _stream
+    for B in (1, 2, 7, 128, 1000, 4096):
+        cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+        out = torch.empty(B, dtype=torch.long, device=DEV)
+        seen = []
+        for k in range(4):
+            _lib.call("cal_randperm", _p(out), B, 1234, _p(cnt), _stream())
+            p = out.cpu()
+            assert torch.equal(p.sort().values, torch.arange(B)), B
+            seen.append(p.clone())
+        assert int(cnt.item()) == 4
+        if B >= 7:
+            assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+        cnt.fill_(1)                                        # same (seed, counter) -> same permutation
+        _lib.call("cal_randperm", _p(out), B, 1234, _p(cnt), _stream())
+        assert torch.equal(out.cpu(), seen[1])
+    B, trials = 8, 4000
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    outs = torch.empty(trials, B, dtype=torch.long, device=DEV)
+    for k in range(trials):
+        _lib.call("cal_randperm", _p(outs[k]), B, 99, _p(cnt), _stream())
+    counts = torch.zeros(B, B)
+    o = outs.cpu()
+    for pos in range(B):
+        counts[pos] = torch.bincount(o[:, pos], minlength=B).float()
+    assert (counts - trials / B).abs().max() < 6 * (trials / B) ** 0.5      # ~6 sigma of a binomial cell
+
+
+def test_trainer_device_perm_graph_trains_and_redraws():
+    """Default trainer path: the permutation is drawn inside the captured graph (no host upload); an explicit
+    host permutation still works on the same trainer and matches the eager engine bit for bit."""
+    from cal_amd import model as M
+    from cal_amd.trainer import CausalTrainer
+    _, b1 = _config2_batch(32, seed=1)
+    torch.manual_seed(4)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=32, layers=2)
+    m = M.CausalGCN(10, 4, _args(layers=2, hidden=32))
+    m.load_state_dict(sd)
+    tr = CausalTrainer(m.to(DEV), _args(layers=2, hidden=32), lr=1e-2, use_graph=True)
+    tr.reserve_for([b1])
+    losses, perms = [], []
+    for i in range(8):
+        losses.append(tr.step(b1)[0].item())
+        perms.append(tr._graphs[id(b1)].perm.cpu().clone())
+        assert torch.equal(perms[-1].sort().values, torch.arange(32))
+    assert len({tuple(p.tolist()) for p in perms}) == 8          # a fresh draw on every replay
+    assert losses[-1] < losses[0]
+    # explicit permutation on the same trainer -> second captured variant; equals an eager trainer from the same state
+    snap = {k: v.clone() for k, v in m.state_dict().items()}
+    ea, eq, st = tr.engine.exp_avg.clone(), tr.engine.exp_avg_sq.clone(), tr.engine.step_count.clone()
+    perm = torch.arange(32).roll(3)
+    l_graph = tr.step(b1, perm)[0].item()
+    p_graph = tr.flat_p.clone()
+    m2 = M.CausalGCN(10, 4, _args(layers=2, hidden=32))
+    m2.load_state_dict(snap)
+    tr2 = CausalTrainer(m2.to(DEV), _args(layers=2, hidden=32), lr=1e-2, use_graph=False)
+    tr2.engine.exp_avg.copy_(ea); tr2.engine.exp_avg_sq.copy_(eq); tr2.engine.step_count.copy_(st)
+    l_eager = tr2.step(b1, perm)[0].item()
+    assert abs(l_graph - l_eager) < 1e-6
+    assert torch.allclose(p_graph, tr2.flat_p, atol=1e-6)
