@@ -130,8 +130,11 @@ static size_t al(size_t n) { return (n + 63) / 64 * 64; }   // 256 B granules (i
 
 using namespace cal;
 
-extern "C" int cal_plan_build(const int64_t*, int64_t, int64_t, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*,
-                              int32_t*, int32_t*, int32_t*, int32_t*, void*);
+namespace cal {
+int plan_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
+               int32_t* rowptr_src, int32_t* nbr_src, int32_t* eid_src, int32_t* row32, int32_t* col32, int32_t* work,
+               int32_t* status, bool prezeroed, hipStream_t stream);
+}
 
 // cfg: [F, H, C, L].  Returns an opaque handle (0 on failure).
 CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
@@ -406,6 +409,7 @@ int with_g(int H, F f) {
 
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+#define RC0(x) do { int rc0_ = (x); if (rc0_) return rc0_; } while (0)
 // weight-gradient GEMM (TN) with split-K slabs when the reduction axis is long
 int grad_gemm(Ctx& c, GemmArgs& a, int nbatch, float** dst, FinishArgs& fa, size_t& slab_off) {
     int S = splitk_for(a.M, a.N, a.K, nbatch);
@@ -440,6 +444,29 @@ int grad_gemm(Ctx& c, GemmArgs& a, int nbatch, float** dst, FinishArgs& fa, size
 void join_side(Ctx& c) {
     for (int i = 0; i < c.nfork; ++i) hipStreamWaitEvent(c.st, c.e->ev_join[i], 0);
     c.nfork = 0;
+}
+
+// dX (NT, `ax`) and dW (TN, `aw`, split-K slabs like grad_gemm) of one layer in a single launch when both
+// go to the tiled kernel; otherwise the two launches of before.
+int dual_gemm(Ctx& c, GemmArgs& ax, int nbx, GemmArgs& aw, int nbw, float** dst, FinishArgs& fa, size_t& slab_off) {
+    if (use_ks(ax.M)) {
+        RC0(grad_gemm(c, aw, nbw, dst, fa, slab_off));
+        return fwd_gemm(c, true, ax, nbx);
+    }
+    int S = splitk_for(aw.M, aw.N, aw.K, nbw);
+    gemm_set_split(aw, S);
+    if (aw.nsplit > 1) {
+        for (int b = 0; b < nbw; ++b) {
+            size_t need = (size_t)aw.nsplit * aw.M * aw.N;
+            if (slab_off + need > c.e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
+            aw.p[b].C = c.e->slabs + slab_off;
+            fa.st[fa.nst++] = SlabTask{c.e->slabs + slab_off, dst[b], aw.M * aw.N, aw.nsplit};
+            slab_off += need;
+        }
+    } else {
+        for (int b = 0; b < nbw; ++b) aw.p[b].C = dst[b];
+    }
+    return launch_gemm_dual(ax, nbx, aw, nbw, c.st);
 }
 
 bool use_ro(const Ctx& c) {
@@ -505,12 +532,16 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     const int64_t E = c.E;
     hipStream_t st = c.st;
     const size_t NH = (size_t)N * H;
-    // 0. zero the fp64 arena (a kernel, not a memset node)
-    hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(e->arena_n, 256)), dim3(256), 0, st, e->arena, (int64_t)e->arena_n);
-    CAL_CHECK_LAUNCH("k_zero_f64"); STAGE();
+    // 0. zero the fp64 arena and the GraphPlan counters (one kernel, not memset nodes)
+    {
+        const int64_t ni = 4 * ((int64_t)N + 1);
+        hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256)), dim3(256), 0, st, e->arena,
+                           (int64_t)e->arena_n, e->work, ni, e->status);
+        CAL_CHECK_LAUNCH("k_zero_f64"); STAGE();
+    }
     // 1. GraphPlan
-    RC(cal_plan_build(edge_index, E, N, e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
-                      e->row32, e->col32, e->work, e->status, st)); STAGE();
+    RC(plan_build(edge_index, E, N, e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
+                  e->row32, e->col32, e->work, e->status, true, st)); STAGE();
     hipLaunchKernelGGL(k_gptr_dis, dim3(cdiv(N + 1, 256)), dim3(256), 0, st, batch, N, B, e->gptr, e->rowptr_src, e->loop_w,
                        e->dis_unit, e->status);
     CAL_CHECK_LAUNCH("k_gptr_dis"); STAGE();
@@ -799,18 +830,16 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[k].xa.has_bn = 1; a.p[k].xa.bn = bnref(c, L + 1 + k, N, 0);
             dst[k] = e->G + (k ? e->o_ow : e->o_cw);
         }
-        RC(grad_gemm(c, a, 2, dst, fa, slab_off)); STAGE();
-    }
-    // P7. d(BN_k out) = dz_k @ W_k^T with the BN_k-backward sums
-    {
-        GemmArgs a = gemm_args(N, H, H, false, true, 0);
+    // P7. d(BN_k out) = dz_k @ W_k^T with the BN_k-backward sums (same launch as P6)
+        GemmArgs aw = a;
+        a = gemm_args(N, H, H, false, true, 0);
         for (int k = 0; k < 2; ++k) {
             a.p[k].A = e->dzco + (size_t)k * NH; a.p[k].B = e->P + (k ? e->o_ow : e->o_cw); a.p[k].C = e->dXhco + (size_t)k * NH;
             a.p[k].aux = x; a.p[k].aux_rs = e->anode + k; a.p[k].aux_rs_stride = 2; a.p[k].has_aux = 1;
             a.p[k].aux_bn = bnref(c, L + 1 + k, N, 0);
             gemm_stats(c, a.p[k], N, H, bn_dsum(c, L + 1 + k), bn_dprod(c, L + 1 + k), true);
         }
-        RC(fwd_gemm(c, true, a, 2)); STAGE();
+        RC(dual_gemm(c, a, 2, aw, 2, dst, fa, slab_off)); STAGE();
         RC(flush_finals(c)); STAGE();
     }
     // P8. everything between the last backbone conv and the two causal convs
@@ -847,14 +876,12 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[0].A = hin; a.p[0].B = dzi;
             a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 0);
             float* dst[1] = {e->G + e->o_conv_w[i - 1]};
-            RC(grad_gemm(c, a, 1, dst, fa, slab_off)); STAGE();
-        }
-        {
-            GemmArgs a = gemm_args(N, H, H, false, true, 0);
+            GemmArgs aw = a;
+            a = gemm_args(N, H, H, false, true, 0);
             a.p[0].A = dzi; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->dXh;
             a.p[0].aux = hin; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, i, N, 0);
             gemm_stats(c, a.p[0], N, H, bn_dsum(c, i), bn_dprod(c, i), true);
-            RC(fwd_gemm(c, true, a, 1)); STAGE();
+            RC(dual_gemm(c, a, 1, aw, 1, dst, fa, slab_off)); STAGE();
             RC(flush_finals(c)); STAGE();
         }
         {
@@ -874,10 +901,8 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         a.p[0].A = x0; a.p[0].B = e->dZ;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 0);
         float* dst[1] = {e->G + e->o_feat_w};
-        RC(grad_gemm(c, a, 1, dst, fa, slab_off)); STAGE();
-    }
-    {
-        GemmArgs a = gemm_args(N, F, H, false, true, 0);
+        GemmArgs aw = a;
+        a = gemm_args(N, F, H, false, true, 0);
         a.p[0].A = e->dZ; a.p[0].B = e->P + e->o_feat_w; a.p[0].C = nullptr;
         a.p[0].aux = x0; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, 0, N, 0);
         a.p[0].dot_sum = bn_dsum(c, 0); a.p[0].dot_prod = bn_dprod(c, 0);
@@ -888,7 +913,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                 a.p[0].parts = d_bn0.p;
             }
         }
-        RC(fwd_gemm(c, true, a, 1)); STAGE();
+        RC(dual_gemm(c, a, 1, aw, 1, dst, fa, slab_off)); STAGE();
     }
     // commits: fp64 arena -> fp32 gradients
     for (int k = 0; k < e->nbn; ++k) {

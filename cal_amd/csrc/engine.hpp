@@ -112,6 +112,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStream_t stream);
+int launch_gemm_dual(const GemmArgs& ax, int nbx, const GemmArgs& aw, int nbw, hipStream_t stream);
 int splitk_for(int64_t M, int64_t N, int64_t K, int nbatch);
 void gemm_set_split(GemmArgs& a, int S);
 int gemm_row_tiles(int M);

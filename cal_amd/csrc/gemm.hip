@@ -185,18 +185,34 @@ __device__ __forceinline__ void pre_commit(const GemmArgs& a, const GemmProb& pr
         }
 }
 
-template <bool A_KC, bool B_KC, int XA, int XB>
-__global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) float As[PRE_T * BK * (A_KC ? LDT : LDD)];
-    __shared__ __attribute__((aligned(16))) float Bs[PRE_T * BK * (B_KC ? LDT : LDD)];
-    __shared__ float xsc[2][A_KC || B_KC ? XMAX : BM];
-    __shared__ float xsh[2][A_KC || B_KC ? XMAX : BM];
-    __shared__ double red[4][2][32];
+// LDS of one workgroup, carved from a raw buffer so that two differently-shaped bodies can share a kernel
+// (k_gemm_dual): operand stages, BN tables, epilogue reduction scratch.
+template <bool A_KC, bool B_KC>
+struct GemmSmem {
+    static constexpr int XW = A_KC || B_KC ? XMAX : BM;
+    static constexpr int A = 0;
+    static constexpr int B = A + PRE_T * BK * (A_KC ? LDT : LDD);
+    static constexpr int SC = B + PRE_T * BK * (B_KC ? LDT : LDD);
+    static constexpr int SH = SC + 2 * XW;
+    static constexpr int RED = (SH + 2 * XW + 1) / 2 * 2;          // doubles: 8-byte aligned
+    static constexpr int FLOATS = RED + 2 * 4 * 2 * 32;
+};
 
-    const int batch = blockIdx.z / a.nsplit, split = blockIdx.z % a.nsplit;
+// one 64x64 output tile; (bx, by, bz) = tile row, tile column, batch * nsplit + split; nbx = row tiles
+template <bool A_KC, bool B_KC, int XA, int XB>
+__device__ __forceinline__ void gemm_block(const GemmArgs& a, int vecA, int vecB, int bx, int by, int bz, int nbx,
+                                           float* __restrict__ smem) {
+    using SM = GemmSmem<A_KC, B_KC>;
+    float* As = smem + SM::A;
+    float* Bs = smem + SM::B;
+    float (*xsc)[SM::XW] = reinterpret_cast<float (*)[SM::XW]>(smem + SM::SC);
+    float (*xsh)[SM::XW] = reinterpret_cast<float (*)[SM::XW]>(smem + SM::SH);
+    double (*red)[2][32] = reinterpret_cast<double (*)[2][32]>(smem + SM::RED);
+
+    const int batch = bz / a.nsplit, split = bz % a.nsplit;
     const GemmProb& pr = a.p[batch];
     const int M = a.M, N = a.N, K = a.K;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     const int kb = split * a.kchunk, ke = min(K, kb + a.kchunk);
     float* C = pr.C ? pr.C + (size_t)split * M * a.ldc : nullptr;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -212,7 +228,7 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
     const bool pre = nt >= 1 && nt <= PRE_T;
     GEMM_CLK(0);
 #ifdef CAL_GEMM_CLOCKS
-    if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) g_gemm_blk[2 * (blockIdx.x + gridDim.x * blockIdx.y)] = wall_clock64();
+    if (threadIdx.x == 0 && bz == 0 && bx + nbx * by < 2048) g_gemm_blk[2 * (bx + nbx * by)] = wall_clock64();
 #endif
     float4 ra[PRE_T][NQ], rb[PRE_T][NQ];
     if (pre) {
@@ -227,7 +243,7 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
         const int c0 = A_KC ? kb : m0;
         for (int t = threadIdx.x; t < cnt; t += 256) {
             bn_scale_shift(pr.xa.bn, c0 + t, xsc[0][t], xsh[0][t]);
-            if (pr.xa.bn.update && blockIdx.y == 0 && split == 0 && (A_KC ? blockIdx.x == 0 : true)) bn_update_running(pr.xa.bn, c0 + t);
+            if (pr.xa.bn.update && by == 0 && split == 0 && (A_KC ? bx == 0 : true)) bn_update_running(pr.xa.bn, c0 + t);
         }
         if (!A_KC) for (int t = cnt + threadIdx.x; t < BM; t += 256) { xsc[0][t] = 0.f; xsh[0][t] = 0.f; }
     }
@@ -236,7 +252,7 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
         const int c0 = B_KC ? kb : n0;
         for (int t = threadIdx.x; t < cnt; t += 256) {
             bn_scale_shift(pr.xb.bn, c0 + t, xsc[1][t], xsh[1][t]);
-            if (pr.xb.bn.update && blockIdx.x == 0 && split == 0 && (B_KC ? blockIdx.y == 0 : true)) bn_update_running(pr.xb.bn, c0 + t);
+            if (pr.xb.bn.update && bx == 0 && split == 0 && (B_KC ? by == 0 : true)) bn_update_running(pr.xb.bn, c0 + t);
         }
         if (!B_KC) for (int t = cnt + threadIdx.x; t < BN; t += 256) { xsc[1][t] = 0.f; xsh[1][t] = 0.f; }
     }
@@ -346,8 +362,8 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
             const double t1 = red[wave][0][li] + red[wave + 2][0][li];
             const double t2 = red[wave][1][li] + red[wave + 2][1][li];
             if (pr.parts) {                     // one partial row per row tile: [gridDim.x][2][N]
-                pr.parts[((size_t)blockIdx.x * 2 + 0) * N + col] = t1;
-                pr.parts[((size_t)blockIdx.x * 2 + 1) * N + col] = t2;
+                pr.parts[((size_t)bx * 2 + 0) * N + col] = t1;
+                pr.parts[((size_t)bx * 2 + 1) * N + col] = t2;
             } else {
                 atomicAdd((want_st ? pr.st_sum : pr.dot_sum) + col, t1);
                 atomicAdd((want_st ? pr.st_sq : pr.dot_prod) + col, t2);
@@ -356,8 +372,33 @@ __global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int ve
     }
     GEMM_CLK(5);
 #ifdef CAL_GEMM_CLOCKS
-    if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.x + gridDim.x * blockIdx.y < 2048) g_gemm_blk[2 * (blockIdx.x + gridDim.x * blockIdx.y) + 1] = wall_clock64();
+    if (threadIdx.x == 0 && bz == 0 && bx + nbx * by < 2048) g_gemm_blk[2 * (bx + nbx * by) + 1] = wall_clock64();
 #endif
+}
+
+template <bool A_KC, bool B_KC, int XA, int XB>
+__global__ void __launch_bounds__(256) k_gemm(const GemmArgs a, int vecA, int vecB) {
+    __shared__ __attribute__((aligned(16))) float smem[GemmSmem<A_KC, B_KC>::FLOATS];
+    gemm_block<A_KC, B_KC, XA, XB>(a, vecA, vecB, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, smem);
+}
+
+// Two independent GEMM launches in one grid (1-D block index): blocks [0, n1) run problem set 1 (template
+// parameters *1), the rest problem set 2.  Used for the dX / dW pair of every layer's backward: both read
+// the same dZ, neither depends on the other, and alone each leaves half of the chip idle (230 tiles on 256
+// CUs at one ~7 us workgroup each) -- run back to back they cost two kernel latencies, together about one.
+struct DualGrid { int gx1, gy1, n1; int gx2, gy2; };
+template <bool A1, bool B1, int XA1, int XB1, bool A2, bool B2, int XA2, int XB2>
+__global__ void __launch_bounds__(256) k_gemm_dual(const GemmArgs a1, int vecA1, int vecB1, const GemmArgs a2, int vecA2,
+                                                   int vecB2, const DualGrid g) {
+    constexpr int F1 = GemmSmem<A1, B1>::FLOATS, F2 = GemmSmem<A2, B2>::FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[F1 > F2 ? F1 : F2];
+    int b = blockIdx.x;
+    if (b < g.n1) {
+        gemm_block<A1, B1, XA1, XB1>(a1, vecA1, vecB1, b % g.gx1, (b / g.gx1) % g.gy1, b / (g.gx1 * g.gy1), g.gx1, smem);
+    } else {
+        b -= g.n1;
+        gemm_block<A2, B2, XA2, XB2>(a2, vecA2, vecB2, b % g.gx2, (b / g.gx2) % g.gy2, b / (g.gx2 * g.gy2), g.gx2, smem);
+    }
 }
 
 __global__ void k_splitk_reduce(const float* __restrict__ part, float* __restrict__ out, int64_t n, int S,
@@ -378,11 +419,12 @@ static void launch_one(const GemmArgs& a, dim3 grid, int vecA, int vecB, hipStre
     hipLaunchKernelGGL((k_gemm<A_KC, B_KC, XA, XB>), grid, dim3(256), 0, stream, a, vecA, vecB);
 }
 
-int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStream_t stream) {
-    if (a.M == 0 || a.N == 0 || nbatch == 0) return 0;
-    int vecA = (a.lda % 4 == 0), vecB = (a.ldb % 4 == 0);
-    const bool a_kc = !transA, b_kc = transB;
-    int xa = -1, xb = -1;
+int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStream_t stream);
+
+// alignment flags and operand-transform classes of a batch (0 = plain, 1 = BN, 2 = row scale + BN)
+static int gemm_classify(bool a_kc, bool b_kc, const GemmArgs& a, int nbatch, int& vecA, int& vecB, int& xa, int& xb) {
+    vecA = (a.lda % 4 == 0); vecB = (a.ldb % 4 == 0);
+    xa = -1; xb = -1;
     for (int b = 0; b < nbatch; ++b) {
         vecA = vecA && aligned16(a.p[b].A);
         vecB = vecB && aligned16(a.p[b].B);
@@ -394,6 +436,35 @@ int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStre
             if (a.kchunk > XMAX) { set_error("launch_gemm: BN-transformed operand wider than %d", XMAX); return 2; }
         }
     }
+    return 0;
+}
+
+// dX = dZ W^T (NT, set `ax`, first in block order: it is on the critical path) together with
+// dW = op(X)^T dZ (TN with the BN / row-scale transform on X, set `aw`, usually split-K) in ONE launch.
+int launch_gemm_dual(const GemmArgs& ax, int nbx, const GemmArgs& aw, int nbw, hipStream_t stream) {
+    if (ax.M == 0 || ax.N == 0 || nbx == 0) return launch_gemm(true, false, aw, nbw, stream);
+    if (aw.M == 0 || aw.N == 0 || nbw == 0) return launch_gemm(false, true, ax, nbx, stream);
+    int vax, vbx, xax, xbx, vaw, vbw, xaw, xbw;
+    if (int rc = gemm_classify(true, true, ax, nbx, vax, vbx, xax, xbx)) return rc;
+    if (int rc = gemm_classify(false, false, aw, nbw, vaw, vbw, xaw, xbw)) return rc;
+    if (xax != 0 || xbx != 0 || xbw != 0) { set_error("launch_gemm_dual: operand-transform combination not instantiated"); return 2; }
+    DualGrid g;
+    g.gx1 = cdiv(ax.M, BM); g.gy1 = cdiv(ax.N, BN); g.n1 = g.gx1 * g.gy1 * nbx * ax.nsplit;
+    g.gx2 = cdiv(aw.M, BM); g.gy2 = cdiv(aw.N, BN);
+    const int n2 = g.gx2 * g.gy2 * nbw * aw.nsplit;
+    const dim3 grid(g.n1 + n2);
+    if (xaw == 0) hipLaunchKernelGGL((k_gemm_dual<true, true, 0, 0, false, false, 0, 0>), grid, dim3(256), 0, stream, ax, vax, vbx, aw, vaw, vbw, g);
+    else if (xaw == 1) hipLaunchKernelGGL((k_gemm_dual<true, true, 0, 0, false, false, 1, 0>), grid, dim3(256), 0, stream, ax, vax, vbx, aw, vaw, vbw, g);
+    else hipLaunchKernelGGL((k_gemm_dual<true, true, 0, 0, false, false, 2, 0>), grid, dim3(256), 0, stream, ax, vax, vbx, aw, vaw, vbw, g);
+    CAL_CHECK_LAUNCH("k_gemm_dual");
+    return 0;
+}
+
+int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStream_t stream) {
+    if (a.M == 0 || a.N == 0 || nbatch == 0) return 0;
+    int vecA, vecB, xa, xb;
+    const bool a_kc = !transA, b_kc = transB;
+    if (int rc = gemm_classify(a_kc, b_kc, a, nbatch, vecA, vecB, xa, xb)) return rc;
     dim3 grid(cdiv(a.M, BM), cdiv(a.N, BN), nbatch * a.nsplit);
     bool ok = true;
     if (a_kc && !b_kc) {          // NN

@@ -150,12 +150,12 @@ CAL_EXPORT int cal_version() { return 100; }
 // Build both CSR views.  `work` must hold 4*(N+1) + 4*E ints; `status` one int (bit0: edge index out of
 // range, bit1: batch vector not sorted / out of range) -- zeroed here, read by the caller when it
 // chooses to validate.
-CAL_EXPORT int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
-                              int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
-                              int32_t* rowptr_src, int32_t* nbr_src, int32_t* eid_src,
-                              int32_t* row32, int32_t* col32, int32_t* work, int32_t* status,
-                              void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+namespace cal {
+// prezeroed: the caller has already zeroed work[0 .. 4(N+1)) and *status on this stream (the step engine
+// does it in its own arena-zeroing launch: one kernel boundary less per step)
+int plan_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
+               int32_t* rowptr_src, int32_t* nbr_src, int32_t* eid_src, int32_t* row32, int32_t* col32, int32_t* work,
+               int32_t* status, bool prezeroed, hipStream_t stream) {
     CAL_REQUIRE(N >= 0 && E >= 0 && N < (1ll << 31) && E < (1ll << 31), "N/E out of int32 range");
     int n = (int)N;
     int* cnt_dst = work;
@@ -168,9 +168,11 @@ CAL_EXPORT int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
     int* te_s = tn_s + E;
     // a kernel, not hipMemsetAsync: memset nodes inside several captured hipGraphs faulted on replay
     // (ROCm 7.2), and one launch is cheaper than two memset nodes anyway
-    hipLaunchKernelGGL(k_zero_i32, dim3(cdiv(4 * (int64_t)(n + 1), 256)), dim3(256), 0, stream, work,
-                       4 * (int64_t)(n + 1), status);
-    CAL_CHECK_LAUNCH("k_zero_i32");
+    if (!prezeroed) {
+        hipLaunchKernelGGL(k_zero_i32, dim3(cdiv(4 * (int64_t)(n + 1), 256)), dim3(256), 0, stream, work,
+                           4 * (int64_t)(n + 1), status);
+        CAL_CHECK_LAUNCH("k_zero_i32");
+    }
     if (E > 0) {
         hipLaunchKernelGGL(k_plan_count, dim3(cdiv(E, 256)), dim3(256), 0, stream, edge_index, E, n,
                            cnt_dst, cnt_src, row32, col32, status);
@@ -188,6 +190,16 @@ CAL_EXPORT int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
         CAL_CHECK_LAUNCH("k_plan_rank");
     }
     return 0;
+}
+}  // namespace cal
+
+CAL_EXPORT int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
+                              int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
+                              int32_t* rowptr_src, int32_t* nbr_src, int32_t* eid_src,
+                              int32_t* row32, int32_t* col32, int32_t* work, int32_t* status,
+                              void* stream_) {
+    return cal::plan_build(edge_index, E, N, rowptr_dst, nbr_dst, eid_dst, rowptr_src, nbr_src, eid_src, row32, col32, work,
+                           status, false, (hipStream_t)stream_);
 }
 
 CAL_EXPORT int cal_graph_ptr(const int64_t* batch, int64_t N, int64_t B, int32_t* gptr, int32_t* status,
