@@ -34,11 +34,13 @@ struct FinishArgs {
     int nst, nct;
     float* stats;            // fused readout: stats[0] = wc*stats[1] + wo*stats[2] + wco*stats[3]
     float wc, wo, wco;
+    float* tick;             // Adam step counter to advance (the update follows in the same step) or null
 };
 __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __restrict__ grad) {
     const int task = blockIdx.y;
     if (fa.stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         fa.stats[0] = fa.wc * fa.stats[1] + fa.wo * fa.stats[2] + fa.wco * fa.stats[3];
+    if (fa.tick && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) fa.tick[0] += 1.f;
     // Both task kinds are pure reductions over S slabs / P partial rows: the loops keep 8 loads in flight
     // per lane (unconditional on a clamped index, pinned, masked when added) -- as dependent loops with
     // two loads in flight the 58-slab weight-gradient sums made this kernel 11 us.
@@ -303,6 +305,7 @@ struct Ctx {
     int rpb_n, rpb_b;   // rows per block for node-level / graph-level row walkers
     int nfork;          // weight-gradient GEMMs forked to the side stream so far
     const int64_t* y; const int64_t* perm; float wc, wo, wco; int want_grad;
+    int tick_in_finish; // the step ends with the Adam update: k_finish advances the step counter
     size_t parts_off;   // bump allocator over Engine::parts
     FinalArgs fin;      // pending k_stats_final tasks
 };
@@ -689,6 +692,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     const float* xin[3] = {e->pooled, e->pooled + BH, e->xco};
     FinishArgs fa;
     memset(&fa, 0, sizeof(fa));
+    fa.tick = c.tick_in_finish ? e->step : nullptr;
     size_t slab_off = 0;
     auto commit_p = [&](const double* src, int P, int stride, int dst, int n, float scale) {
         if (fa.nct < MAX_COMMITS) fa.ct[fa.nct] = CommitTask{src, P, stride, dst, n, scale};
@@ -978,7 +982,9 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     c.nfork = 0;
     const int want_grad = (mode & 2) ? 1 : 0;
     c.y = y; c.perm = perm; c.wc = wc; c.wo = wo; c.wco = wco; c.want_grad = want_grad;
+    c.tick_in_finish = (mode & 4) ? 1 : 0;
     CAL_REQUIRE(!want_grad || c.training, "backward needs a training-mode forward");
+    CAL_REQUIRE(!(mode & 4) || want_grad, "the Adam update needs the backward pass in the same step");
     g_stage = 0;
     g_stage_names.clear();
     {
@@ -992,12 +998,10 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
             if (rc) return rc;
         }
     }
-    if (mode & 4) {
+    if (mode & 4) {          // k_finish has already advanced the step counter (c.tick_in_finish)
         hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, c.st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
-                           e->beta2, e->eps, e->wd, e->nparam);
+                           e->beta2, e->eps, e->wd, e->nparam, 1);
         CAL_CHECK_LAUNCH("k_adam");
-        hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, c.st, e->step);
-        CAL_CHECK_LAUNCH("k_adam_tick");
     }
     return 0;
 }
@@ -1018,6 +1022,7 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
     c.rpb_b = std::max(32, cdiv(B, 64));
     c.parts_off = 0; c.fin.nt = 0; c.nfork = 0;
     c.y = nullptr; c.perm = nullptr; c.wc = c.wo = c.wco = 0.f; c.want_grad = 1;
+    c.tick_in_finish = 0;
     hipLaunchKernelGGL(k_logsoftmax_bwd, dim3(1), dim3(256), 0, c.st, e->logp, dlogp, e->dzl, e->arena + e->a_db2, (int)B, e->C);
     CAL_CHECK_LAUNCH("k_logsoftmax_bwd");
     g_stage = 0;
@@ -1070,7 +1075,7 @@ CAL_EXPORT int cal_engine_adam(void* h, void* stream_) {
     Engine* e = (Engine*)h;
     hipStream_t st = (hipStream_t)stream_;
     hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
-                       e->beta2, e->eps, e->wd, e->nparam);
+                       e->beta2, e->eps, e->wd, e->nparam, 0);
     CAL_CHECK_LAUNCH("k_adam");
     hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, e->step);
     CAL_CHECK_LAUNCH("k_adam_tick");

@@ -862,12 +862,12 @@ struct CommitTask { const double* src; int P; int stride; int dst; int n; float 
 
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        float* __restrict__ step, const float* __restrict__ lr_ptr, float beta1, float beta2, float eps,
-                       float wd, int64_t n) {
+                       float wd, int64_t n, int ticked) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // every thread reads the (not yet incremented) step; thread 0 of the LAST block to finish would
-    // race, so the increment happens in a separate tiny launch (k_adam_tick)
+    // every thread reads the step counter, so it cannot be advanced in this launch: either the step's
+    // k_finish has already done it (ticked = 1) or a separate tiny launch follows (k_adam_tick)
     if (i >= n) return;
-    const float t = step[0] + 1.f;
+    const float t = step[0] + (ticked ? 0.f : 1.f);
     const float lr = lr_ptr[0];
     float gi = g[i];
     if (wd != 0.f) gi = fmaf(wd, p[i], gi);
