@@ -21,6 +21,7 @@
 
 #include "engine_kernels.hpp"
 #include "engine_readout.hpp"
+#include "engine_gconv.hpp"
 
 namespace cal {
 
@@ -123,7 +124,8 @@ struct Engine {
     double* parts; size_t parts_doubles;
     // side stream for the weight-gradient GEMMs (off the critical path until the final commit)
     hipStream_t side; hipEvent_t ev_fork[24], ev_join[24];
-    int *rowptr_dst, *nbr_dst, *eid_dst, *rowptr_src, *nbr_src, *eid_src, *row32, *col32, *work, *status, *gptr, *iperm;
+    int *rowptr_dst, *nbr_dst, *eid_dst, *rowptr_src, *nbr_src, *eid_src, *row32, *col32, *work, *status, *gptr, *iperm, *eptr;
+    int max_nodes, max_edges;   // per-graph bounds of the coming batches (0 = unknown): cal_engine_set_graph_bounds
 };
 
 static size_t al(size_t n) { return (n + 63) / 64 * 64; }   // 256 B granules (in floats/ints)
@@ -260,6 +262,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     I32(e->rowptr_src, N + 1); I32(e->nbr_src, E); I32(e->eid_src, E);
     I32(e->row32, E); I32(e->col32, E); I32(e->work, 4 * (N + 1) + 4 * E); I32(e->status, 4); I32(e->gptr, B + 1);
     I32(e->iperm, B);
+    I32(e->eptr, B + 1);
     return off * 4;
 }
 
@@ -472,6 +475,20 @@ int dual_gemm(Ctx& c, GemmArgs& ax, int nbx, GemmArgs& aw, int nbw, float** dst,
     return launch_gemm_dual(ax, nbx, aw, nbw, c.st);
 }
 
+// per-graph fused convolution (engine_gconv.hpp): needs the batch's per-graph bounds from the host
+bool use_gc(const Ctx& c) {
+    const Engine* e = c.e;
+    return e->max_nodes > 0 && e->max_nodes <= GC_T && e->max_edges <= GC_E && e->H % GC_N == 0 && e->H <= GC_K && c.B > 0;
+}
+bool gc_small(const Ctx& c) { return c.e->max_nodes <= 64 && c.e->max_edges <= gc_edge_cap(64); }
+// partial-row statistics of a per-graph kernel: one row per graph
+Acc graph_acc(Ctx& c, double* dst, int cols) {
+    double* p = parts_alloc(c, (size_t)c.B * cols);
+    if (!p) return Acc(dst);
+    final_task(c, p, c.B, cols, cols, dst);
+    return Acc(dst, p, cols);
+}
+
 bool use_ro(const Ctx& c) {
     const int B = c.B, H = c.e->H, C = c.e->C;
     const int B4 = (B + 15) & ~15;
@@ -546,7 +563,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     RC(plan_build(edge_index, E, N, e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
                   e->row32, e->col32, e->work, e->status, true, st)); STAGE();
     hipLaunchKernelGGL(k_gptr_dis, dim3(cdiv(N + 1, 256)), dim3(256), 0, st, batch, N, B, e->gptr, e->rowptr_src, e->loop_w,
-                       e->dis_unit, e->status);
+                       e->dis_unit, e->status, e->rowptr_dst, e->eptr);
     CAL_CHECK_LAUNCH("k_gptr_dis"); STAGE();
     const CSR gd{e->rowptr_dst, e->nbr_dst, e->eid_dst, (int)c.E}, gs{e->rowptr_src, e->nbr_src, e->eid_src, (int)c.E};
     (void)gs;
@@ -567,7 +584,25 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         RC(flush_finals(c)); STAGE();
     }
     // 4. backbone: h_i = relu(A_hat (BN_i(h_{i-1}) @ W_i) + b_i)   (model.py:93-95)
+    const bool gc = use_gc(c);
     for (int i = 1; i <= L; ++i) {
+        if (gc) {        // GEMM + aggregation + statistics in one per-graph kernel
+            GconvBranch gb;
+            memset(&gb, 0, sizeof(gb));
+            gb.x = e->h + (size_t)(i - 1) * NH; gb.W = e->P + e->o_conv_w[i - 1]; gb.bias = e->P + e->o_conv_b[i - 1];
+            gb.dis = e->dis_unit; gb.bn = bnref(c, i, N, 1); gb.out = e->h + (size_t)i * NH;
+            if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H); }
+            {
+                ProfScope ps(st, 2, 2.0 * N * H * H);
+                if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<false, 64>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, gb, gb, 1,
+                                                    e->loop_w, H, H, e->status);
+                else hipLaunchKernelGGL((k_gconv_fwd<false, GC_T>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, gb, gb, 1,
+                                        e->loop_w, H, H, e->status);
+            }
+            CAL_CHECK_LAUNCH("k_gconv_fwd"); STAGE();
+            RC(flush_finals(c)); STAGE();
+            continue;
+        }
         GemmArgs a = gemm_args(N, H, H, false, false, 0);
         a.p[0].A = e->h + (size_t)(i - 1) * NH; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->z;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 1);
@@ -605,8 +640,24 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     hipLaunchKernelGGL(k_edge_att_deg, dim3(cdiv(N, 32)), dim3(256), 0, st, gs, e->pq, e->P + e->o_eatt_b, e->att, e->dis_co,
                        e->dis_co + N, e->loop_w, N, E);
     CAL_CHECK_LAUNCH("k_edge_att_deg"); STAGE();
+    // 7-9 fused: both weighted convolutions and the add-pool in one per-graph launch
+    if (gc) {
+        GconvBranch gb[2];
+        memset(gb, 0, sizeof(gb));
+        for (int k = 0; k < 2; ++k) {
+            gb[k].x = x; gb[k].W = e->P + (k ? e->o_ow : e->o_cw); gb[k].bias = e->P + (k ? e->o_ob : e->o_cb);
+            gb[k].ew = e->att + (size_t)k * E; gb[k].dis = e->dis_co + (size_t)k * N;
+            gb[k].rs = e->anode + k; gb[k].rs_stride = 2; gb[k].bn = bnref(c, L + 1 + k, N, 1);
+            gb[k].out = e->hco + (size_t)k * NH; gb[k].z = e->zco + (size_t)k * NH; gb[k].pooled = e->pooled + (size_t)k * B * H;
+        }
+        if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<true, 64>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, gb[0], gb[1], 1,
+                                            e->loop_w, H, H, e->status);
+        else hipLaunchKernelGGL((k_gconv_fwd<true, GC_T>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, gb[0], gb[1], 1,
+                                e->loop_w, H, H, e->status);
+        CAL_CHECK_LAUNCH("k_gconv_fwd(co)"); STAGE();
+    }
     // 7. z_k = BN_k(a_k * x) @ W_k for k in (context, objects)   (model.py:112-113)
-    {
+    if (!gc) {
         GemmArgs a = gemm_args(N, H, H, false, false, 0);
         for (int k = 0; k < 2; ++k) {
             a.p[k].A = x; a.p[k].B = e->P + (k ? e->o_ow : e->o_cw); a.p[k].C = e->zco + (size_t)k * NH;
@@ -616,7 +667,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         RC(fwd_gemm(c, false, a, 2)); STAGE();
     }
     // 8. h_k = relu(A_hat_k z_k + b_k)
-    {
+    if (!gc) {
         SpmmBranch b0{e->zco, e->hco, e->P + e->o_cb, e->att, e->dis_co, Acc(), Acc()};
         SpmmBranch b1{e->zco + NH, e->hco + NH, e->P + e->o_ob, e->att + E, e->dis_co + N, Acc(), Acc()};
         RC(with_g(H, [&](auto g) {
@@ -627,7 +678,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         CAL_CHECK_LAUNCH("k_espmm(co)"); STAGE();
     }
     // 9. add-pool (model.py:115-116)
-    {
+    if (!gc) {
         int tc = std::min(256, pow2ceil(H / 4));
         hipLaunchKernelGGL((k_pool2<4>), dim3(B, 2), dim3(256), 0, st, e->hco, e->hco + NH, e->gptr, e->pooled,
                            e->pooled + (size_t)B * H, H, tc);
@@ -1031,6 +1082,16 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
     return rc == -12345 ? 0 : rc;
 }
 
+// Per-graph bounds of the batches that follow (largest node count / stored-edge count of any single graph;
+// 0 = unknown).  With bounds that fit (engine_gconv.hpp) the step runs the per-graph fused convolutions; a
+// bound that turns out too small sets bit 3 of the status word and leaves that graph's outputs unwritten.
+CAL_EXPORT int cal_engine_set_graph_bounds(void* h, int64_t max_nodes, int64_t max_edges) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e != nullptr && max_nodes >= 0 && max_edges >= 0, "bad arguments");
+    e->max_nodes = (int)std::min<int64_t>(max_nodes, 1 << 30);
+    e->max_edges = (int)std::min<int64_t>(max_edges, 1 << 30);
+    return 0;
+}
 CAL_EXPORT int cal_engine_debug_stop(int k) { g_stop_after = k; return 0; }
 // name of launch site k (1-based, as counted by cal_engine_debug_stop) in the latest untruncated step; "" past the end
 CAL_EXPORT const char* cal_engine_stage_name(int k) {

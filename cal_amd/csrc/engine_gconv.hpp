@@ -1,0 +1,333 @@
+// Per-graph fused GCN convolution of the step engine, forward:
+//     out = relu(A_hat (BN(rs * x) @ W) + b)          (gcn_conv.py:75-104 behind model.py:93-95, 112-113)
+// as ONE kernel instead of GEMM -> aggregation.  A mini-batch's adjacency is block diagonal (one block
+// per graph, ~57 nodes for SPMotif), so a workgroup that owns a whole graph and a 64-column slice of the
+// output keeps z = BN(x) W in LDS, builds the graph's dense normalised adjacency block next to it and
+// aggregates with a second matrix product: z never goes to HBM, there is no neighbour gather at all, and
+// the per-graph column sums of the output (add-pool, model.py:115-116) and the next BatchNorm's batch
+// statistics fall out of the epilogue.
+//
+//   grid (B graphs, H / 64 column slices, branches), 256 threads; requires per graph <= GC_T nodes and
+//   <= GC_E stored edges (the host passes the batch's bounds, cal_engine_set_graph_bounds; otherwise the
+//   unfused kernels run), H % 64 == 0 and K = hidden <= GC_K.
+//
+// Timeline of a workgroup: graph extents (gptr/eptr) -> every global load of the kernel issued at once
+// (x rows, W slice, CSR rows and edges, BN statistics) -> edge coefficients dis_j * w_e -> operands
+// staged in LDS (x transposed to k-major with BN / row scale applied) -> z = x' W on 32x32x2 f32 MFMAs ->
+// z tile to LDS (over the W stage), adjacency block At[j][i] = dis_i * coef_ij (+ the self loop) built
+// over the x stage by one lane per row -> out tile = A z on MFMAs -> bias, ReLU, store, column sums.
+// (Aggregating from the CSR rows with LDS reads instead was a chain of dependent LDS accesses per edge
+// with one wave per SIMD to hide it: 4.5-9 us per graph; the dense product is ~1 us.)
+#pragma once
+#include "engine_readout.hpp"     // RO_CLK profiling aid
+
+namespace cal {
+
+constexpr int GC_T = 128;                 // nodes per graph (T = 128 instantiation; T = 64 for small graphs)
+constexpr int GC_N = 64;                  // output columns per workgroup
+constexpr int GC_K = 128;                 // reduction width (= hidden)
+constexpr int GC_E = 2048;                // stored edges per graph (T = 128; half of it for T = 64)
+constexpr int GC_LDB = GC_N + 4, GC_LDZ = GC_N + 1;
+// T = 64 keeps a workgroup under 80 KB of LDS, so two of them share a CU: the two-branch launch (512
+// workgroups) then needs one pass over the chip instead of two, and one workgroup's loads overlap the
+// other's MFMAs.
+constexpr int gc_edge_cap(int T) { return T == 64 ? 1024 : 2048; }
+
+struct GconvBranch {
+    const float* x;          // [N,K] layer input (raw)
+    const float* W;          // [K,H]
+    const float* bias;       // [H]
+    const float* ew;         // per-edge weight in edge-id order, or null (all ones)
+    const float* dis;        // [N] deg^-1/2 (of the weighted degrees when ew is set)
+    const float* rs;         // per-row scale of x (node attention), or null
+    int rs_stride;
+    BNRef bn;                // BatchNorm applied to rs * x
+    float* out;              // [N,H]
+    float* z;                // [N,H] BN(rs x) W, kept for the backward of the weighted convs, or null
+    float* pooled;           // [B,H] per-graph column sums of out (global_add_pool), or null
+    Acc st_sum, st_sq;       // column statistics of out (one partial row per graph), or off
+};
+
+typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
+
+// kred/32 blocks of 16 MFMA steps over k-major LDS operands A[k][row] (stride LDA) and B[k][col]
+// (stride LDB); TWO = this wave also owns row tile r0 + 2 (graphs with more than 64 nodes)
+template <bool TWO, int LDA, int LDB>
+__device__ __forceinline__ void gconv_mma(const float* As, const float* Bs, int kred, int r0, int ct, int li, int lk,
+                                          gc_f32x16& acc0, gc_f32x16& acc1) {
+    const float* a0p = As + r0 * 32 + li;
+    const float* a1p = As + (r0 + 2) * 32 + li;
+    const float* bp = Bs + ct * 32 + li;
+    float a0[2][16], a1[2][16], bv[2][16];
+    auto read_ops = [&](int kb, int s) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = kb * 32 + 2 * i + lk;
+            a0[s][i] = a0p[k * LDA];
+            if (TWO) a1[s][i] = a1p[k * LDA];
+            bv[s][i] = bp[k * LDB];
+        }
+    };
+    const int nkb = kred / 32;
+    read_ops(0, 0);
+    for (int kb = 0; kb < nkb; kb += 2) {
+        if (kb + 1 < nkb) read_ops(kb + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0][i], bv[0][i], acc0, 0, 0, 0);
+            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][i], bv[0][i], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 1 < nkb) {
+            if (kb + 2 < nkb) read_ops(kb + 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1][i], bv[1][i], acc0, 0, 0, 0);
+                if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][i], bv[1][i], acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <bool RS, int T>
+__global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
+                                                   const GconvBranch b0, const GconvBranch b1, int relu, float loop_w, int H,
+                                                   int K, int* __restrict__ status) {
+    constexpr int LDA = T + 1, ECAP = gc_edge_cap(T);
+    __shared__ __attribute__((aligned(16))) float As[GC_K * LDA];          // x stage [k][row]; later the adjacency block [j][i]
+    __shared__ __attribute__((aligned(16))) float Bs[GC_K * GC_LDB];       // W slice [k][col]; later the z tile [row][col]
+    __shared__ float sc_s[GC_K], sh_s[GC_K];
+    __shared__ int ptr_s[T + 4];
+    __shared__ float dis_s[T];
+    __shared__ int en[ECAP];
+    __shared__ float ec[ECAP];
+    __shared__ double red[4][2][32];
+    __shared__ float pool_s[4][32];
+    BLK_CLK(0);
+    const GconvBranch& br = blockIdx.z ? b1 : b0;
+    const int b = blockIdx.x, n0 = blockIdx.y * GC_N, t = threadIdx.x;
+    const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
+    const bool want = br.st_sum.on();
+    if (rows <= 0) {                                     // empty graph: its partial rows still have to exist
+        if (br.bn.update && blockIdx.x == 0 && blockIdx.y == 0 && t < K) bn_update_running(br.bn, t);
+        if (t < GC_N) {
+            if (want) { br.st_sum.add(n0 + t, 0.0); br.st_sq.add(n0 + t, 0.0); }
+            if (br.pooled) br.pooled[(size_t)b * H + n0 + t] = 0.f;
+        }
+        return;
+    }
+    if (rows > T || ne > ECAP || ne < 0) {            // the host's bounds were wrong: flag it, write nothing
+        if (t == 0) atomicOr(status, 8);
+        return;
+    }
+    RO_CLK(32);
+    BLK_CLK(2);
+    const bool hasw = br.ew != nullptr;
+    const int rowsP = (rows + 31) & ~31, R = rowsP >> 5, nkc = K >> 5;
+    // ---- every global load of the kernel, issued before the first wait -------------------------------------
+    // x rows: item (u, t) -> 32-wide k chunk kc, row block rr, row (t >> 3), float4 (t & 7) of the chunk:
+    // 8 lanes x 16 B per row (coalesced), and the transposing LDS stores below see only 2-way bank conflicts
+    constexpr int UA = T / 8;                          // x float4s per lane: T rows x GC_K / 4 over 256 lanes
+    float4 va[UA];
+    {
+        int kc = 0, rr = 0;
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            const bool ok = kc < nkc;
+            const int r = min(((ok ? rr : 0) << 5) + (t >> 3), rows - 1), k = ((ok ? kc : 0) << 5) + ((t & 7) << 2);
+            va[u] = *reinterpret_cast<const float4*>(br.x + (size_t)(g0 + r) * K + k);
+            if (++rr == R) { rr = 0; ++kc; }
+        }
+    }
+    float4 vb[8];                                        // W[k][n0 + 4 j4 ..]: 16 lanes per k row
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int idx = t + u * 256, k = min(idx >> 4, K - 1), j4 = idx & 15;
+        vb[u] = *reinterpret_cast<const float4*>(br.W + (size_t)k * H + n0 + 4 * j4);
+    }
+    const int pv = g.ptr[g0 + min(t, rows)];
+    const float dv = br.dis[g0 + min(t, rows - 1)];
+    float rsv[4] = {1.f, 1.f, 1.f, 1.f};                 // row scale of this lane's x row in each 32-row block
+    if (RS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rsv[q] = br.rs[(size_t)(g0 + min((q << 5) + (t >> 3), rows - 1)) * br.rs_stride];
+    }
+    int nv[8], ev[8];
+    if (ne > 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = e0 + min(t + u * 256, ne - 1);
+            nv[u] = g.nbr[s];
+            ev[u] = hasw ? g.eid[s] : 0;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { nv[u] = g0; ev[u] = 0; }
+    }
+    const int lane = t & 63, li = lane & 31, lk = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ct = w & 1, r0 = w >> 1;
+    const float bias = br.bias ? br.bias[n0 + ct * 32 + li] : 0.f;
+    if (t < K) {
+        bn_scale_shift(br.bn, t, sc_s[t], sh_s[t]);
+        if (br.bn.update && blockIdx.x == 0 && blockIdx.y == 0) bn_update_running(br.bn, t);
+    }
+    // all of the above stay in flight together: without the pins hipcc pairs every W load with its LDS store
+    // ("load, s_waitcnt vmcnt(0), ds_write" x 8: eight serial round trips, 5-30 us under 256-way contention)
+#pragma unroll
+    for (int u = 0; u < UA; ++u) ro_pin(va[u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ro_pin(vb[u]);
+    // second round: edge coefficients dis_j * w_e (needs the neighbour / edge ids)
+    float cv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        float c = br.dis[nv[u]];
+        if (hasw) c *= br.ew[ev[u]];
+        cv[u] = c;
+    }
+    RO_CLK(33);
+    // ---- stage everything in LDS ---------------------------------------------------------------------------
+    if (t <= rows) ptr_s[t] = pv - e0;
+    if (t < rows) dis_s[t] = dv;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int s = t + u * 256;
+        if (s < ne) {
+            const int loc = nv[u] - g0;
+            const bool inb = loc >= 0 && loc < rows;        // an edge that leaves its graph is not a mini-batch: flag it
+            en[s] = inb ? loc : 0; ec[s] = inb ? cv[u] : 0.f;
+            if (!inb) atomicOr(status, 16);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int idx = t + u * 256, k = idx >> 4, j4 = idx & 15;
+        if (k < K) *reinterpret_cast<float4*>(Bs + k * GC_LDB + 4 * j4) = vb[u];
+    }
+    RO_CLK(34);
+    __syncthreads();                                     // BN tables
+    {
+        int kc = 0, rr = 0;
+#pragma unroll
+        for (int u = 0; u < UA; ++u) {
+            if (kc < nkc) {
+                const int r = (rr << 5) + (t >> 3), k = (kc << 5) + ((t & 7) << 2);
+                float x0 = va[u].x, x1 = va[u].y, x2 = va[u].z, x3 = va[u].w;
+                if (RS) {
+                    const float s = rr == 0 ? rsv[0] : (rr == 1 ? rsv[1] : (rr == 2 ? rsv[2] : rsv[3]));
+                    x0 *= s; x1 *= s; x2 *= s; x3 *= s;
+                }
+                float* d = As + k * LDA + r;
+                d[0] = fmaf(x0, sc_s[k], sh_s[k]);
+                d[LDA] = fmaf(x1, sc_s[k + 1], sh_s[k + 1]);
+                d[2 * LDA] = fmaf(x2, sc_s[k + 2], sh_s[k + 2]);
+                d[3 * LDA] = fmaf(x3, sc_s[k + 3], sh_s[k + 3]);
+            }
+            if (++rr == R) { rr = 0; ++kc; }
+        }
+    }
+    __syncthreads();
+    RO_CLK(35);
+    BLK_CLK(3);
+    // ---- z tile = BN(x) W on the matrix cores: wave w owns column tile w & 1 and row tiles w >> 1 (, + 2) ---
+    gc_f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    if (r0 < R) {
+        if (r0 + 2 < R) gconv_mma<true, LDA, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
+        else gconv_mma<false, LDA, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
+    }
+    RO_CLK(36);
+    __syncthreads();                                     // every wave is done reading both stages
+    // ---- z tile -> LDS (over the W stage); zero the adjacency block (over the x stage) ------------------------
+    float* Zs = Bs;
+    float* At = As;                                      // At[j * LDA + i] = weight of edge j -> i, times dis_i
+    if (r0 < R) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            Zs[row * GC_LDZ + ct * 32 + li] = acc0[r];
+            if (br.z && row < rows) br.z[(size_t)(g0 + row) * H + n0 + ct * 32 + li] = acc0[r];
+        }
+        if (r0 + 2 < R) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r0 + 2) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                Zs[row * GC_LDZ + ct * 32 + li] = acc1[r];
+                if (br.z && row < rows) br.z[(size_t)(g0 + row) * H + n0 + ct * 32 + li] = acc1[r];
+            }
+        }
+    }
+    {
+        const int nz4 = (rowsP * LDA + 3) >> 2;       // rows j < rowsP of the block (contiguous), as float4s
+        float4* z4 = reinterpret_cast<float4*>(At);
+        for (int idx = t; idx < nz4; idx += 256) z4[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    // one lane per destination row i: its incoming edges and its self loop (duplicate edges accumulate)
+    if (t < rows) {
+        const float di = dis_s[t];
+        for (int s = ptr_s[t]; s < ptr_s[t + 1]; ++s) At[en[s] * LDA + t] += di * ec[s];
+        At[t * LDA + t] += di * di * loop_w;
+    }
+    __syncthreads();
+    RO_CLK(37);
+    // ---- out tile = A z on the matrix cores (reduction over the graph's rowsP nodes) ---------------------------
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    if (r0 < R) {
+        if (r0 + 2 < R) gconv_mma<true, LDA, GC_LDZ>(At, Zs, rowsP, r0, ct, li, lk, acc0, acc1);
+        else gconv_mma<false, LDA, GC_LDZ>(At, Zs, rowsP, r0, ct, li, lk, acc0, acc1);
+    }
+    RO_CLK(38);
+    // ---- epilogue: bias, ReLU, store, column sums of this graph ---------------------------------------------------
+    double s1 = 0.0, s2 = 0.0;
+    float psum = 0.f;
+    const int col = n0 + ct * 32 + li;
+    asm volatile("" :: "v"(bias));                       // consume the bias load before the guarded stores (see gemm.hip)
+    if (r0 < R) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            float v = acc0[r] + bias;
+            if (relu) v = fmaxf(v, 0.f);
+            if (row < rows) {
+                br.out[(size_t)(g0 + row) * H + col] = v;
+                s1 += (double)v; s2 += (double)v * (double)v; psum += v;
+            }
+        }
+        if (r0 + 2 < R) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r0 + 2) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                float v = acc1[r] + bias;
+                if (relu) v = fmaxf(v, 0.f);
+                if (row < rows) {
+                    br.out[(size_t)(g0 + row) * H + col] = v;
+                    s1 += (double)v; s2 += (double)v * (double)v; psum += v;
+                }
+            }
+        }
+    }
+    // lanes lk = 0 / 1 hold different rows of the same column; waves w and w ^ 2 hold the other row tiles
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    if (lk == 0) { red[w][0][li] = s1; red[w][1][li] = s2; pool_s[w][li] = psum; }
+    __syncthreads();
+    if (w < 2 && lk == 0) {
+        if (want) {
+            br.st_sum.add(col, red[w][0][li] + red[w + 2][0][li]);
+            br.st_sq.add(col, red[w][1][li] + red[w + 2][1][li]);
+        }
+        if (br.pooled) br.pooled[(size_t)b * H + col] = pool_s[w][li] + pool_s[w + 2][li];
+    }
+    RO_CLK(39);
+    BLK_CLK(1);
+}
+
+}  // namespace cal

@@ -11,9 +11,9 @@
 namespace cal {
 
 #ifdef CAL_BLK_CLOCKS                     // profiling aid: start / end timestamp (100 MHz) of every workgroup of one kernel
-__device__ long long g_blk_clk[2 * 4096];
+__device__ long long g_blk_clk[4 * 2048];     // 4 timestamps per workgroup: entry, two free marks, exit
 #define BLK_CLK(which) do { const int b_ = blockIdx.x + gridDim.x * blockIdx.y; \
-                            if (threadIdx.x == 0 && b_ < 4096) g_blk_clk[2 * b_ + (which)] = wall_clock64(); } while (0)
+                            if (threadIdx.x == 0 && b_ < 2048) g_blk_clk[4 * b_ + ((which) == 1 ? 3 : (which) == 0 ? 0 : (which) - 1)] = wall_clock64(); } while (0)
 #else
 #define BLK_CLK(which) do {} while (0)
 #endif
@@ -127,9 +127,10 @@ __global__ void __launch_bounds__(256) k_colstats(const float* __restrict__ x, i
 // ------------------------------------------------------------------------------------------------
 // gptr + unweighted deg^-1/2 (gcn_conv.py:65-68 with edge_weight = 1)
 // ------------------------------------------------------------------------------------------------
+// eptr[b] = first CSR-by-destination slot of graph b (the per-graph kernels' edge range)
 __global__ void k_gptr_dis(const int64_t* __restrict__ batch, int N, int B, int* __restrict__ gptr,
                            const int* __restrict__ ptr_src, float loop_w, float* __restrict__ dis_unit,
-                           int* __restrict__ status) {
+                           int* __restrict__ status, const int* __restrict__ ptr_dst, int* __restrict__ eptr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > N) return;
     if (i < N) {
@@ -139,7 +140,10 @@ __global__ void k_gptr_dis(const int64_t* __restrict__ batch, int N, int B, int*
     int64_t prev = i == 0 ? -1 : batch[i - 1];
     int64_t cur = i == N ? (int64_t)B : batch[i];
     if (i < N && (cur < prev || cur >= B || cur < 0)) { atomicOr(status, 2); return; }
-    for (int64_t b = prev + 1; b <= cur && b <= B; ++b) gptr[b] = i;
+    if (prev + 1 <= cur) {
+        const int pd = ptr_dst[i];
+        for (int64_t b = prev + 1; b <= cur && b <= B; ++b) { gptr[b] = i; eptr[b] = pd; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -82,6 +82,10 @@ class Batch(Data):
         self.ptr = None
         self.num_graphs = 0
         self._plan = None
+        # largest node / edge count of a single member graph (host ints, 0 = unknown): lets the native step
+        # engine pick its per-graph fused kernels without a device round trip
+        self.max_nodes = 0
+        self.max_edges = 0
 
     @staticmethod
     def from_data_list(data_list: Sequence[Data]) -> "Batch":
@@ -107,6 +111,8 @@ class Batch(Data):
         b.batch = torch.cat(bvec, 0) if bvec else torch.zeros(0, dtype=torch.long)
         b.ptr = torch.tensor(ptr, dtype=torch.long)
         b.num_graphs = len(data_list)
+        b.max_nodes = max((int(d.num_nodes) for d in data_list), default=0)
+        b.max_edges = max((int(d.edge_index.size(1)) for d in data_list), default=0)
         return b
 
     @property

@@ -79,6 +79,8 @@ class DeviceDataset:
         else:
             b.feat = xo
         b.num_graphs = B
+        b.max_nodes = int(n.max()) if B else 0
+        b.max_edges = int(e.max()) if B else 0
         b.ptr = None
         b._meta = meta            # keep the device copy alive until the kernel has consumed it
         return b

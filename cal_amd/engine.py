@@ -91,6 +91,7 @@ class StepEngine:
                   betas[0], betas[1], eps, weight_decay)
         self._ws: Optional[torch.Tensor] = None
         self._cap = (0, 0, 0)
+        self._bounds = (0, 0)
         self.wc, self.wo, self.wco = float(getattr(a, "c", 0.5)), float(getattr(a, "o", 1.0)), float(getattr(a, "co", 0.5))
 
     def __del__(self):
@@ -135,6 +136,10 @@ class StepEngine:
             raise ValueError("features must be float32 [N, %d]" % self.F)
         self.reserve(N, E, B)
         self._last_B = B
+        bounds = (int(getattr(batch, "max_nodes", 0) or 0), int(getattr(batch, "max_edges", 0) or 0))
+        if bounds != self._bounds:
+            _lib.call("cal_engine_set_graph_bounds", self._h, bounds[0], bounds[1])
+            self._bounds = bounds
         if perm is None:
             perm = torch.arange(B, device=self.device)
         if y is None:

@@ -160,6 +160,10 @@ CAL_API int cal_engine_adam(void* engine, void* stream);
 /* backward from an external d loss / d log-probs [3,B,C] of the last training-mode forward (autograd surface) */
 CAL_API int cal_engine_backward_from(void* engine, const float* x0, const int64_t* batch,
                                      const float* dlogp, int64_t N, int64_t E, int64_t B, void* stream);
+/* per-graph bounds of the coming batches (largest node count / edge count of a single graph; 0 = unknown):
+ * when they fit, the step runs its per-graph fused convolution kernels (GEMM + aggregation + add-pool in
+ * LDS); a violated bound sets bit 3 of the engine's status word */
+CAL_API int cal_engine_set_graph_bounds(void* engine, int64_t max_nodes, int64_t max_edges);
 /* profiling aid: make cal_engine_step return after its k-th launch site (0 = run everything) */
 CAL_API int cal_engine_debug_stop(int k);
 /* name of launch site k (1-based) of the latest untruncated cal_engine_step; "" past the end */

@@ -21,15 +21,20 @@ for stop in [int(a) for a in sys.argv[1:]]:
     torch.cuda.synchronize()
     out = (ctypes.c_longlong * 8192)()
     assert f(out) == 0
-    t = np.array(list(out), dtype=np.int64).reshape(4096, 2) / 100.0
-    t = t[t[:, 1] > 0]
-    # keep the blocks of the latest launch: those whose start is within 100 us of the newest start
-    t = t[t[:, 0] > t[:, 0].max() - 100.0]
+    t = np.array(list(out), dtype=np.int64).reshape(2048, 4) / 100.0          # entry, mark 2, mark 3, exit
+    t = t[t[:, 3] > 0]
+    t = t[t[:, 0] > t[:, 0].max() - 100.0]          # the blocks of the latest launch
     t0 = t[:, 0].min()
-    d = t[:, 1] - t[:, 0]
+    d = t[:, 3] - t[:, 0]
     print("stop %d: %d workgroups, starts spread %.2f us, durations min/med/max %.2f/%.2f/%.2f us, last end %.2f us after first start"
-          % (stop, len(t), t[:, 0].max() - t0, d.min(), np.median(d), d.max(), t[:, 1].max() - t0))
-    order = np.argsort(t[:, 0])
-    q = [0, len(t) // 4, len(t) // 2, 3 * len(t) // 4, len(t) - 1]
-    print("   start quantiles (us):", " ".join("%.2f" % (t[order[i], 0] - t0) for i in q), " end quantiles:", " ".join("%.2f" % (np.sort(t[:, 1])[i] - t0) for i in q))
+          % (stop, len(t), t[:, 0].max() - t0, d.min(), np.median(d), d.max(), t[:, 3].max() - t0))
+    if (t[:, 1] > 0).all() and (t[:, 2] > 0).all():
+        for name, ia, ib in (("entry->mark2", 0, 1), ("mark2->mark3", 1, 2), ("mark3->exit", 2, 3)):
+            x = t[:, ib] - t[:, ia]
+            print("   %-14s min/med/max %.2f/%.2f/%.2f us" % (name, x.min(), np.median(x), x.max()))
 _lib.lib().cal_engine_debug_stop(0)
+if os.environ.get("BLK_DUMP"):
+    x = (t[:, 2] - t[:, 1])
+    print("mark2->mark3 by block index (x = graph 0..127 then y=1):")
+    for r in range(0, len(x), 16):
+        print("  %3d: " % r + " ".join("%5.1f" % v for v in x[r:r + 16]))

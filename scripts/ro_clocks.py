@@ -19,5 +19,5 @@ f = _lib.lib().cal_debug_ro_clocks
 f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_int
 assert f(out) == 0
 v = list(out)
-for name, lo, hi in (("fwd_a", 0, 5), ("fwd_b", 6, 10), ("bwd_a", 24, 28), ("bwd_b", 16, 21)):
+for name, lo, hi in (("gconv", 32, 39), ("fwd_a", 0, 5), ("fwd_b", 6, 10), ("bwd_a", 24, 28), ("bwd_b", 16, 21)):
     print(name, " ".join("%.2fus" % ((v[k + 1] - v[k]) / 100.0) for k in range(lo, hi)), "total %.2fus" % ((v[hi] - v[lo]) / 100.0))
