@@ -181,7 +181,7 @@ def engine_roofline(trainer, batches, iters=20):
     n = int(h.cal_engine_profile_read(buf, cap))
     rec = np.array(buf[:3 * n], dtype=np.float64).reshape(n, 3)
     out = {}
-    for cls, key in ((0, "gemm"), (1, "spmm")):
+    for cls, key in ((0, "gemm"), (1, "spmm"), (2, "gconv"), (3, "dual")):
         r = rec[(rec[:, 0] == cls) & (rec[:, 1] > 0)]
         if len(r) == 0:
             continue
@@ -196,19 +196,34 @@ def engine_roofline(trainer, batches, iters=20):
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         pass
-    if "gemm" in out:
-        dur, work, per_step = out["gemm"]
+    note = ("config-2 working set (3.7 MB activations) is cache-resident and every launch is a few hundred "
+            "workgroups of one ~10 us dependent chain: the step is latency-bound by construction (SURVEY.md 8d); "
+            "event pairs include the launch gap")
+    mfma = {
+        "gemm": ("k_gemm", "k_gemm<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers, unfused path)", "k_gemm_backbone"),
+        "gconv": ("k_gconv_fwd", "k_gconv_fwd: per-graph fused BN + [n,H]x[H,64] MFMA GEMM + dense-block aggregation MFMA + "
+                                 "bias/ReLU/BN statistics (backbone layers, forward)", "k_gconv_fwd"),
+        "dual": ("k_gemm_dual", "k_gemm_dual: dX = dZ W^T (NT, BN-backward sums) + dW = BN(h)^T dZ (TN, split-K) in one grid "
+                                "(backbone layers, backward)", "k_gemm_dual"),
+    }
+    # primary roofline = the MFMA kernel class that takes the most time per step
+    best = None
+    for key in mfma:
+        if key in out and (best is None or out[key][0] * out[key][2] > out[best][0] * out[best][2]):
+            best = key
+    for key in mfma:
+        if key not in out:
+            continue
+        dur, work, per_step = out[key]
         ach = work / dur / 1e12
-        roof["roofline"] = dict(bound="mfma", kernel="k_gemm<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers)",
-                                achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3,
-                                traffic=pmc.get("k_gemm_backbone", {}).get("bytes_per_launch"),
-                                avg_launch_us=dur * 1e6, algorithmic_flops_per_launch=work, timed_launches_per_step=per_step,
-                                note="config-2 working set (3.7 MB activations) is cache-resident: the step is "
-                                     "launch/latency-bound by construction (SURVEY.md 8d); event pairs include the launch gap")
+        d = dict(bound="mfma", kernel=mfma[key][1], achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3,
+                 traffic=pmc.get(mfma[key][2], {}).get("bytes_per_launch"), avg_launch_us=dur * 1e6,
+                 algorithmic_flops_per_launch=work, timed_launches_per_step=per_step, note=note)
+        roof["roofline" if key == best else "roofline_" + mfma[key][0]] = d
     if "spmm" in out:
         dur, work, per_step = out["spmm"]
         ach = work / dur / 1e9
-        roof["roofline_aggregation"] = dict(bound="hbm", kernel="k_espmm (CSR aggregation + bias + ReLU + BN statistics)",
+        roof["roofline_aggregation"] = dict(bound="hbm", kernel="k_espmm (CSR aggregation; transposed, backward of the backbone layers)",
                                             achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
                                             traffic=pmc.get("k_espmm", {}).get("bytes_per_launch"),
                                             avg_launch_us=dur * 1e6, algorithmic_bytes_per_launch=work,

@@ -522,8 +522,9 @@ RoArgs make_ro(const Ctx& c) {
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 // live kernel timing for bench.py's roofline block: when enabled, HIP events are recorded on the
-// launch stream around every node-level dense GEMM ([N,H]x[H,H], class 0) and every aggregation
-// (k_espmm, class 1) of the step.  Events are created here (never in a normal step).
+// launch stream around the backbone's kernels: unfused forward GEMM ([N,H]x[H,H], class 0), aggregation
+// (k_espmm forward / transposed backward, class 1), per-graph fused convolution (class 2, flops), and the
+// backward's dX + dW dual GEMM (class 3, flops).  Events are created here (never in a normal step).
 struct ProfRec { hipEvent_t e0, e1; int cls; double work; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -593,7 +594,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             gb.dis = e->dis_unit; gb.bn = bnref(c, i, N, 1); gb.out = e->h + (size_t)i * NH;
             if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H); }
             {
-                ProfScope ps(st, 2, 2.0 * N * H * H);
+                ProfScope ps(st, 2, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H);
                 if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<false, 64>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, gb, gb, 1,
                                                     e->loop_w, H, H, e->status);
                 else hipLaunchKernelGGL((k_gconv_fwd<false, GC_T>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, gb, gb, 1,
@@ -919,11 +920,14 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     for (int i = L; i >= 1; --i) {
         float* dzi = e->dzi + (size_t)(i - 1) * NH;     // per layer: the side-stream dW GEMM reads it later
         SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
-        RC(with_g(H, [&](auto g) {
-            constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, br, br, 0, e->loop_w, N, H, spmm_rpb(H, false));
-            return 0;
-        }));
+        {
+            ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0);
+            RC(with_g(H, [&](auto g) {
+                constexpr int G = decltype(g)::value;
+                hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, br, br, 0, e->loop_w, N, H, spmm_rpb(H, false));
+                return 0;
+            }));
+        }
         CAL_CHECK_LAUNCH("k_espmm(T)"); STAGE();
         const float* hin = e->h + (size_t)(i - 1) * NH;
         {
@@ -936,7 +940,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[0].A = dzi; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->dXh;
             a.p[0].aux = hin; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, i, N, 0);
             gemm_stats(c, a.p[0], N, H, bn_dsum(c, i), bn_dprod(c, i), true);
-            RC(dual_gemm(c, a, 1, aw, 1, dst, fa, slab_off)); STAGE();
+            { ProfScope ps(st, 3, 4.0 * N * H * H); RC(dual_gemm(c, a, 1, aw, 1, dst, fa, slab_off)); } STAGE();
             RC(flush_finals(c)); STAGE();
         }
         {

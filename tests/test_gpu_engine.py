@@ -224,6 +224,11 @@ def _ragged_batch(seed, nfeat, sizes):
     (128, 0, 10, 4, [20, 30, 25, 8]),
     # fused-readout corner cases: B not a multiple of 16 (several 16-graph row blocks, clamped MFMA tiles),
     # hidden/4 not a divisor of 256 (LDS statistics pass), many classes (large fc2 tile, one lane per score)
+    # per-graph fused convolution: 64-node variant (two workgroups per CU), 128-node variant with one and two
+    # row tiles per wave (65..96 and 97..128 nodes), and a graph beyond 128 nodes (falls back to GEMM + aggregation)
+    (64, 2, 6, 3, [64, 1, 33, 2, 50]),
+    (128, 2, 10, 4, [100, 70, 128, 65, 3]),
+    (64, 1, 5, 2, [150, 20, 7]),
     (48, 1, 5, 3, [4, 2, 7] * 12 + [5]),
     (80, 2, 4, 40, [3, 5] * 50),
     (16, 1, 6, 2, [2, 3] * 100),
@@ -356,3 +361,36 @@ def test_trainer_device_perm_graph_trains_and_redraws():
     l_eager = tr2.step(b1, perm)[0].item()
     assert abs(l_graph - l_eager) < 1e-6
     assert torch.allclose(p_graph, tr2.flat_p, atol=1e-6)
+
+
+def test_fused_conv_matches_unfused_and_flags_bad_bounds():
+    """The per-graph fused convolution against the GEMM + aggregation path on the same batch (bounds withheld),
+    and the status word when the host's per-graph bounds are too small."""
+    torch.manual_seed(11)
+    sizes = [60, 33, 64, 17, 48, 5]
+    b = _ragged_batch(128, 10, sizes)
+    bd = _ragged_batch(128, 10, sizes).to(DEV)
+    bd.y = bd.y % 4
+    assert bd.max_nodes == 64 and bd.max_edges > 0
+    sd = O.init_state("CausalGCN", 10, 4, hidden=128, layers=2)
+    perm = torch.randperm(len(sizes)).to(DEV)
+    res = []
+    for fused in (True, False):
+        m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(hidden=128, layers=2), 10, 4)
+        if not fused:
+            bd.max_nodes, keep = 0, bd.max_nodes            # unknown bounds -> unfused kernels
+        stats = eng.train_step(bd, perm, adam=False).cpu().clone()
+        if not fused:
+            bd.max_nodes = keep
+        res.append((stats, eng.flat_g.clone(), eng.buffer("logp", 3 * len(sizes) * 4).clone()))
+    assert torch.allclose(res[0][0], res[1][0], atol=1e-5)
+    assert torch.allclose(res[0][2], res[1][2], atol=2e-5)
+    assert torch.allclose(res[0][1], res[1][1], atol=2e-5, rtol=1e-3)
+    # a bound that is too small for the kernel variant it selects: the engine flags it (bit 3) instead of
+    # reading outside its tiles
+    big = _ragged_batch(128, 10, [100, 20]).to(DEV)
+    big.y = big.y % 4
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(hidden=128, layers=2), 10, 4)
+    big.max_nodes, big.max_edges = 50, 10                    # claims the 64-node variant fits
+    eng.train_step(big, torch.arange(2, device=DEV), adam=False)
+    assert int(eng.buffer("status", 1, dtype=torch.int32).item()) & 8
