@@ -58,6 +58,30 @@ __device__ __forceinline__ void bn_mean_rstd(const BNRef& bn, int c, float& mean
     rstd = 1.0f / sqrtf(var + bn.eps);
 }
 
+// The same for the VEC consecutive columns c .. c+VEC-1 with every load issued before the first use:
+// called per column, each column's loads sit in their own conditional block and hipcc waits for one
+// column before it requests the next -- VEC dependent round trips in a kernel prologue.
+template <int VEC>
+__device__ __forceinline__ void bn_mean_rstd_v(const BNRef& bn, int c, float (&mean)[VEC], float (&rstd)[VEC]) {
+    if (bn.use_running) {
+        float rv[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { mean[j] = bn.run_mean[c + j]; rv[j] = bn.run_var[c + j]; }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) rstd[j] = 1.0f / sqrtf(rv[j] + bn.eps);
+    } else {
+        double s[VEC], q[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { s[j] = bn.sum[c + j]; q[j] = bn.sq[c + j]; }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const double m = s[j] * (double)bn.inv_n, v = q[j] * (double)bn.inv_n - m * m;
+            mean[j] = (float)m;
+            rstd[j] = 1.0f / sqrtf((float)(v > 0.0 ? v : 0.0) + bn.eps);
+        }
+    }
+}
+
 __device__ __forceinline__ void bn_update_running(const BNRef& bn, int c) {
     double m = bn.sum[c] * (double)bn.inv_n;
     double v = bn.sq[c] * (double)bn.inv_n - m * m;

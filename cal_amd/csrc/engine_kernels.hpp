@@ -523,15 +523,22 @@ __global__ void __launch_bounds__(256) k_bn_bwd(const BnBwdProb p0, const BnBwdP
         const bool cok = c < W;
         float mean[VEC], rstd[VEC], gs[VEC], m1[VEC], m2[VEC];
         double cs[VEC];
+        {   // per-column constants, all loads up front on a clamped column (W % VEC == 0)
+            const int cb = min(c, W - VEC);
+            double ds[VEC], dp[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            cs[j] = 0.0;
-            if (cok && c + j < W) {
-                bn_mean_rstd(p.bn, c + j, mean[j], rstd[j]);
-                gs[j] = (p.bn.gamma ? p.bn.gamma[c + j] : 1.f) * rstd[j];
-                m1[j] = (float)(p.dot_sum[c + j] * (double)p.bn.inv_n);
-                m2[j] = (float)(p.dot_prod[c + j] * (double)p.bn.inv_n);
-            } else { mean[j] = rstd[j] = gs[j] = m1[j] = m2[j] = 0.f; }
+            for (int j = 0; j < VEC; ++j) {
+                cs[j] = 0.0;
+                gs[j] = p.bn.gamma ? p.bn.gamma[cb + j] : 1.f;
+                ds[j] = p.dot_sum[cb + j]; dp[j] = p.dot_prod[cb + j];
+            }
+            bn_mean_rstd_v<VEC>(p.bn, cb, mean, rstd);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                gs[j] *= rstd[j];
+                m1[j] = (float)(ds[j] * (double)p.bn.inv_n);
+                m2[j] = (float)(dp[j] * (double)p.bn.inv_n);
+            }
         }
         // UR rows per pass with all their loads issued first: one row per iteration (load, wait, store --
         // the store may alias the next row's loads as far as hipcc knows) is one memory round trip per row
@@ -745,22 +752,29 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
     float mc[VEC], rc[VEC], gc[VEC], m1c[VEC], m2c[VEC], mo[VEC], ro[VEC], go[VEC], m1o[VEC], m2o[VEC];
     float wn[VEC], wp[VEC], wq[VEC];
     double cs_b[VEC], cs_n[VEC], cs_p[VEC], cs_q[VEC];
+    {   // per-column constants: every load issued up front on a clamped column (H % VEC == 0); per column and
+        // under `if (cok)` this prologue was ~20 dependent load groups
+        const int cb = min(c, H - VEC);
+        double d1c[VEC], d2c[VEC], d1o[VEC], d2o[VEC];
+        float w0[VEC], w1[VEC], w2[VEC], w3[VEC], w4[VEC], w5[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        cs_b[j] = cs_n[j] = cs_p[j] = cs_q[j] = 0.0;
-        if (cok && c + j < H) {
-            bn_mean_rstd(a.bnc, c + j, mc[j], rc[j]);
-            bn_mean_rstd(a.bno, c + j, mo[j], ro[j]);
-            gc[j] = (a.bnc.gamma ? a.bnc.gamma[c + j] : 1.f) * rc[j];
-            go[j] = (a.bno.gamma ? a.bno.gamma[c + j] : 1.f) * ro[j];
-            m1c[j] = (float)(a.dsc[c + j] * (double)inv_n); m2c[j] = (float)(a.dpc[c + j] * (double)inv_n);
-            m1o[j] = (float)(a.dso[c + j] * (double)inv_n); m2o[j] = (float)(a.dpo[c + j] * (double)inv_n);
-            wn[j] = a.Wn[c + j] - a.Wn[H + c + j];
-            wp[j] = a.We[c + j] - a.We[2 * H + c + j];
-            wq[j] = a.We[H + c + j] - a.We[3 * H + c + j];
-        } else {
-            mc[j] = rc[j] = gc[j] = m1c[j] = m2c[j] = mo[j] = ro[j] = go[j] = m1o[j] = m2o[j] = 0.f;
-            wn[j] = wp[j] = wq[j] = 0.f;
+        for (int j = 0; j < VEC; ++j) {
+            cs_b[j] = cs_n[j] = cs_p[j] = cs_q[j] = 0.0;
+            gc[j] = a.bnc.gamma ? a.bnc.gamma[cb + j] : 1.f;
+            go[j] = a.bno.gamma ? a.bno.gamma[cb + j] : 1.f;
+            d1c[j] = a.dsc[cb + j]; d2c[j] = a.dpc[cb + j]; d1o[j] = a.dso[cb + j]; d2o[j] = a.dpo[cb + j];
+            w0[j] = a.Wn[cb + j]; w1[j] = a.Wn[H + cb + j];
+            w2[j] = a.We[cb + j]; w3[j] = a.We[2 * H + cb + j]; w4[j] = a.We[H + cb + j]; w5[j] = a.We[3 * H + cb + j];
+        }
+        bn_mean_rstd_v<VEC>(a.bnc, cb, mc, rc);
+        bn_mean_rstd_v<VEC>(a.bno, cb, mo, ro);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const bool on = cok && c + j < H;
+            gc[j] = on ? gc[j] * rc[j] : 0.f; go[j] = on ? go[j] * ro[j] : 0.f;
+            m1c[j] = (float)(d1c[j] * (double)inv_n); m2c[j] = (float)(d2c[j] * (double)inv_n);
+            m1o[j] = (float)(d1o[j] * (double)inv_n); m2o[j] = (float)(d2o[j] * (double)inv_n);
+            wn[j] = on ? w0[j] - w1[j] : 0.f; wp[j] = on ? w2[j] - w3[j] : 0.f; wq[j] = on ? w4[j] - w5[j] : 0.f;
         }
     }
     // UR rows per pass, each dependent round of loads (row data + CSR extents -> edge ids -> edge
