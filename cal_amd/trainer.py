@@ -156,9 +156,10 @@ class CausalTrainer:
             self.engine.reserve(n, e, g)
 
     def _fwd_bwd(self, batch, perm, stats):
+        """One forward + backward (+ fused Adam); returns the device stats tensor.  On the engine path that is a
+        view of the engine's own stats buffer (no copy node in the graph): it holds the LATEST step's values."""
         if self.engine is not None:
-            stats.copy_(self.engine.train_step(batch, perm, adam=self.fused_opt))
-            return
+            return self.engine.train_step(batch, perm, adam=self.fused_opt)
         self.flat_g.zero_()
         if self.rebuild_plan:
             batch._plan = None
@@ -168,6 +169,7 @@ class CausalTrainer:
         with torch.no_grad():
             correct = o.max(1)[1].eq(batch.y.view(-1)).sum().to(torch.float32)
             stats.copy_(torch.stack([loss.detach(), lc.detach(), lo.detach(), lco.detach(), correct]))
+        return stats
 
     def _allreduce(self):
         if self.world_size > 1:
@@ -222,7 +224,7 @@ class CausalTrainer:
         with torch.cuda.graph(g, pool=self._pool):
             if draws:
                 self._device_perm_into(cap.perm, nb)
-            self._fwd_bwd(batch, cap.perm, cap.stats)
+            cap.stats = self._fwd_bwd(batch, cap.perm, cap.stats)
         self._restore(snap)
         cap.graphs[dev_perm] = g
         return cap
@@ -324,8 +326,7 @@ class CausalTrainer:
                     self._device_perm_into(dperm, nb)
                 else:
                     self._upload_perm(perm, dperm)
-            self._fwd_bwd(batch, dperm, self.stats)
-            stats = self.stats
+            stats = self._fwd_bwd(batch, dperm, self.stats)
         self._allreduce()
         self._opt_step()
         return stats
