@@ -61,6 +61,25 @@ __device__ __forceinline__ void block_col_atomic(double v, int cslot, int rlane,
     __syncthreads();
 }
 
+// NV column sums at once (two barriers in total instead of two per sum): out[q] is valid on the lanes
+// with rlane == 0 && valid.  lds: at least NV * nrl * ncols doubles.
+template <int NV>
+__device__ __forceinline__ void block_col_sums(const double (&v)[NV], int cslot, int rlane, int nrl, int ncols, bool valid,
+                                               double* lds, double (&out)[NV]) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) lds[(q * nrl + rlane) * ncols + cslot] = valid ? v[q] : 0.0;
+    __syncthreads();
+    if (rlane == 0 && valid) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            double t = 0.0;
+            for (int k = 0; k < nrl; ++k) t += lds[(q * nrl + k) * ncols + cslot];
+            out[q] = t;
+        }
+    }
+    __syncthreads();
+}
+
 // Sum the rows of partial buffers into their final destination.  grid (ceil(n/8), ntasks): a block
 // owns 8 columns, 32 lanes walk the P rows of each.  The row loop keeps 8 loads in flight per lane
 // (unconditional, clamped, pinned): as a plain dependent loop over P = 458 rows this kernel took
@@ -229,11 +248,62 @@ __global__ void __launch_bounds__(256) k_node_att_fwd(const float* __restrict__ 
                                                       float* __restrict__ anode, float* __restrict__ pq,
                                                       const Acc stc_sum, const Acc stc_sq, const Acc sto_sum,
                                                       const Acc sto_sq, int N, int H, int rows_per_block) {
-    __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
+    __shared__ double lds[4 * 256 * (VEC == 4 ? 4 : 1)];
     constexpr int RPB = 256 / G;
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
     using V = Vec<VEC>;
+    // Fast path (one column chunk per lane, at most 4 rows per lane group): the group's rows and the six
+    // weight vectors are loaded once, all up front, and stay in registers for both passes -- the generic
+    // code below reloads the weights per row and reads anode / x back from memory for the statistics.
+    if (H <= G * VEC && rows_per_block <= 4 * RPB) {
+        const int c = l * VEC, cc = min(c, H - VEC);
+        const bool cok = c < H;
+        V w[6], xv[4];
+        w[0] = V::ld(Wn + cc); w[1] = V::ld(Wn + H + cc); w[2] = V::ld(We + cc);
+        w[3] = V::ld(We + 2 * H + cc); w[4] = V::ld(We + H + cc); w[5] = V::ld(We + 3 * H + cc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = V::ld(x + (size_t)max(min(rbeg + grp + u * RPB, rend - 1), 0) * H + cc);
+        const float b0 = bn[0], b1 = bn[1];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) w[u].pin();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xv[u].pin(); if (!cok) xv[u] = V::zero(); }
+        double sc1[VEC], sc2[VEC], so1[VEC], so2[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { sc1[j] = sc2[j] = so1[j] = so2[j] = 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int v = rbeg + grp + u * RPB;
+            const float l0 = group_sum<G>(xv[u].dot(w[0])) + b0, l1 = group_sum<G>(xv[u].dot(w[1])) + b1;
+            const float p0 = group_sum<G>(xv[u].dot(w[2])), p1 = group_sum<G>(xv[u].dot(w[3]));
+            const float q0 = group_sum<G>(xv[u].dot(w[4])), q1 = group_sum<G>(xv[u].dot(w[5]));
+            const float m = fmaxf(l0, l1);
+            const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+            const float inv = 1.f / (e0 + e1), a0 = e0 * inv, a1 = e1 * inv;
+            if (v < rend) {
+                if (l == 0) {
+                    anode[2 * (size_t)v] = a0;
+                    anode[2 * (size_t)v + 1] = a1;
+                    *reinterpret_cast<float4*>(pq + 4 * (size_t)v) = make_float4(p0, p1, q0, q1);
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const double xc = (double)(a0 * xv[u].get(j)), xo = (double)(a1 * xv[u].get(j));
+                    sc1[j] += xc; sc2[j] += xc * xc; so1[j] += xo; so2[j] += xo * xo;
+                }
+            }
+        }
+        // the 4 VEC column sums of this lane through LDS in one go (G lanes x VEC columns = one slot per column)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const double v4[4] = {sc1[j], sc2[j], so1[j], so2[j]};
+            double o4[4];
+            block_col_sums<4>(v4, l * VEC + j, grp, RPB, G * VEC, cok, lds, o4);
+            if (grp == 0 && cok) { stc_sum.add(c + j, o4[0]); stc_sq.add(c + j, o4[1]); sto_sum.add(c + j, o4[2]); sto_sq.add(c + j, o4[3]); }
+        }
+        return;
+    }
     // pass 1: logits / projections per row (full-row dot products)
     for (int v = rbeg + grp; v < rend; v += RPB) {
         float l0 = 0.f, l1 = 0.f, p0 = 0.f, p1 = 0.f, q0 = 0.f, q1 = 0.f;
@@ -738,7 +808,7 @@ struct AttBwdArgs {
 
 template <int VEC, int G>
 __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, int N, int H, int rows_per_block) {
-    __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
+    __shared__ double lds[4 * 256 * (VEC == 4 ? 4 : 1)];
     __shared__ double sc_lds[2][256 / G];
     constexpr int RPB = 256 / G;
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
@@ -855,10 +925,14 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-        if (a.dbias.on()) block_col_atomic(cs_b[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dbias, c + j, lds);
-        block_col_atomic(cs_n[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dWn, c + j, lds);
-        block_col_atomic(cs_p[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dWe, c + j, lds);
-        block_col_atomic(cs_q[j], l * VEC + j, grp, RPB, G * VEC, cok && c + j < H, a.dWe, H + c + j, lds);
+        const bool on = cok && c + j < H;
+        const double v4[4] = {cs_b[j], cs_n[j], cs_p[j], cs_q[j]};
+        double o4[4];
+        block_col_sums<4>(v4, l * VEC + j, grp, RPB, G * VEC, on, lds, o4);
+        if (grp == 0 && on) {
+            if (a.dbias.on()) a.dbias.add(c + j, o4[0]);
+            a.dWn.add(c + j, o4[1]); a.dWe.add(c + j, o4[2]); a.dWe.add(H + c + j, o4[3]);
+        }
     }
     if (l == 0) { sc_lds[0][grp] = sdl; sc_lds[1][grp] = ssp; }
     __syncthreads();
