@@ -22,6 +22,7 @@
 #include "engine_kernels.hpp"
 #include "engine_readout.hpp"
 #include "engine_gconv.hpp"
+#include "engine_gconv_bwd.hpp"
 
 namespace cal {
 
@@ -36,39 +37,54 @@ struct FinishArgs {
     float* stats;            // fused readout: stats[0] = wc*stats[1] + wo*stats[2] + wco*stats[3]
     float wc, wo, wco;
     float* tick;             // Adam step counter to advance (the update follows in the same step) or null
+    int blk0[MAX_SLABS + MAX_COMMITS + 1];   // first block of every task in the flattened 1-D grid (filled at launch)
 };
+// grid: 1-D, task t owns blocks [blk0[t], blk0[t+1]): n/64 per slab task, ceil(n/16) per commit task (a
+// (64, tasks) grid spent most of its ~12k blocks on nothing once the slab tasks wanted 256 blocks each)
 __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __restrict__ grad) {
-    const int task = blockIdx.y;
-    if (fa.stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    int task = 0;
+    const int ntask = fa.nst + fa.nct;
+    while (task + 1 < ntask && (int)blockIdx.x >= fa.blk0[task + 1]) ++task;
+    const int bx = blockIdx.x - fa.blk0[task], nbx = fa.blk0[task + 1] - fa.blk0[task];
+    if (fa.stats && blockIdx.x == 0 && threadIdx.x == 0)
         fa.stats[0] = fa.wc * fa.stats[1] + fa.wo * fa.stats[2] + fa.wco * fa.stats[3];
-    if (fa.tick && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) fa.tick[0] += 1.f;
+    if (fa.tick && blockIdx.x == 0 && threadIdx.x == 0) fa.tick[0] += 1.f;
     // Both task kinds are pure reductions over S slabs / P partial rows: the loops keep 8 loads in flight
     // per lane (unconditional on a clamped index, pinned, masked when added) -- as dependent loops with
     // two loads in flight the 58-slab weight-gradient sums made this kernel 11 us.
     if (task < fa.nst) {
+        // 64 elements per block pass, the S slabs split over the block's 4 waves (S = #graphs = 128 with the
+        // per-graph fused backward): 4x shorter load chains, combined through LDS in a fixed order
         const SlabTask t = fa.st[task];
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < t.n; i += gridDim.x * 256) {
+        __shared__ float sred[256];
+        const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+        const int per = (t.S + 3) / 4, z_lo = grp * per, z_hi = min(t.S, z_lo + per);
+        for (int i0 = bx * 64; i0 < t.n; i0 += nbx * 64) {
+            const int i = min(i0 + el, t.n - 1);
             float s0 = 0.f, s1 = 0.f;
-            for (int z0 = 0; z0 < t.S; z0 += 8) {
+            for (int z0 = z_lo; z0 < z_hi; z0 += 8) {
                 float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = t.slabs[(size_t)max(min(z0 + u, t.S - 1), 0) * t.n + i];
+                for (int u = 0; u < 8; ++u) v[u] = t.slabs[(size_t)max(min(z0 + u, z_hi - 1), 0) * t.n + i];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
 #pragma unroll
                 for (int u = 0; u < 8; u += 2) {
-                    s0 += z0 + u < t.S ? v[u] : 0.f;
-                    s1 += z0 + u + 1 < t.S ? v[u + 1] : 0.f;
+                    s0 += z0 + u < z_hi ? v[u] : 0.f;
+                    s1 += z0 + u + 1 < z_hi ? v[u + 1] : 0.f;
                 }
             }
-            t.dst[i] = s0 + s1;
+            sred[threadIdx.x] = s0 + s1;
+            __syncthreads();
+            if (grp == 0 && i0 + el < t.n) t.dst[i] = (sred[el] + sred[64 + el]) + (sred[128 + el] + sred[192 + el]);
+            __syncthreads();
         }
     } else if (task - fa.nst < fa.nct) {
         const CommitTask t = fa.ct[task - fa.nst];
         // 16 part-lanes x 16 columns per block pass
         __shared__ double red[256];
         const int pl = threadIdx.x >> 4, cl = threadIdx.x & 15;
-        for (int c0 = blockIdx.x * 16; c0 < t.n; c0 += gridDim.x * 16) {
+        for (int c0 = bx * 16; c0 < t.n; c0 += nbx * 16) {
             const int c = c0 + cl, cc = min(c, t.n - 1);
             double sacc = 0.0;
             for (int q0 = pl; q0 < t.P; q0 += 16 * 8) {
@@ -125,6 +141,7 @@ struct Engine {
     // side stream for the weight-gradient GEMMs (off the critical path until the final commit)
     hipStream_t side; hipEvent_t ev_fork[24], ev_join[24];
     int *rowptr_dst, *nbr_dst, *eid_dst, *rowptr_src, *nbr_src, *eid_src, *row32, *col32, *work, *status, *gptr, *iperm, *eptr;
+    float* coef;                // [3][E] edge coefficients dis_j * w_e in CSR-by-destination slot order: unit, context, objects
     int max_nodes, max_edges;   // per-graph bounds of the coming batches (0 = unknown): cal_engine_set_graph_bounds
 };
 
@@ -243,7 +260,8 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     F32(e->dzco, 2 * N * H); F32(e->dXhco, 2 * N * H); F32(e->dZ, N * H); F32(e->dzi, (L > 0 ? L : 1) * N * H); F32(e->dXh, N * H);
     // split-K slabs: worst case per weight gradient (S <= 256, but S*tiles ~ 512 => S*M*N <= ~512*64*64 + M*N)
     size_t slab = 0;
-    auto slab_of = [&](size_t M, size_t Nn) { return (size_t)(512 * 64 * 64 + 2 * M * Nn); };
+    // (per-graph fused backward: one [M,N] slab per graph)
+    auto slab_of = [&](size_t M, size_t Nn) { return std::max<size_t>(512 * 64 * 64, (size_t)B * M * Nn) + 2 * M * Nn; };
     slab += slab_of(F, H) + (L + 2) * slab_of(H, H) + 3 * slab_of(H, H) + 3 * slab_of(C, H);
     if (assign) e->slab_floats = slab;
     F32(e->slabs, slab);
@@ -263,6 +281,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     I32(e->row32, E); I32(e->col32, E); I32(e->work, 4 * (N + 1) + 4 * E); I32(e->status, 4); I32(e->gptr, B + 1);
     I32(e->iperm, B);
     I32(e->eptr, B + 1);
+    F32(e->coef, 3 * E);
     return off * 4;
 }
 
@@ -481,12 +500,39 @@ bool use_gc(const Ctx& c) {
     return e->max_nodes > 0 && e->max_nodes <= GC_T && e->max_edges <= GC_E && e->H % GC_N == 0 && e->H <= GC_K && c.B > 0;
 }
 bool gc_small(const Ctx& c) { return c.e->max_nodes <= 64 && c.e->max_edges <= gc_edge_cap(64); }
+// per-graph fused backward (engine_gconv_bwd.hpp): 64-node graphs only
+bool use_gcb(const Ctx& c) { return use_gc(c) && gc_small(c) && c.B <= 128 * 4; }
 // partial-row statistics of a per-graph kernel: one row per graph
 Acc graph_acc(Ctx& c, double* dst, int cols) {
     double* p = parts_alloc(c, (size_t)c.B * cols);
     if (!p) return Acc(dst);
     final_task(c, p, c.B, cols, cols, dst);
     return Acc(dst, p, cols);
+}
+
+// Launch the per-graph fused backward for nb branches: slabs (one per graph) and the BatchNorm-backward partial
+// rows are registered like those of the GEMM path.  gb[k].dot_parts / .slab are filled in here.
+int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, double** dsum, double** dprod,
+              FinishArgs& fa, size_t& slab_off, bool rs) {
+    Engine* e = c.e;
+    const int H = e->H, B = c.B, nsl = H / GC_N;
+    for (int k = 0; k < nb; ++k) {
+        const size_t need = (size_t)B * H * H;
+        if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
+        gb[k].slab = e->slabs + slab_off;
+        fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, dst[k], H * H, B};
+        slab_off += need;
+        double* p = parts_alloc(c, (size_t)B * nsl * 2 * H);
+        if (!p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+        gb[k].dot_parts = p;
+        final_task(c, p, B * nsl, 2 * H, H, dsum[k]);
+        final_task(c, p + H, B * nsl, 2 * H, H, dprod[k]);
+    }
+    const dim3 grid(B, nsl, nb);
+    if (rs) hipLaunchKernelGGL((k_gconv_bwd<true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    else hipLaunchKernelGGL((k_gconv_bwd<false>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    CAL_CHECK_LAUNCH("k_gconv_bwd");
+    return 0;
 }
 
 bool use_ro(const Ctx& c) {
@@ -592,6 +638,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             memset(&gb, 0, sizeof(gb));
             gb.x = e->h + (size_t)(i - 1) * NH; gb.W = e->P + e->o_conv_w[i - 1]; gb.bias = e->P + e->o_conv_b[i - 1];
             gb.dis = e->dis_unit; gb.bn = bnref(c, i, N, 1); gb.out = e->h + (size_t)i * NH;
+            if (i == 1) gb.coef_out = e->coef; else gb.coef_in = e->coef;
             if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H); }
             {
                 ProfScope ps(st, 2, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H);
@@ -650,6 +697,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             gb[k].ew = e->att + (size_t)k * E; gb[k].dis = e->dis_co + (size_t)k * N;
             gb[k].rs = e->anode + k; gb[k].rs_stride = 2; gb[k].bn = bnref(c, L + 1 + k, N, 1);
             gb[k].out = e->hco + (size_t)k * NH; gb[k].z = e->zco + (size_t)k * NH; gb[k].pooled = e->pooled + (size_t)k * B * H;
+            gb[k].coef_out = e->coef + (size_t)(1 + k) * E;
         }
         if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<true, 64>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, gb[0], gb[1], 1,
                                             e->loop_w, H, H, e->status);
@@ -864,8 +912,9 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                            e->dl, N, E);
         CAL_CHECK_LAUNCH("k_normbwd_edge"); STAGE();
     }
+    const bool gcb = use_gcb(c);
     // P5. dz_k = A_hat_k^T dZ_k
-    {
+    if (!gcb) {
         SpmmBranch b0{e->dZco, e->dzco, nullptr, e->att, e->dis_co, Acc(), Acc()};
         SpmmBranch b1{e->dZco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, Acc(), Acc()};
         RC(with_g(H, [&](auto g) {
@@ -876,8 +925,24 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         CAL_CHECK_LAUNCH("k_espmm(co,T)"); STAGE();
     }
     const float* x = e->h + (size_t)L * NH;
+    // P5-P7 fused per graph: dz_k stays in LDS; dX'_k arrives as one partial per output-column slice
+    if (gcb) {
+        GconvBwdBranch gb[2];
+        memset(gb, 0, sizeof(gb));
+        float* dst[2]; double* dsum[2]; double* dprod[2];
+        for (int k = 0; k < 2; ++k) {
+            gb[k].dout = e->dZco + (size_t)k * NH; gb[k].x = x; gb[k].W = e->P + (k ? e->o_ow : e->o_cw);
+            gb[k].ew = e->att + (size_t)k * E; gb[k].dis = e->dis_co + (size_t)k * N;
+            gb[k].rs = e->anode + k; gb[k].rs_stride = 2; gb[k].bn = bnref(c, L + 1 + k, N, 0);
+            gb[k].dxp0 = e->dXhco + (size_t)k * NH; gb[k].dxp1 = e->dzco + (size_t)k * NH;
+            gb[k].coef_in = e->coef + (size_t)(1 + k) * E;
+            dst[k] = e->G + (k ? e->o_ow : e->o_cw); dsum[k] = bn_dsum(c, L + 1 + k); dprod[k] = bn_dprod(c, L + 1 + k);
+        }
+        RC(gconv_bwd(c, gd, gb, 2, dst, dsum, dprod, fa, slab_off, true)); STAGE();
+        RC(flush_finals(c)); STAGE();
+    }
     // P6. dW_k = BN_k(a_k x)^T @ dz_k
-    {
+    if (!gcb) {
         GemmArgs a = gemm_args(H, H, N, true, false, 0);
         float* dst[2];
         for (int k = 0; k < 2; ++k) {
@@ -902,6 +967,8 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     {
         AttBwdArgs aa;
         aa.x = x; aa.anode = e->anode; aa.dxhc = e->dXhco; aa.dxho = e->dXhco + NH;
+        const bool two = gcb && H > GC_N;               // second output-column slice of the fused backward
+        aa.dxhc2 = two ? e->dzco : nullptr; aa.dxho2 = two ? e->dzco + NH : nullptr;
         aa.bnc = bnref(c, L + 1, N, 0); aa.bno = bnref(c, L + 2, N, 0);
         aa.dsc = bn_dsum(c, L + 1); aa.dpc = bn_dprod(c, L + 1); aa.dso = bn_dsum(c, L + 2); aa.dpo = bn_dprod(c, L + 2);
         aa.Wn = e->P + e->o_natt_w; aa.We = e->P + e->o_eatt_w; aa.dl = e->dl;
@@ -919,6 +986,27 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     // Q. backbone layers, last to first
     for (int i = L; i >= 1; --i) {
         float* dzi = e->dzi + (size_t)(i - 1) * NH;     // per layer: the side-stream dW GEMM reads it later
+        if (gcb) {
+            const float* hin = e->h + (size_t)(i - 1) * NH;
+            GconvBwdBranch gb;
+            memset(&gb, 0, sizeof(gb));
+            gb.dout = e->dZ; gb.x = hin; gb.W = e->P + e->o_conv_w[i - 1]; gb.dis = e->dis_unit; gb.bn = bnref(c, i, N, 0);
+            gb.dxp0 = e->dXh; gb.dxp1 = dzi;
+            gb.coef_in = e->coef;               // written by the forward's first fused layer
+            float* dst[1] = {e->G + e->o_conv_w[i - 1]};
+            double* dsum[1] = {bn_dsum(c, i)}; double* dprod[1] = {bn_dprod(c, i)};
+            { ProfScope ps(st, 3, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false)); } STAGE();
+            RC(flush_finals(c)); STAGE();
+            BnBwdProb p{e->dXh, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i),
+                        i >= 2 ? deferred(H, d_convb[i - 2]) : Acc(), H > GC_N ? dzi : nullptr};
+            RC(with_g(H, [&](auto g) {
+                constexpr int G = decltype(g)::value;
+                hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
+                return 0;
+            }));
+            CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();
+            continue;
+        }
         SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
         {
             ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0);
@@ -1006,7 +1094,13 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     }
     if (fa.nct > MAX_COMMITS) { set_error("engine: too many commit tasks"); return 2; }
     join_side(c);
-    hipLaunchKernelGGL(k_finish, dim3(64, fa.nst + fa.nct), dim3(256), 0, st, fa, e->G);
+    {
+        int nblk = 0;
+        for (int i = 0; i < fa.nst; ++i) { fa.blk0[i] = nblk; nblk += std::max(1, cdiv(fa.st[i].n, 64)); }
+        for (int i = 0; i < fa.nct; ++i) { fa.blk0[fa.nst + i] = nblk; nblk += std::max(1, cdiv(fa.ct[i].n, 16)); }
+        fa.blk0[fa.nst + fa.nct] = nblk;
+        hipLaunchKernelGGL(k_finish, dim3(nblk), dim3(256), 0, st, fa, e->G);
+    }
     CAL_CHECK_LAUNCH("k_finish"); STAGE();
     return 0;
 }

@@ -46,6 +46,11 @@ struct GconvBranch {
     float* z;                // [N,H] BN(rs x) W, kept for the backward of the weighted convs, or null
     float* pooled;           // [B,H] per-graph column sums of out (global_add_pool), or null
     Acc st_sum, st_sq;       // column statistics of out (one partial row per graph), or off
+    // edge coefficients dis_j * w_e in CSR-slot order: the first kernel of a step that needs them writes them
+    // (coef_out), every later one (deeper layers, the backward) reads them in its first round of loads (coef_in)
+    // instead of chasing nbr -> dis / eid -> w in a second one
+    const float* coef_in;
+    float* coef_out;
 };
 
 typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
@@ -175,6 +180,9 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
         bn_scale_shift(br.bn, t, sc_s[t], sh_s[t]);
         if (br.bn.update && blockIdx.x == 0 && blockIdx.y == 0) bn_update_running(br.bn, t);
     }
+    float cin[8];                                        // coefficients of an earlier kernel of this step, if any
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cin[u] = br.coef_in ? br.coef_in[e0 + max(min(t + u * 256, ne - 1), 0)] : 0.f;
     // all of the above stay in flight together: without the pins hipcc pairs every W load with its LDS store
     // ("load, s_waitcnt vmcnt(0), ds_write" x 8: eight serial round trips, 5-30 us under 256-way contention)
 #pragma unroll
@@ -183,11 +191,16 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     for (int u = 0; u < 8; ++u) ro_pin(vb[u]);
     // second round: edge coefficients dis_j * w_e (needs the neighbour / edge ids)
     float cv[8];
+    if (br.coef_in) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        float c = br.dis[nv[u]];
-        if (hasw) c *= br.ew[ev[u]];
-        cv[u] = c;
+        for (int u = 0; u < 8; ++u) cv[u] = cin[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float c = br.dis[nv[u]];
+            if (hasw) c *= br.ew[ev[u]];
+            cv[u] = c;
+        }
     }
     RO_CLK(33);
     // ---- stage everything in LDS ---------------------------------------------------------------------------
@@ -200,6 +213,7 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
             const int loc = nv[u] - g0;
             const bool inb = loc >= 0 && loc < rows;        // an edge that leaves its graph is not a mini-batch: flag it
             en[s] = inb ? loc : 0; ec[s] = inb ? cv[u] : 0.f;
+            if (br.coef_out && blockIdx.y == 0) br.coef_out[e0 + s] = cv[u];
             if (!inb) atomicOr(status, 16);
         }
     }

@@ -1,0 +1,260 @@
+// Per-graph fused backward of a GCN convolution of the step engine (the transpose of engine_gconv.hpp):
+// with dOut = gradient w.r.t. the convolution's pre-activation output, x' = BN(rs * x) its (normalised)
+// input and z = x' W,
+//     dz  = A_hat^T dOut                       (gcn_conv.py:92-104 backward)
+//     dX' = dz W^T  (+ the two BatchNorm-backward column sums  sum dX',  sum dX' * x_hat)
+//     dW  = x'^T dz
+// as ONE kernel instead of transposed aggregation -> dX GEMM + dW GEMM.  A workgroup owns one graph and a
+// 64-column slice `ns` of the OUTPUT features: it aggregates only its slice of dz (dense adjacency block
+// on MFMA, like the forward), multiplies it with W[:, ns]^T into a PARTIAL dX' over all K input columns
+// (the H/64 slices are summed by the consumer: k_bn_bwd / k_att_bwd read both partials) and with x'^T into
+// the columns `ns` of this graph's dW slab (the B slabs are summed by k_finish, as split-K slabs were).
+// dz never goes to HBM and neither product re-reads it.
+//
+//   grid (B graphs, H / 64 slices, branches), 512 threads; graphs of at most 64 nodes / 1024 stored edges
+//   (cal_engine_set_graph_bounds), K = H in {64, 128}.  LDS ~129 KB: one workgroup per CU, so it brings its
+//   own latency hiding: 8 waves -- waves 0-3 run the dX' product and its epilogue while waves 4-7 run the
+//   dW product (both only need dz), and twice as many loads are in flight while staging.
+#pragma once
+#include "engine_gconv.hpp"
+
+namespace cal {
+
+constexpr int GB_NT = 512;                // threads per workgroup
+constexpr int GB_T = 64;                  // nodes per graph
+constexpr int GB_E = 1024;                // stored edges per graph
+constexpr int GB_LDJ = GB_T + 1;          // k-major tiles indexed by a node: adjacency block, dz^T
+constexpr int GB_LDD = GC_N + 4;          // row-major [node][64 output columns]: dOut slice, dz
+constexpr int GB_LDW = GC_K + 1;          // W slice transposed: Wt[n][k_in]
+constexpr int GB_LDX = GC_K + 4;          // row-major [node][K]: normalised input rows
+
+struct GconvBwdBranch {
+    const float* dout;       // [N,H]
+    const float* x;          // [N,K] raw layer input
+    const float* W;          // [K,H]
+    const float* ew;         // per-edge weight in edge-id order, or null
+    const float* dis;        // [N]
+    const float* rs;         // per-row scale of x, or null
+    int rs_stride;
+    BNRef bn;                // BatchNorm applied to rs * x (batch statistics of the forward)
+    float* dxp0; float* dxp1; // [N,K] partial dX' of output-column slice 0 / 1
+    float* slab;             // [B][K,H] per-graph dW
+    double* dot_parts;       // [B * H/64][2K]: (sum dX', sum dX' * x_hat) partial rows
+    const float* coef_in;    // edge coefficients dis_j * w_e in CSR-slot order, written by the forward kernel, or null
+};
+
+// acc[0] (+acc[1]) += A B over kred (multiple of 32) with k-major LDS operands A[k*LDA + row], B[k*LDB + col];
+// NA == 2: two row tiles (a0, a1) against b0; NB == 2: a0 against two column tiles (b0, b1).
+// ax(v, kstep) transforms an A element (identity or the BatchNorm affine of the lane's row).
+template <int NA, int NB, int LDA, int LDB, class AX>
+__device__ __forceinline__ void gb_mma(const float* a0, const float* a1, const float* b0, const float* b1, int kred, int lk,
+                                       AX ax, gc_f32x16 (&acc)[2]) {
+    static_assert(NA == 1 || NB == 1, "one of the operands is shared");
+    float av[2][2][16], bv[2][2][16];
+    auto read_ops = [&](int kb, int s) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = kb * 32 + 2 * i + lk;
+            av[s][0][i] = ax(a0[k * LDA]);
+            if (NA == 2) av[s][1][i] = ax(a1[k * LDA]);
+            bv[s][0][i] = b0[k * LDB];
+            if (NB == 2) bv[s][1][i] = b1[k * LDB];
+        }
+    };
+    auto mul = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][0][i], bv[s][0][i], acc[0], 0, 0, 0);
+            if (NA == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][1][i], bv[s][0][i], acc[1], 0, 0, 0);
+            if (NB == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][0][i], bv[s][1][i], acc[1], 0, 0, 0);
+        }
+    };
+    const int nkb = kred / 32;
+    read_ops(0, 0);
+    for (int kb = 0; kb < nkb; kb += 2) {
+        if (kb + 1 < nkb) read_ops(kb + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mul(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 1 < nkb) {
+            if (kb + 2 < nkb) read_ops(kb + 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <bool RS>
+__global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
+                                                   const GconvBwdBranch b0, const GconvBwdBranch b1, float loop_w, int N, int H,
+                                                   int K, int* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) float Ab[GB_T * GB_LDJ];       // adjacency block Ab[j][i]: dz_i += Ab[j][i] dOut_j
+    __shared__ __attribute__((aligned(16))) float Ds[GB_T * GB_LDD];       // dOut slice [j][n]; later dz [i][n]
+    __shared__ __attribute__((aligned(16))) float Zt[GC_N * GB_LDJ];       // dz^T [n][i]
+    __shared__ __attribute__((aligned(16))) float Wt[GC_N * GB_LDW];       // W[:, ns]^T: Wt[n][k_in]
+    __shared__ __attribute__((aligned(16))) float Xs[GB_T * GB_LDX];       // x_hat rows [i][k_in] (normalised, no affine)
+    __shared__ float mean_s[GC_K], rstd_s[GC_K], gam_s[GC_K], bet_s[GC_K];
+    __shared__ int ptr_s[GB_T + 4];
+    __shared__ float dis_s[GB_T], rs_s[GB_T];
+    __shared__ int en[GB_E];
+    __shared__ float ec[GB_E];
+    BLK_CLK(0);
+    const GconvBwdBranch& br = blockIdx.z ? b1 : b0;
+    const int b = blockIdx.x, sl = blockIdx.y, ns0 = sl * GC_N, t = threadIdx.x;
+    const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
+    const int lane = t & 63, li = lane & 31, lk = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    double* parts = br.dot_parts + ((size_t)sl * gridDim.x + b) * (2 * K);
+    float* slab = br.slab + (size_t)b * K * H;
+    if (rows <= 0 || rows > GB_T || ne > GB_E || ne < 0) {
+        // empty graph (or a violated bound, flagged): its partial row and its slab slice must still exist
+        if (rows > 0 && t == 0) atomicOr(status, 8);
+        for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
+        for (int i = t; i < K * GC_N; i += GB_NT) slab[(size_t)(i / GC_N) * H + ns0 + i % GC_N] = 0.f;
+        return;
+    }
+    const bool hasw = br.ew != nullptr;
+    const int rowsP = (rows + 31) & ~31, R = rowsP >> 5, K4 = K >> 2;
+    // ---- every global load of the kernel, issued before the first wait ------------------------------------------
+    RoBatch<float4, 2> bd;                               // dOut[g0 + j][ns0 + 4 n4 ..]: rows x 16 float4
+    RoBatch<float4, 4> bx, bw;                           // x[g0 + i][4 k4 ..]: rows x K/4;  W[k_in][ns0 + 4 n4 ..]: K x 16
+    ro_issue<GB_NT>(bd, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(br.dout + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+    ro_issue<GB_NT>(bx, rows, K4, [&](int i, int k4) { return *reinterpret_cast<const float4*>(br.x + (size_t)(g0 + i) * K + 4 * k4); });
+    ro_issue<GB_NT>(bw, K, 16, [&](int k, int n4) { return *reinterpret_cast<const float4*>(br.W + (size_t)k * H + ns0 + 4 * n4); });
+    const int pv = g.ptr[g0 + min(t, rows)];
+    const float dv = br.dis[g0 + min(t, rows - 1)];
+    const float rv = RS ? br.rs[(size_t)(g0 + min(t, rows - 1)) * br.rs_stride] : 1.f;
+    int nv[2], ev[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int s = e0 + max(min(t + u * GB_NT, ne - 1), 0);
+        nv[u] = ne > 0 ? g.nbr[s] : g0;
+        ev[u] = (ne > 0 && hasw) ? g.eid[s] : 0;
+    }
+    float cin[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) cin[u] = br.coef_in ? br.coef_in[e0 + max(min(t + u * GB_NT, ne - 1), 0)] : 0.f;
+    if (t < K) {
+        float m1[1], r1[1];
+        bn_mean_rstd_v<1>(br.bn, t, m1, r1);
+        mean_s[t] = m1[0]; rstd_s[t] = r1[0];
+        gam_s[t] = br.bn.gamma ? br.bn.gamma[t] : 1.f;
+        bet_s[t] = br.bn.beta ? br.bn.beta[t] : 0.f;
+    }
+    for (int i = t; i < (rowsP * GB_LDJ + 3) / 4; i += GB_NT) reinterpret_cast<float4*>(Ab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cv[2];
+    if (br.coef_in) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) cv[u] = cin[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float c = br.dis[nv[u]];
+            if (hasw) c *= br.ew[ev[u]];
+            cv[u] = c;
+        }
+    }
+    // ---- stage everything in LDS -----------------------------------------------------------------------------------
+    if (t <= rows) ptr_s[t] = pv - e0;
+    if (t < rows) { dis_s[t] = dv; rs_s[t] = rv; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int s = t + u * GB_NT;
+        if (s < ne) {
+            const int loc = nv[u] - g0;
+            const bool inb = loc >= 0 && loc < rows;
+            en[s] = inb ? loc : 0; ec[s] = inb ? cv[u] : 0.f;
+            if (!inb) atomicOr(status, 16);
+        }
+    }
+    ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
+    ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) {
+        float* d = Wt + (4 * n4) * GB_LDW + k;
+        d[0] = v.x; d[GB_LDW] = v.y; d[2 * GB_LDW] = v.z; d[3 * GB_LDW] = v.w;
+    });
+    __syncthreads();                                     // per-column BN constants, row scales, zeroed Ab, CSR
+    ro_commit<GB_NT>(bx, rows, K4, [&](int i, int k4, float4 v) {
+        const float s = RS ? rs_s[i] : 1.f;
+        const int k = 4 * k4;
+        v.x = (v.x * s - mean_s[k]) * rstd_s[k]; v.y = (v.y * s - mean_s[k + 1]) * rstd_s[k + 1];
+        v.z = (v.z * s - mean_s[k + 2]) * rstd_s[k + 2]; v.w = (v.w * s - mean_s[k + 3]) * rstd_s[k + 3];
+        *reinterpret_cast<float4*>(Xs + i * GB_LDX + k) = v;
+    });
+    // rows rows .. rowsP of dOut / x_hat: zero (they are reduced over in the products below)
+    for (int i = t; i < (rowsP - rows) * GB_LDD; i += GB_NT) Ds[rows * GB_LDD + i] = 0.f;
+    for (int i = t; i < (rowsP - rows) * GB_LDX; i += GB_NT) Xs[rows * GB_LDX + i] = 0.f;
+    if (t < rows) {                                      // one lane per destination row j: its own row of the block
+        const float dj = dis_s[t];
+        for (int s = ptr_s[t]; s < ptr_s[t + 1]; ++s) Ab[t * GB_LDJ + en[s]] += dj * ec[s];
+        Ab[t * GB_LDJ + t] += dj * dj * loop_w;
+    }
+    __syncthreads();
+    BLK_CLK(2);
+    auto ident = [](float v) { return v; };
+    gc_f32x16 acc[2];
+    // ---- P1: dz[:, ns] = Ab^T dOut[:, ns]   (rows i x 64 columns, reduction over the graph's rowsP nodes) ------------
+    {
+        const int rt = w >> 1, ct = w & 1;              // waves 0-3: one tile each; waves 4-7 wait at the barriers
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+        if (rt < R) gb_mma<1, 1, GB_LDJ, GB_LDD>(Ab + rt * 32 + li, nullptr, Ds + ct * 32 + li, nullptr, rowsP, lk, ident, acc);
+        __syncthreads();                                 // every wave is done reading dOut
+        if (rt < R) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                Zt[(ct * 32 + li) * GB_LDJ + row] = acc[0][r];
+                Ds[row * GB_LDD + ct * 32 + li] = acc[0][r];           // dz row-major over the dOut stage
+            }
+        }
+        __syncthreads();
+    }
+    // ---- P2: partial dX'[:, :] = dz[:, ns] W[:, ns]^T   (rows i x K columns, reduction over the 64 columns of ns) ------
+    if (w < 4 && w * 32 < K) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+        if (R == 2) gb_mma<2, 1, GB_LDJ, GB_LDW>(Zt + li, Zt + 32 + li, Wt + w * 32 + li, nullptr, GC_N, lk, ident, acc);
+        else gb_mma<1, 1, GB_LDJ, GB_LDW>(Zt + li, nullptr, Wt + w * 32 + li, nullptr, GC_N, lk, ident, acc);
+        const int k = w * 32 + li;
+        float* dxp = sl ? br.dxp1 : br.dxp0;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q < R) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (i < rows) {
+                        const float v = acc[q][r];
+                        dxp[(size_t)(g0 + i) * K + k] = v;
+                        s1 += (double)v; s2 += (double)v * (double)Xs[i * GB_LDX + k];
+                    }
+                }
+            }
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lk == 0) { parts[k] = s1; parts[K + k] = s2; }
+    }
+    BLK_CLK(3);
+    // ---- P3: dW[:, ns] (this graph) = x'^T dz[:, ns]   (K rows x 64 columns, reduction over the graph's nodes) ---------
+    if (w >= 4 && (w - 4) * 32 < K) {
+        const int wq = w - 4, k = wq * 32 + li;
+        const float gam = gam_s[k], bet = bet_s[k];
+        auto affine = [&](float v) { return fmaf(v, gam, bet); };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+        gb_mma<1, 2, GB_LDX, GB_LDD>(Xs + wq * 32 + li, nullptr, Ds + li, Ds + 32 + li, rowsP, lk, affine, acc);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                slab[(size_t)kk * H + ns0 + q * 32 + li] = acc[q][r];
+            }
+    }
+    BLK_CLK(1);
+}
+
+}  // namespace cal

@@ -578,6 +578,7 @@ struct BnBwdProb {
     const double* dot_sum;
     const double* dot_prod;
     Acc colsum;          // column sums of dy (bias gradient of the producing layer) or off
+    const float* dyh2;   // second partial of dyh (per-graph fused backward: one per output-column slice) or null
 };
 
 template <int VEC, int G>
@@ -615,14 +616,15 @@ __global__ void __launch_bounds__(256) k_bn_bwd(const BnBwdProb p0, const BnBwdP
         constexpr int UR = 4;
         const int cc = min(c, W - VEC);
         for (int r0 = rbeg + grp; r0 < rend; r0 += RPB * UR) {
-            V d[UR], xv[UR];
+            V d[UR], xv[UR], d2[UR];
 #pragma unroll
             for (int u = 0; u < UR; ++u) {
                 const size_t r = (size_t)min(r0 + u * RPB, rend - 1);
                 d[u] = V::ld(p.dyh + r * W + cc); xv[u] = V::ld(p.x + r * W + cc);
+                d2[u] = p.dyh2 ? V::ld(p.dyh2 + r * W + cc) : V::zero();
             }
 #pragma unroll
-            for (int u = 0; u < UR; ++u) { d[u].pin(); xv[u].pin(); }
+            for (int u = 0; u < UR; ++u) { d[u].pin(); xv[u].pin(); d2[u].pin(); d[u].add(d2[u]); }
 #pragma unroll
             for (int u = 0; u < UR; ++u) {
                 const int r = r0 + u * RPB;
@@ -804,6 +806,7 @@ struct AttBwdArgs {
     Acc dbias;         // [H] bias gradient of the last backbone conv (off when there is none)
     Acc dWn;           // [H] (+1: d bn0 at [H])
     Acc dWe;           // [2H] (+1: d be0 at [2H])
+    const float* dxhc2; const float* dxho2;   // second partials of dxhc / dxho (per-graph fused backward) or null
 };
 
 template <int VEC, int G>
@@ -853,18 +856,21 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
     const int cc = min(c, H - VEC);
     for (int v0 = rbeg + grp; v0 < rend; v0 += RPB * UR) {
         float a0[UR], a1[UR];
-        V x4[UR], hc4[UR], ho4[UR];
+        V x4[UR], hc4[UR], ho4[UR], hc2[UR], ho2[UR];
         int ps0[UR], ps1[UR], pd0[UR], pd1[UR];
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
             const size_t v = (size_t)min(v0 + u * RPB, rend - 1);
             a0[u] = a.anode[2 * v]; a1[u] = a.anode[2 * v + 1];
             x4[u] = V::ld(a.x + v * H + cc); hc4[u] = V::ld(a.dxhc + v * H + cc); ho4[u] = V::ld(a.dxho + v * H + cc);
+            hc2[u] = a.dxhc2 ? V::ld(a.dxhc2 + v * H + cc) : V::zero();
+            ho2[u] = a.dxho2 ? V::ld(a.dxho2 + v * H + cc) : V::zero();
             ps0[u] = a.gs.ptr[v]; ps1[u] = a.gs.ptr[v + 1]; pd0[u] = a.gd.ptr[v]; pd1[u] = a.gd.ptr[v + 1];
         }
 #pragma unroll
         for (int u = 0; u < UR; ++u) {
-            x4[u].pin(); hc4[u].pin(); ho4[u].pin();
+            x4[u].pin(); hc4[u].pin(); ho4[u].pin(); hc2[u].pin(); ho2[u].pin();
+            hc4[u].add(hc2[u]); ho4[u].add(ho2[u]);
             asm volatile("" : "+v"(a0[u]), "+v"(a1[u]), "+v"(ps0[u]), "+v"(ps1[u]), "+v"(pd0[u]), "+v"(pd1[u]));
         }
         int es[UR], ed[UR];

@@ -90,27 +90,27 @@ __device__ __forceinline__ void ro_pin(float4& v) { asm volatile("" : "+v"(v.x),
 // ro_issue starts the loads (unconditional, out-of-range lanes re-read item (0,0)); ro_commit pins
 // the values and hands the in-range ones to `st`.
 template <class T, int U> struct RoBatch { T v[U]; };
-template <class T, int U, class LoadF>
-__device__ __forceinline__ void ro_issue(RoBatch<T, U>& bt, int rows, int cols, LoadF ld) {
-    const int total = rows * cols, q = 256 / cols, r = 256 % cols;
+template <int NT = 256, class T, int U, class LoadF>
+__device__ __forceinline__ void ro_issue(RoBatch<T, U>& bt, int rows, int cols, LoadF ld) {      // NT = threads per workgroup
+    const int total = rows * cols, q = NT / cols, r = NT % cols;
     int row = (int)threadIdx.x / cols, col = (int)threadIdx.x % cols;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const bool ok = (int)threadIdx.x + u * 256 < total;
+        const bool ok = (int)threadIdx.x + u * NT < total;
         bt.v[u] = ld(ok ? row : 0, ok ? col : 0);
         row += q; col += r;
         if (col >= cols) { col -= cols; ++row; }
     }
 }
-template <class T, int U, class StoreF>
+template <int NT = 256, class T, int U, class StoreF>
 __device__ __forceinline__ void ro_commit(RoBatch<T, U>& bt, int rows, int cols, StoreF st) {
-    const int total = rows * cols, q = 256 / cols, r = 256 % cols;
+    const int total = rows * cols, q = NT / cols, r = NT % cols;
     int row = (int)threadIdx.x / cols, col = (int)threadIdx.x % cols;
 #pragma unroll
     for (int u = 0; u < U; ++u) ro_pin(bt.v[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        if ((int)threadIdx.x + u * 256 < total) st(row, col, bt.v[u]);
+        if ((int)threadIdx.x + u * NT < total) st(row, col, bt.v[u]);
         row += q; col += r;
         if (col >= cols) { col -= cols; ++row; }
     }
