@@ -181,7 +181,7 @@ def engine_roofline(trainer, batches, iters=20):
     n = int(h.cal_engine_profile_read(buf, cap))
     rec = np.array(buf[:3 * n], dtype=np.float64).reshape(n, 3)
     out = {}
-    for cls, key in ((0, "gemm"), (1, "spmm"), (2, "gconv"), (3, "dual")):
+    for cls, key in ((0, "gemm"), (1, "spmm"), (2, "gconv"), (3, "dual"), (4, "gconv_bwd")):
         r = rec[(rec[:, 0] == cls) & (rec[:, 1] > 0)]
         if len(r) == 0:
             continue
@@ -203,6 +203,8 @@ def engine_roofline(trainer, batches, iters=20):
         "gemm": ("k_gemm", "k_gemm<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers, unfused path)", "k_gemm_backbone"),
         "gconv": ("k_gconv_fwd", "k_gconv_fwd: per-graph fused BN + [n,H]x[H,64] MFMA GEMM + dense-block aggregation MFMA + "
                                  "bias/ReLU/BN statistics (backbone layers, forward)", "k_gconv_fwd"),
+        "gconv_bwd": ("k_gconv_bwd", "k_gconv_bwd: per-graph fused backward -- dense-block transposed aggregation + dX' = dz W^T (BN-backward "
+                                     "sums) + dW = x'^T dz, all on MFMA (backbone layers, backward)", "k_gconv_bwd"),
         "dual": ("k_gemm_dual", "k_gemm_dual: dX = dZ W^T (NT, BN-backward sums) + dW = BN(h)^T dZ (TN, split-K) in one grid "
                                 "(backbone layers, backward)", "k_gemm_dual"),
     }

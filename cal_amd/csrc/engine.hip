@@ -569,8 +569,8 @@ RoArgs make_ro(const Ctx& c) {
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 // live kernel timing for bench.py's roofline block: when enabled, HIP events are recorded on the
 // launch stream around the backbone's kernels: unfused forward GEMM ([N,H]x[H,H], class 0), aggregation
-// (k_espmm forward / transposed backward, class 1), per-graph fused convolution (class 2, flops), and the
-// backward's dX + dW dual GEMM (class 3, flops).  Events are created here (never in a normal step).
+// (k_espmm forward / transposed backward, class 1), per-graph fused convolution forward (class 2, flops), the
+// backward's dX + dW dual GEMM (class 3, flops) and the per-graph fused backward (class 4, flops).  Events are created here (never in a normal step).
 struct ProfRec { hipEvent_t e0, e1; int cls; double work; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -995,7 +995,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             gb.coef_in = e->coef;               // written by the forward's first fused layer
             float* dst[1] = {e->G + e->o_conv_w[i - 1]};
             double* dsum[1] = {bn_dsum(c, i)}; double* dprod[1] = {bn_dprod(c, i)};
-            { ProfScope ps(st, 3, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false)); } STAGE();
+            { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false)); } STAGE();
             RC(flush_finals(c)); STAGE();
             BnBwdProb p{e->dXh, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i),
                         i >= 2 ? deferred(H, d_convb[i - 2]) : Acc(), H > GC_N ? dzi : nullptr};
