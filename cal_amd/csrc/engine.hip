@@ -529,8 +529,9 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
         final_task(c, p + H, B * nsl, 2 * H, H, dprod[k]);
     }
     const dim3 grid(B, nsl, nb);
-    if (rs) hipLaunchKernelGGL((k_gconv_bwd<true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
-    else hipLaunchKernelGGL((k_gconv_bwd<false>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    if (rs) hipLaunchKernelGGL((k_gconv_bwd<true, false>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    else if (gb[0].dout) hipLaunchKernelGGL((k_gconv_bwd<false, false>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    else hipLaunchKernelGGL((k_gconv_bwd<false, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
     CAL_CHECK_LAUNCH("k_gconv_bwd");
     return 0;
 }
@@ -987,24 +988,40 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     for (int i = L; i >= 1; --i) {
         float* dzi = e->dzi + (size_t)(i - 1) * NH;     // per layer: the side-stream dW GEMM reads it later
         if (gcb) {
+            // Layer i reads dOut = e->dZ (i == L, written by k_att_bwd) or builds it while staging from layer i+1's
+            // partial dX' (BatchNorm_{i+1}-backward + ReLU mask fused in: no k_bn_bwd launch, no dZ round trip);
+            // slice-0 partials ping-pong between dXh and z (idle in the fused forward), slice-1 partials are per layer.
             const float* hin = e->h + (size_t)(i - 1) * NH;
+            float* p0 = ((L - i) & 1) ? e->z : e->dXh;
             GconvBwdBranch gb;
             memset(&gb, 0, sizeof(gb));
-            gb.dout = e->dZ; gb.x = hin; gb.W = e->P + e->o_conv_w[i - 1]; gb.dis = e->dis_unit; gb.bn = bnref(c, i, N, 0);
-            gb.dxp0 = e->dXh; gb.dxp1 = dzi;
+            gb.x = hin; gb.W = e->P + e->o_conv_w[i - 1]; gb.dis = e->dis_unit; gb.bn = bnref(c, i, N, 0);
+            gb.dxp0 = p0; gb.dxp1 = dzi;
             gb.coef_in = e->coef;               // written by the forward's first fused layer
+            if (i == L) gb.dout = e->dZ;
+            else {
+                gb.dy0 = ((L - i - 1) & 1) ? e->z : e->dXh;
+                gb.dy1 = H > GC_N ? e->dzi + (size_t)i * NH : nullptr;
+                gb.y = e->h + (size_t)i * NH;
+                gb.ubn = bnref(c, i + 1, N, 0); gb.udot_sum = bn_dsum(c, i + 1); gb.udot_prod = bn_dprod(c, i + 1);
+                Deferred& db = d_convb[i - 1];  // bias of conv i: column sums of dOut, one partial row per graph
+                db.p = parts_alloc(c, (size_t)B * H); db.P = B; db.stride = H;
+                if (!db.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+                gb.bias_parts = db.p;
+            }
             float* dst[1] = {e->G + e->o_conv_w[i - 1]};
             double* dsum[1] = {bn_dsum(c, i)}; double* dprod[1] = {bn_dprod(c, i)};
             { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false)); } STAGE();
             RC(flush_finals(c)); STAGE();
-            BnBwdProb p{e->dXh, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i),
-                        i >= 2 ? deferred(H, d_convb[i - 2]) : Acc(), H > GC_N ? dzi : nullptr};
-            RC(with_g(H, [&](auto g) {
-                constexpr int G = decltype(g)::value;
-                hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
-                return 0;
-            }));
-            CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();
+            if (i == 1) {       // the feature layer below is a plain GEMM: materialise dZ for it
+                BnBwdProb p{p0, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i), Acc(), H > GC_N ? dzi : nullptr};
+                RC(with_g(H, [&](auto g) {
+                    constexpr int G = decltype(g)::value;
+                    hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
+                    return 0;
+                }));
+                CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();
+            }
             continue;
         }
         SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};

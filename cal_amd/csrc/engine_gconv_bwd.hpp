@@ -41,6 +41,15 @@ struct GconvBwdBranch {
     float* slab;             // [B][K,H] per-graph dW
     double* dot_parts;       // [B * H/64][2K]: (sum dX', sum dX' * x_hat) partial rows
     const float* coef_in;    // edge coefficients dis_j * w_e in CSR-slot order, written by the forward kernel, or null
+    // UP variant: dOut is not materialised.  It is the BatchNorm-backward (+ ReLU mask) of the layer ABOVE,
+    //     dOut = relu'(y) * gamma_u rstd_u (dY - m1_u - y_hat m2_u),   dY = dy0 + dy1,
+    // computed while the slice is staged (what k_bn_bwd would have written and this kernel read back), and its
+    // per-graph column sums (the bias gradient of this convolution) go to bias_parts [B][H].
+    const float* dy0; const float* dy1;      // partials of the upper layer's dX' (dy1 null when H == 64)
+    const float* y;                          // [N,H] this convolution's output after ReLU = the upper BatchNorm's input
+    BNRef ubn;                               // the upper BatchNorm
+    const double* udot_sum; const double* udot_prod;
+    double* bias_parts;
 };
 
 // acc[0] (+acc[1]) += A B over kred (multiple of 32) with k-major LDS operands A[k*LDA + row], B[k*LDB + col];
@@ -85,7 +94,7 @@ __device__ __forceinline__ void gb_mma(const float* a0, const float* a1, const f
     }
 }
 
-template <bool RS>
+template <bool RS, bool UP>
 __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBwdBranch b0, const GconvBwdBranch b1, float loop_w, int N, int H,
                                                    int K, int* __restrict__ status) {
@@ -99,6 +108,8 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     __shared__ float dis_s[GB_T], rs_s[GB_T];
     __shared__ int en[GB_E];
     __shared__ float ec[GB_E];
+    __shared__ float um_s[GC_N], ur_s[GC_N], ug_s[GC_N], u1_s[GC_N], u2_s[GC_N];     // upper BatchNorm, this slice's columns
+    __shared__ float bs_s[GB_NT / 64][16][4];
     BLK_CLK(0);
     const GconvBwdBranch& br = blockIdx.z ? b1 : b0;
     const int b = blockIdx.x, sl = blockIdx.y, ns0 = sl * GC_N, t = threadIdx.x;
@@ -111,15 +122,24 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         // empty graph (or a violated bound, flagged): its partial row and its slab slice must still exist
         if (rows > 0 && t == 0) atomicOr(status, 8);
         for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
+        if (UP && t < GC_N) br.bias_parts[(size_t)b * H + ns0 + t] = 0.0;
         for (int i = t; i < K * GC_N; i += GB_NT) slab[(size_t)(i / GC_N) * H + ns0 + i % GC_N] = 0.f;
         return;
     }
     const bool hasw = br.ew != nullptr;
     const int rowsP = (rows + 31) & ~31, R = rowsP >> 5, K4 = K >> 2;
     // ---- every global load of the kernel, issued before the first wait ------------------------------------------
-    RoBatch<float4, 2> bd;                               // dOut[g0 + j][ns0 + 4 n4 ..]: rows x 16 float4
+    RoBatch<float4, 2> bd, bd1, by;                      // dOut[g0 + j][ns0 + 4 n4 ..]: rows x 16 float4 (UP: dy0, dy1, y)
     RoBatch<float4, 4> bx, bw;                           // x[g0 + i][4 k4 ..]: rows x K/4;  W[k_in][ns0 + 4 n4 ..]: K x 16
-    ro_issue<GB_NT>(bd, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(br.dout + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+    {
+        const float* d0 = UP ? br.dy0 : br.dout;
+        ro_issue<GB_NT>(bd, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(d0 + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+        if (UP) {
+            const float* d1 = br.dy1 ? br.dy1 : br.dy0;
+            ro_issue<GB_NT>(bd1, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(d1 + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+            ro_issue<GB_NT>(by, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(br.y + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+        }
+    }
     ro_issue<GB_NT>(bx, rows, K4, [&](int i, int k4) { return *reinterpret_cast<const float4*>(br.x + (size_t)(g0 + i) * K + 4 * k4); });
     ro_issue<GB_NT>(bw, K, 16, [&](int k, int n4) { return *reinterpret_cast<const float4*>(br.W + (size_t)k * H + ns0 + 4 * n4); });
     const int pv = g.ptr[g0 + min(t, rows)];
@@ -135,6 +155,15 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     float cin[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) cin[u] = br.coef_in ? br.coef_in[e0 + max(min(t + u * GB_NT, ne - 1), 0)] : 0.f;
+    if (UP && t >= 256 && t < 256 + GC_N) {              // upper BatchNorm constants of this slice's 64 columns
+        const int c = ns0 + t - 256;
+        float m1[1], r1[1];
+        bn_mean_rstd_v<1>(br.ubn, c, m1, r1);
+        um_s[t - 256] = m1[0]; ur_s[t - 256] = r1[0];
+        ug_s[t - 256] = (br.ubn.gamma ? br.ubn.gamma[c] : 1.f) * r1[0];
+        u1_s[t - 256] = (float)(br.udot_sum[c] * (double)br.ubn.inv_n);
+        u2_s[t - 256] = (float)(br.udot_prod[c] * (double)br.ubn.inv_n);
+    }
     if (t < K) {
         float m1[1], r1[1];
         bn_mean_rstd_v<1>(br.bn, t, m1, r1);
@@ -168,7 +197,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
             if (!inb) atomicOr(status, 16);
         }
     }
-    ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
+    if (!UP) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
     ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) {
         float* d = Wt + (4 * n4) * GB_LDW + k;
         d[0] = v.x; d[GB_LDW] = v.y; d[2 * GB_LDW] = v.z; d[3 * GB_LDW] = v.w;
@@ -181,6 +210,42 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         v.z = (v.z * s - mean_s[k + 2]) * rstd_s[k + 2]; v.w = (v.w * s - mean_s[k + 3]) * rstd_s[k + 3];
         *reinterpret_cast<float4*>(Xs + i * GB_LDX + k) = v;
     });
+    if (UP) {
+        // dOut slice from the upper layer's partials: lane t always holds column group t % 16 (512 % 16 == 0), so
+        // its column sums stay in registers until the cross-lane reduction below
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool two = br.dy1 != nullptr;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { ro_pin(bd.v[u]); ro_pin(bd1.v[u]); ro_pin(by.v[u]); }
+        const int c = 4 * (t & 15);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                   // item (u, t) = row t / 16 + 32 u, column group t % 16
+            const int j = (t >> 4) + u * (GB_NT / 16);
+            if (j < rows) {
+                const float4 v0 = bd.v[u], v1 = bd1.v[u], yv = by.v[u];
+                const float d[4] = {v0.x + (two ? v1.x : 0.f), v0.y + (two ? v1.y : 0.f), v0.z + (two ? v1.z : 0.f), v0.w + (two ? v1.w : 0.f)};
+                const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float yn = (yy[q] - um_s[c + q]) * ur_s[c + q];
+                    const float g1 = ug_s[c + q] * (d[q] - u1_s[c + q] - yn * u2_s[c + q]);
+                    o[q] = yy[q] > 0.f ? g1 : 0.f;
+                    cs[q] += o[q];
+                }
+                *reinterpret_cast<float4*>(Ds + j * GB_LDD + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cs[q] += __shfl_xor(cs[q], 16, 64);
+            cs[q] += __shfl_xor(cs[q], 32, 64);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bs_s[t >> 6][lane][q] = cs[q];
+        }
+    }
     // rows rows .. rowsP of dOut / x_hat: zero (they are reduced over in the products below)
     for (int i = t; i < (rowsP - rows) * GB_LDD; i += GB_NT) Ds[rows * GB_LDD + i] = 0.f;
     for (int i = t; i < (rowsP - rows) * GB_LDX; i += GB_NT) Xs[rows * GB_LDX + i] = 0.f;
@@ -190,6 +255,12 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         Ab[t * GB_LDJ + t] += dj * dj * loop_w;
     }
     __syncthreads();
+    if (UP && t < GC_N) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < GB_NT / 64; ++k) tot += (double)bs_s[k][t >> 2][t & 3];
+        br.bias_parts[(size_t)b * H + ns0 + t] = tot;
+    }
     BLK_CLK(2);
     auto ident = [](float v) { return v; };
     gc_f32x16 acc[2];
