@@ -23,6 +23,7 @@
 #include "engine_readout.hpp"
 #include "engine_gconv.hpp"
 #include "engine_gconv_bwd.hpp"
+#include "engine_plan.hpp"
 
 namespace cal {
 
@@ -143,6 +144,7 @@ struct Engine {
     int *rowptr_dst, *nbr_dst, *eid_dst, *rowptr_src, *nbr_src, *eid_src, *row32, *col32, *work, *status, *gptr, *iperm, *eptr;
     float* coef;                // [3][E] edge coefficients dis_j * w_e in CSR-by-destination slot order: unit, context, objects
     int max_nodes, max_edges;   // per-graph bounds of the coming batches (0 = unknown): cal_engine_set_graph_bounds
+    const int64_t *node_ptr, *edge_ptr;   // [B+1] device arrays of the coming batch (null = unknown): cal_engine_set_graph_ptrs
 };
 
 static size_t al(size_t n) { return (n + 63) / 64 * 64; }   // 256 B granules (in floats/ints)
@@ -309,7 +311,9 @@ CAL_EXPORT int64_t cal_engine_buffer_offset(void* h, const char* name) {
         {"zl", e->zl}, {"logp", e->logp}, {"stats", e->stats}, {"dzl", e->dzl}, {"dyh1", e->dyh1}, {"dy1", e->dy1},
         {"dxh", e->dxh}, {"dpool", e->dpool}, {"dZco", e->dZco}, {"gn", e->gn}, {"gself", e->gself}, {"ddeg", e->ddeg},
         {"dl", e->dl}, {"dzco", e->dzco}, {"dXhco", e->dXhco}, {"dZ", e->dZ}, {"dzi", e->dzi}, {"dXh", e->dXh},
-        {"arena", e->arena}, {"gptr", e->gptr}, {"status", e->status},
+        {"arena", e->arena}, {"gptr", e->gptr}, {"status", e->status}, {"eptr", e->eptr},
+        {"rowptr_dst", e->rowptr_dst}, {"nbr_dst", e->nbr_dst}, {"eid_dst", e->eid_dst},
+        {"rowptr_src", e->rowptr_src}, {"nbr_src", e->nbr_src}, {"eid_src", e->eid_src},
     };
     for (auto& t : tab)
         if (!strcmp(t.n, name)) return ((char*)t.p - e->ws) / 4;
@@ -600,19 +604,28 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     const int64_t E = c.E;
     hipStream_t st = c.st;
     const size_t NH = (size_t)N * H;
+    // per-graph plan (engine_plan.hpp) when the host vouches for the batch layout
+    const bool fast_plan = e->node_ptr && e->edge_ptr && B > 0 && e->max_nodes > 0 && e->max_nodes <= GP_T && e->max_edges <= GP_E;
     // 0. zero the fp64 arena and the GraphPlan counters (one kernel, not memset nodes)
     {
-        const int64_t ni = 4 * ((int64_t)N + 1);
+        const int64_t ni = fast_plan ? 0 : 4 * ((int64_t)N + 1);
         hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256)), dim3(256), 0, st, e->arena,
                            (int64_t)e->arena_n, e->work, ni, e->status);
         CAL_CHECK_LAUNCH("k_zero_f64"); STAGE();
     }
     // 1. GraphPlan
-    RC(plan_build(edge_index, E, N, e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
-                  e->row32, e->col32, e->work, e->status, true, st)); STAGE();
-    hipLaunchKernelGGL(k_gptr_dis, dim3(cdiv(N + 1, 256)), dim3(256), 0, st, batch, N, B, e->gptr, e->rowptr_src, e->loop_w,
-                       e->dis_unit, e->status, e->rowptr_dst, e->eptr);
-    CAL_CHECK_LAUNCH("k_gptr_dis"); STAGE();
+    if (fast_plan) {
+        hipLaunchKernelGGL(k_plan_graph, dim3(B), dim3(256), 0, st, edge_index, E, N, B, e->node_ptr, e->edge_ptr, batch, e->loop_w,
+                           e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src, e->row32, e->col32,
+                           e->gptr, e->eptr, e->dis_unit, e->status);
+        CAL_CHECK_LAUNCH("k_plan_graph"); STAGE();
+    } else {
+        RC(plan_build(edge_index, E, N, e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
+                      e->row32, e->col32, e->work, e->status, true, st)); STAGE();
+        hipLaunchKernelGGL(k_gptr_dis, dim3(cdiv(N + 1, 256)), dim3(256), 0, st, batch, N, B, e->gptr, e->rowptr_src, e->loop_w,
+                           e->dis_unit, e->status, e->rowptr_dst, e->eptr);
+        CAL_CHECK_LAUNCH("k_gptr_dis"); STAGE();
+    }
     const CSR gd{e->rowptr_dst, e->nbr_dst, e->eid_dst, (int)c.E}, gs{e->rowptr_src, e->nbr_src, e->eid_src, (int)c.E};
     (void)gs;
     // 2. bn_feat statistics (model.py:90)
@@ -1205,6 +1218,16 @@ CAL_EXPORT int cal_engine_set_graph_bounds(void* h, int64_t max_nodes, int64_t m
     CAL_REQUIRE(e != nullptr && max_nodes >= 0 && max_edges >= 0, "bad arguments");
     e->max_nodes = (int)std::min<int64_t>(max_nodes, 1 << 30);
     e->max_edges = (int)std::min<int64_t>(max_edges, 1 << 30);
+    return 0;
+}
+// Layout of the coming batch, as every collate knows it: graph b owns nodes [node_ptr[b], node_ptr[b+1]) and the
+// contiguous edge_index columns [edge_ptr[b], edge_ptr[b+1]), and no edge is a self loop (both [B+1] int64 DEVICE
+// arrays, alive until the step has run; null = unknown).  Together with the per-graph bounds this selects the
+// one-kernel per-graph GraphPlan; what the kernel finds violated is flagged in the status word.
+CAL_EXPORT int cal_engine_set_graph_ptrs(void* h, const int64_t* node_ptr, const int64_t* edge_ptr) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e != nullptr, "bad arguments");
+    e->node_ptr = node_ptr; e->edge_ptr = edge_ptr;
     return 0;
 }
 CAL_EXPORT int cal_engine_debug_stop(int k) { g_stop_after = k; return 0; }

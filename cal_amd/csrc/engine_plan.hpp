@@ -1,0 +1,125 @@
+// Per-graph GraphPlan of the step engine: the work of plan.hip's five launches (zero, count, scan, fill,
+// rank: gcn_conv.py:56-57 remove/add self loops, :92 the scatter index) plus k_gptr_dis in ONE kernel,
+// when the host can vouch for the shape of the mini-batch -- what every collate knows for free:
+//   * node_ptr / edge_ptr [B+1]: graph b owns nodes [node_ptr[b], node_ptr[b+1]) and the CONTIGUOUS block
+//     of edge_index columns [edge_ptr[b], edge_ptr[b+1]) (PyG's Batch, cal_collate and Batch.from_data_list
+//     all build batches this way),
+//   * no self loops in the input (so every edge keeps its slot and the slot range of a graph is its edge
+//     range: no cross-graph prefix sum), at most GP_T nodes and GP_E edges per graph.
+// A workgroup builds both CSR views of its graph in LDS: degrees with LDS atomics, one wave scans them,
+// edges are scattered with LDS cursors and then ranked by edge id inside their row (rows are short), which
+// gives the same deterministic slot order as plan.hip.  Violations are flagged in the status word
+// (bit 0: endpoint outside the graph / index range, bit 1: batch vector disagrees with node_ptr, bit 5: self
+// loop, bit 3: bound exceeded); the generic path remains for everything else.
+#pragma once
+#include "engine_kernels.hpp"
+
+namespace cal {
+
+constexpr int GP_T = 128;                 // nodes per graph
+constexpr int GP_E = 1024;                // edges per graph
+
+__global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ ei, int64_t E, int N, int B,
+                                                    const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr,
+                                                    const int64_t* __restrict__ batch, float loop_w,
+                                                    int* __restrict__ ptr_dst, int* __restrict__ nbr_dst, int* __restrict__ eid_dst,
+                                                    int* __restrict__ ptr_src, int* __restrict__ nbr_src, int* __restrict__ eid_src,
+                                                    int* __restrict__ row32, int* __restrict__ col32, int* __restrict__ gptr,
+                                                    int* __restrict__ eptr, float* __restrict__ dis_unit, int* __restrict__ status) {
+    __shared__ int deg_in[GP_T], deg_out[GP_T], off_in[GP_T + 1], off_out[GP_T + 1], cur_in[GP_T], cur_out[GP_T];
+    __shared__ short rl[GP_E], cl[GP_E];                 // local endpoints of the graph's edges (edge-id order)
+    __shared__ short tn_d[GP_E], te_d[GP_E], tn_s[GP_E], te_s[GP_E];     // unordered row contents: neighbour, local edge id
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int g0 = (int)node_ptr[b], rows = (int)node_ptr[b + 1] - g0;
+    const int64_t e0 = edge_ptr[b];
+    const int m = (int)(edge_ptr[b + 1] - e0);
+    if (t == 0) {
+        gptr[b] = g0; eptr[b] = (int)e0;
+        if (b == B - 1) { gptr[B] = g0 + rows; eptr[B] = (int)(e0 + m); ptr_dst[N] = (int)(e0 + m); ptr_src[N] = (int)(e0 + m); }
+        if (b == B - 1 && (g0 + rows != N || e0 + m != E)) atomicOr(status, 2);
+        if (b == 0 && (g0 != 0 || e0 != 0)) atomicOr(status, 2);
+    }
+    if (rows < 0 || rows > GP_T || m < 0 || m > GP_E) { if (t == 0) atomicOr(status, 8); return; }
+    // edges: 4 per lane, both endpoints requested before anything waits
+    int64_t rv[4], cv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t e = e0 + max(min(t + u * 256, m - 1), 0);
+        rv[u] = m > 0 ? ei[e] : 0;
+        cv[u] = m > 0 ? ei[E + e] : 0;
+    }
+    const int64_t bv = rows > 0 ? batch[g0 + min(t, rows - 1)] : (int64_t)b;
+    if (t < GP_T) { deg_in[t] = 0; deg_out[t] = 0; cur_in[t] = 0; cur_out[t] = 0; }
+    __syncthreads();
+    if (t < rows && bv != b) atomicOr(status, 2);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int s = t + u * 256;
+        if (s < m) {
+            int r = (int)(rv[u] - g0), c = (int)(cv[u] - g0);
+            const bool bad = r < 0 || r >= rows || c < 0 || c >= rows;
+            if (bad) { atomicOr(status, 1); r = 0; c = 0; }
+            if (r == c) atomicOr(status, bad ? 1 : 32);
+            rl[s] = (short)r; cl[s] = (short)c;
+            row32[e0 + s] = g0 + r; col32[e0 + s] = g0 + c;
+            atomicAdd(&deg_out[r], 1);
+            atomicAdd(&deg_in[c], 1);
+        }
+    }
+    __syncthreads();
+    // exclusive scans of the two degree arrays: waves 0 / 1, rows <= 128 = two elements per lane
+    if (t < 128) {
+        const int* deg = t < 64 ? deg_in : deg_out;
+        int* off = t < 64 ? off_in : off_out;
+        const int l = t & 63;
+        const int a0 = 2 * l < rows ? deg[2 * l] : 0, a1 = 2 * l + 1 < rows ? deg[2 * l + 1] : 0;
+        int x = a0 + a1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (l >= o) x += y;
+        }
+        const int ex = x - a0 - a1;
+        if (2 * l <= rows) off[2 * l] = ex;
+        if (2 * l + 1 <= rows) off[2 * l + 1] = ex + a0;
+        if (l == 63) off[rows] = x;                      // the total (rows == 128 has no lane for it above)
+    }
+    __syncthreads();
+    if (t < rows) {
+        ptr_dst[g0 + t] = (int)e0 + off_in[t];
+        ptr_src[g0 + t] = (int)e0 + off_out[t];
+        const float d = (float)deg_out[t] + loop_w;
+        dis_unit[g0 + t] = d == 0.f ? 0.f : 1.0f / sqrtf(d);
+    }
+    // scatter into the rows (arbitrary order inside a row) ...
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int s = t + u * 256;
+        if (s < m) {
+            const int r = rl[s], c = cl[s];
+            const int p = off_in[c] + atomicAdd(&cur_in[c], 1);
+            tn_d[p] = (short)r; te_d[p] = (short)s;
+            const int q = off_out[r] + atomicAdd(&cur_out[r], 1);
+            tn_s[q] = (short)c; te_s[q] = (short)s;
+        }
+    }
+    __syncthreads();
+    // ... then every slot moves to its rank by edge id inside its row
+    for (int p = t; p < 2 * m; p += 256) {
+        const bool d = p < m;
+        const int q = d ? p : p - m;
+        const short* te = d ? te_d : te_s;
+        const short* tn = d ? tn_d : tn_s;
+        const int s = te[q];
+        const int v = d ? cl[s] : rl[s];
+        const int* off = d ? off_in : off_out;
+        const int s0 = off[v], s1 = off[v + 1];
+        int rank = 0;
+        for (int k = s0; k < s1; ++k) rank += te[k] < s;
+        const int64_t slot = e0 + s0 + rank;
+        if (d) { nbr_dst[slot] = g0 + tn[q]; eid_dst[slot] = (int)(e0 + s); }
+        else { nbr_src[slot] = g0 + tn[q]; eid_src[slot] = (int)(e0 + s); }
+    }
+}
+
+}  // namespace cal

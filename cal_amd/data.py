@@ -86,6 +86,10 @@ class Batch(Data):
         # engine pick its per-graph fused kernels without a device round trip
         self.max_nodes = 0
         self.max_edges = 0
+        # layout facts of a collated batch (graph b owns nodes [ptr[b], ptr[b+1]) and the contiguous edge columns
+        # [edge_ptr[b], edge_ptr[b+1]); no edge is a self loop): they select the engine's one-kernel CSR build
+        self.edge_ptr = None
+        self.no_self_loops = False
 
     @staticmethod
     def from_data_list(data_list: Sequence[Data]) -> "Batch":
@@ -113,6 +117,11 @@ class Batch(Data):
         b.num_graphs = len(data_list)
         b.max_nodes = max((int(d.num_nodes) for d in data_list), default=0)
         b.max_edges = max((int(d.edge_index.size(1)) for d in data_list), default=0)
+        eptr = [0]
+        for d in data_list:
+            eptr.append(eptr[-1] + int(d.edge_index.size(1)))
+        b.edge_ptr = torch.tensor(eptr, dtype=torch.long)
+        b.no_self_loops = bool(b.edge_index.numel() == 0 or (b.edge_index[0] != b.edge_index[1]).all().item())
         return b
 
     @property

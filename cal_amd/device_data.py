@@ -37,6 +37,7 @@ class DeviceDataset:
         self.node_ptr = torch.from_numpy(self.node_ptr_h).to(dev)
         self.edge_ptr = torch.from_numpy(self.edge_ptr_h).to(dev)
         self.device = dev
+        self.no_self_loops = bool(self.EI.numel() == 0 or (self.EI[0] != self.EI[1]).all().item())
         self._pin = []          # ring of (pinned buffer, event): the async H2D copy of step k may still be
         self._pin_i = 0         # pending when the host prepares step k+1
 
@@ -81,7 +82,9 @@ class DeviceDataset:
         b.num_graphs = B
         b.max_nodes = int(n.max()) if B else 0
         b.max_edges = int(e.max()) if B else 0
-        b.ptr = None
+        b.ptr = meta[B:2 * B + 1]                 # node / edge offsets per graph, already on the device for cal_collate
+        b.edge_ptr = meta[2 * B + 1:3 * B + 2]
+        b.no_self_loops = self.no_self_loops
         b._meta = meta            # keep the device copy alive until the kernel has consumed it
         return b
 

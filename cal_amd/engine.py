@@ -92,6 +92,7 @@ class StepEngine:
         self._ws: Optional[torch.Tensor] = None
         self._cap = (0, 0, 0)
         self._bounds = (0, 0)
+        self._ptrs = (0, 0)
         self.wc, self.wo, self.wco = float(getattr(a, "c", 0.5)), float(getattr(a, "o", 1.0)), float(getattr(a, "co", 0.5))
 
     def __del__(self):
@@ -136,6 +137,15 @@ class StepEngine:
             raise ValueError("features must be float32 [N, %d]" % self.F)
         self.reserve(N, E, B)
         self._last_B = B
+        # layout facts of a collated batch -> one-kernel per-graph CSR build (the tensors stay referenced by the batch)
+        nptr, eptr = getattr(batch, "ptr", None), getattr(batch, "edge_ptr", None)
+        ok = (getattr(batch, "no_self_loops", False) and torch.is_tensor(nptr) and torch.is_tensor(eptr)
+              and nptr.is_cuda and eptr.is_cuda and nptr.dtype == torch.long and eptr.dtype == torch.long
+              and nptr.numel() == B + 1 and eptr.numel() == B + 1 and nptr.is_contiguous() and eptr.is_contiguous())
+        ptrs = (nptr.data_ptr(), eptr.data_ptr()) if ok else (0, 0)
+        if ptrs != self._ptrs:
+            _lib.call("cal_engine_set_graph_ptrs", self._h, ptrs[0] or None, ptrs[1] or None)
+            self._ptrs = ptrs
         bounds = (int(getattr(batch, "max_nodes", 0) or 0), int(getattr(batch, "max_edges", 0) or 0))
         if bounds != self._bounds:
             _lib.call("cal_engine_set_graph_bounds", self._h, bounds[0], bounds[1])

@@ -164,6 +164,10 @@ CAL_API int cal_engine_backward_from(void* engine, const float* x0, const int64_
  * when they fit, the step runs its per-graph fused convolution kernels (GEMM + aggregation + add-pool in
  * LDS); a violated bound sets bit 3 of the engine's status word */
 CAL_API int cal_engine_set_graph_bounds(void* engine, int64_t max_nodes, int64_t max_edges);
+/* layout of the coming batch as the collate knows it: node / edge ranges per graph ([B+1] int64 device arrays, graph
+ * b owns the contiguous edge_index columns [edge_ptr[b], edge_ptr[b+1])) and no self loops; null = unknown.  With the
+ * per-graph bounds this selects the one-kernel per-graph CSR build; violations are flagged in the status word */
+CAL_API int cal_engine_set_graph_ptrs(void* engine, const int64_t* node_ptr, const int64_t* edge_ptr);
 /* profiling aid: make cal_engine_step return after its k-th launch site (0 = run everything) */
 CAL_API int cal_engine_debug_stop(int k);
 /* name of launch site k (1-based) of the latest untruncated cal_engine_step; "" past the end */

@@ -394,3 +394,58 @@ def test_fused_conv_matches_unfused_and_flags_bad_bounds():
     big.max_nodes, big.max_edges = 50, 10                    # claims the 64-node variant fits
     eng.train_step(big, torch.arange(2, device=DEV), adam=False)
     assert int(eng.buffer("status", 1, dtype=torch.int32).item()) & 8
+
+
+def test_per_graph_plan_equals_generic_plan_and_flags_violations():
+    """k_plan_graph (one kernel, needs the collate's node/edge offsets and no self loops) against plan.hip's generic
+    five-launch build on the same batch: identical CSR views, graph pointers and degrees; and the status word when
+    the host's promises do not hold."""
+    torch.manual_seed(21)
+    sizes = [60, 1, 33, 128, 17, 2, 90]
+
+    from cal_amd.data import Batch, Data
+
+    def sparse_batch():            # ~4 out-edges per node, no self loops, duplicate edges allowed
+        g = torch.Generator().manual_seed(5)
+        ds = []
+        for n in sizes:
+            if n == 1:
+                ei = torch.zeros(2, 0, dtype=torch.long)
+            else:
+                src = torch.arange(n).repeat_interleave(4)
+                dst = (src + 1 + torch.randint(0, n - 1, (src.numel(),), generator=g)) % n
+                ei = torch.stack([src, dst])[:, torch.randperm(src.numel(), generator=g)]
+            ds.append(Data(x=torch.randn(n, 6, generator=g), edge_index=ei, y=torch.randint(0, 3, (1,), generator=g)))
+        return Batch.from_data_list(ds)
+
+    bd = sparse_batch().to(DEV)
+    assert bd.no_self_loops and bd.ptr.is_cuda and bd.edge_ptr.is_cuda
+    sd = O.init_state("CausalGCN", 6, 3, hidden=64, layers=1)
+    N, E, B = bd.x.size(0), bd.edge_index.size(1), len(sizes)
+    perm = torch.arange(B, device=DEV)
+    views = []
+    for fast in (True, False):
+        m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(hidden=64, layers=1), 6, 3)
+        keep = bd.no_self_loops
+        if not fast:
+            bd.no_self_loops = False                       # withhold the promise -> generic build
+        eng.forward(bd, perm, training=True)
+        bd.no_self_loops = keep
+        assert int(eng.buffer("status", 1, dtype=torch.int32).item()) == 0
+        v = {k: eng.buffer(k, n, dtype=torch.int32).clone() for k, n in
+             (("rowptr_dst", N + 1), ("nbr_dst", E), ("eid_dst", E), ("rowptr_src", N + 1), ("nbr_src", E), ("eid_src", E),
+              ("gptr", B + 1), ("eptr", B + 1))}
+        v["dis_unit"] = eng.buffer("dis_unit", N).clone()
+        views.append(v)
+    for k in views[0]:
+        assert torch.equal(views[0][k], views[1][k]), k
+    # promises that do not hold: a self loop, and a batch vector that disagrees with node_ptr
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(hidden=64, layers=1), 6, 3)
+    bad = sparse_batch().to(DEV)
+    bad.edge_index[:, 5] = bad.edge_index[0, 5]            # edge 5 becomes a self loop; the flag still says there is none
+    eng.forward(bad, perm, training=True)
+    assert int(eng.buffer("status", 1, dtype=torch.int32).item()) & 32
+    bad2 = sparse_batch().to(DEV)
+    bad2.batch[0] = 1
+    eng.forward(bad2, perm, training=True)
+    assert int(eng.buffer("status", 1, dtype=torch.int32).item()) & 2
