@@ -258,7 +258,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     F32(e->pooled, 2 * B * H); F32(e->xco, B * H); F32(e->y1, 3 * B * H); F32(e->zl, 3 * B * C); F32(e->logp, 3 * B * C);
     F32(e->stats, 8);
     F32(e->dzl, 3 * B * C); F32(e->dyh1, 3 * B * H); F32(e->dy1, 3 * B * H); F32(e->dxh, 3 * B * H); F32(e->dpool, 2 * B * H);
-    F32(e->dZco, 2 * N * H); F32(e->gn, 2 * E); F32(e->gself, 2 * N); F32(e->ddeg, 2 * N); F32(e->dl, E);
+    F32(e->dZco, 2 * N * H); F32(e->gn, 4 * E); F32(e->gself, 4 * N); F32(e->ddeg, 2 * N); F32(e->dl, E);
     F32(e->dzco, 2 * N * H); F32(e->dXhco, 2 * N * H); F32(e->dZ, N * H); F32(e->dzi, (L > 0 ? L : 1) * N * H); F32(e->dXh, N * H);
     // split-K slabs: worst case per weight gradient (S <= 256, but S*tiles ~ 512 => S*M*N <= ~512*64*64 + M*N)
     size_t slab = 0;
@@ -533,9 +533,9 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
         final_task(c, p + H, B * nsl, 2 * H, H, dprod[k]);
     }
     const dim3 grid(B, nsl, nb);
-    if (rs) hipLaunchKernelGGL((k_gconv_bwd<true, false>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
-    else if (gb[0].dout) hipLaunchKernelGGL((k_gconv_bwd<false, false>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
-    else hipLaunchKernelGGL((k_gconv_bwd<false, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    if (rs) hipLaunchKernelGGL((k_gconv_bwd<true, 2>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    else if (gb[0].dout) hipLaunchKernelGGL((k_gconv_bwd<false, 0>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    else hipLaunchKernelGGL((k_gconv_bwd<false, 1>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
     CAL_CHECK_LAUNCH("k_gconv_bwd");
     return 0;
 }
@@ -898,8 +898,10 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         hipLaunchKernelGGL(k_readout_bwd_tail, dim3(cdiv((int64_t)BH, 256)), dim3(256), 0, st, in[0], in[1], in[2], e->iperm, e->dpool, B, H);
         CAL_CHECK_LAUNCH("k_readout_bwd_tail"); STAGE();
     }
+    const bool gcb = use_gcb(c);
     // P1. add-pool backward + ReLU of the causal/trivial convs + their bias gradients
-    {
+    // (per-graph fused backward: both are built while k_gconv_bwd stages dOut, and it emits gn / gself as well)
+    if (!gcb) {
         const Acc acb = deferred(H, d_cb), aob = deferred(H, d_ob);
         if (!acb.on() || !aob.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
         RC(with_g(H, [&](auto g) {
@@ -913,20 +915,25 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             return 0;
         }));
     }
-    CAL_CHECK_LAUNCH("k_pool_bwd_relu"); STAGE();
+    if (!gcb) { CAL_CHECK_LAUNCH("k_pool_bwd_relu"); STAGE(); }
     // P2-P4. gradient w.r.t. the edge weights through propagate and through the normalisation
-    hipLaunchKernelGGL(k_sddmm2, dim3(cdiv(E + N, 32), 2), dim3(256), 0, st, e->row32, e->col32, e->dZco, e->dZco + NH, e->zco,
-                       e->zco + NH, e->gn, e->gself, N, E, H);
-    CAL_CHECK_LAUNCH("k_sddmm2"); STAGE();
-    hipLaunchKernelGGL(k_normbwd_node2, dim3(cdiv(N, 32), 2), dim3(256), 0, st, gs, gd, e->att, e->dis_co, e->gn, e->gself, e->ddeg,
-                       e->loop_w, N, E);
-    CAL_CHECK_LAUNCH("k_normbwd_node2"); STAGE();
-    if (E > 0) {
-        hipLaunchKernelGGL(k_normbwd_edge, dim3(cdiv(E, 256)), dim3(256), 0, st, e->row32, e->col32, e->att, e->dis_co, e->gn, e->ddeg,
-                           e->dl, N, E);
-        CAL_CHECK_LAUNCH("k_normbwd_edge"); STAGE();
+    auto norm_bwd = [&](const float* gn2, const float* gself2) -> int {
+        hipLaunchKernelGGL(k_normbwd_node2, dim3(cdiv(N, 32), 2), dim3(256), 0, st, gs, gd, e->att, e->dis_co, e->gn, e->gself, e->ddeg,
+                           e->loop_w, N, E, gn2, gself2);
+        CAL_CHECK_LAUNCH("k_normbwd_node2"); STAGE();
+        if (E > 0) {
+            hipLaunchKernelGGL(k_normbwd_edge, dim3(cdiv(E, 256)), dim3(256), 0, st, e->row32, e->col32, e->att, e->dis_co, e->gn, e->ddeg,
+                               e->dl, N, E, gn2);
+            CAL_CHECK_LAUNCH("k_normbwd_edge"); STAGE();
+        }
+        return 0;
+    };
+    if (!gcb) {
+        hipLaunchKernelGGL(k_sddmm2, dim3(cdiv(E + N, 32), 2), dim3(256), 0, st, e->row32, e->col32, e->dZco, e->dZco + NH, e->zco,
+                           e->zco + NH, e->gn, e->gself, N, E, H);
+        CAL_CHECK_LAUNCH("k_sddmm2"); STAGE();
+        RC(norm_bwd(nullptr, nullptr));
     }
-    const bool gcb = use_gcb(c);
     // P5. dz_k = A_hat_k^T dZ_k
     if (!gcb) {
         SpmmBranch b0{e->dZco, e->dzco, nullptr, e->att, e->dis_co, Acc(), Acc()};
@@ -945,7 +952,17 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         memset(gb, 0, sizeof(gb));
         float* dst[2]; double* dsum[2]; double* dprod[2];
         for (int k = 0; k < 2; ++k) {
-            gb[k].dout = e->dZco + (size_t)k * NH; gb[k].x = x; gb[k].W = e->P + (k ? e->o_ow : e->o_cw);
+            gb[k].x = x; gb[k].W = e->P + (k ? e->o_ow : e->o_cw);
+            // dOut = relu'(h_k) * (gradient of the graph's pooled row); gn / gself partials per 64-column slice
+            gb[k].y = e->hco + (size_t)k * NH; gb[k].z = e->zco + (size_t)k * NH;
+            if (ro) { gb[k].gp0 = e->dxh + (size_t)k * B * H; gb[k].gp1 = e->dxh + (size_t)2 * B * H; gb[k].iperm = k == 0 ? e->iperm : nullptr; }
+            else gb[k].gp0 = e->dpool + (size_t)k * B * H;
+            gb[k].gn = e->gn + (size_t)k * E; gb[k].gself = e->gself + (size_t)k * N;
+            gb[k].gn_stride = 2 * (size_t)E; gb[k].gself_stride = 2 * (size_t)N;
+            Deferred& db = k ? d_ob : d_cb;
+            db.p = parts_alloc(c, (size_t)B * H); db.P = B; db.stride = H;
+            if (!db.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+            gb[k].bias_parts = db.p;
             gb[k].ew = e->att + (size_t)k * E; gb[k].dis = e->dis_co + (size_t)k * N;
             gb[k].rs = e->anode + k; gb[k].rs_stride = 2; gb[k].bn = bnref(c, L + 1 + k, N, 0);
             gb[k].dxp0 = e->dXhco + (size_t)k * NH; gb[k].dxp1 = e->dzco + (size_t)k * NH;
@@ -954,6 +971,8 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         }
         RC(gconv_bwd(c, gd, gb, 2, dst, dsum, dprod, fa, slab_off, true)); STAGE();
         RC(flush_finals(c)); STAGE();
+        const bool two = H > GC_N;
+        RC(norm_bwd(two ? e->gn + 2 * (size_t)E : nullptr, two ? e->gself + 2 * (size_t)N : nullptr));
     }
     // P6. dW_k = BN_k(a_k x)^T @ dz_k
     if (!gcb) {

@@ -50,6 +50,15 @@ struct GconvBwdBranch {
     BNRef ubn;                               // the upper BatchNorm
     const double* udot_sum; const double* udot_prod;
     double* bias_parts;
+    // POOL variant (the two weighted convolutions under global_add_pool, model.py:112-116): dOut is not materialised
+    // either -- dOut[v] = relu'(out[v]) * g_b with g_b = gp0[b] (+ gp1[pb], pb = iperm[b] or b) the gradient of graph b's
+    // pooled row (y = the convolution's output, bias_parts as above) -- and the kernel also emits this slice's part of
+    //     gn[e] = <dOut[col_e], z[row_e]>,   gself[v] = <dOut[v], z[v]>
+    // (the SDDMM behind the edge-weight gradients, gcn_conv.py:63-70,97 differentiated) from LDS while P1 runs.
+    const float* gp0; const float* gp1; const int* iperm;
+    const float* z;          // [N,H] x' W of the forward
+    float* gn; float* gself; // this branch's [E] / [N] partials of slice 0; slice 1 is gn_stride / gself_stride further
+    size_t gn_stride, gself_stride;
 };
 
 // acc[0] (+acc[1]) += A B over kred (multiple of 32) with k-major LDS operands A[k*LDA + row], B[k*LDB + col];
@@ -94,7 +103,7 @@ __device__ __forceinline__ void gb_mma(const float* a0, const float* a1, const f
     }
 }
 
-template <bool RS, bool UP>
+template <bool RS, int MODE>      // MODE 0: dOut given; 1: UP (from the upper layer's partials); 2: POOL (+ gn / gself)
 __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBwdBranch b0, const GconvBwdBranch b1, float loop_w, int N, int H,
                                                    int K, int* __restrict__ status) {
@@ -110,6 +119,11 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     __shared__ float ec[GB_E];
     __shared__ float um_s[GC_N], ur_s[GC_N], ug_s[GC_N], u1_s[GC_N], u2_s[GC_N];     // upper BatchNorm, this slice's columns
     __shared__ float bs_s[GB_NT / 64][16][4];
+    __shared__ __attribute__((aligned(16))) float Zr[MODE == 2 ? GB_T * GB_LDD : 4];       // POOL: z slice rows [j][n]
+    __shared__ float gv_s[GC_N];                         // POOL: gradient of this graph's pooled row, slice columns
+    __shared__ int ee[MODE == 2 ? GB_E : 1];             // POOL: edge id of CSR slot s
+    __shared__ short er[MODE == 2 ? GB_E : 1];           // POOL: destination row of CSR slot s
+    constexpr bool UP = MODE == 1, POOL = MODE == 2;
     BLK_CLK(0);
     const GconvBwdBranch& br = blockIdx.z ? b1 : b0;
     const int b = blockIdx.x, sl = blockIdx.y, ns0 = sl * GC_N, t = threadIdx.x;
@@ -122,7 +136,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         // empty graph (or a violated bound, flagged): its partial row and its slab slice must still exist
         if (rows > 0 && t == 0) atomicOr(status, 8);
         for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
-        if (UP && t < GC_N) br.bias_parts[(size_t)b * H + ns0 + t] = 0.0;
+        if ((UP || POOL) && t < GC_N) br.bias_parts[(size_t)b * H + ns0 + t] = 0.0;
         for (int i = t; i < K * GC_N; i += GB_NT) slab[(size_t)(i / GC_N) * H + ns0 + i % GC_N] = 0.f;
         return;
     }
@@ -131,7 +145,16 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     // ---- every global load of the kernel, issued before the first wait ------------------------------------------
     RoBatch<float4, 2> bd, bd1, by;                      // dOut[g0 + j][ns0 + 4 n4 ..]: rows x 16 float4 (UP: dy0, dy1, y)
     RoBatch<float4, 4> bx, bw;                           // x[g0 + i][4 k4 ..]: rows x K/4;  W[k_in][ns0 + 4 n4 ..]: K x 16
-    {
+    RoBatch<float4, 2> bz;                               // POOL: z[g0 + j][ns0 + 4 n4 ..]
+    float gv = 0.f;
+    if (POOL) {
+        ro_issue<GB_NT>(by, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(br.y + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+        ro_issue<GB_NT>(bz, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(br.z + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+        if (t < GC_N) {
+            gv = br.gp0[(size_t)b * H + ns0 + t];
+            if (br.gp1) gv += br.gp1[(size_t)(br.iperm ? br.iperm[b] : b) * H + ns0 + t];
+        }
+    } else {
         const float* d0 = UP ? br.dy0 : br.dout;
         ro_issue<GB_NT>(bd, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(d0 + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
         if (UP) {
@@ -194,10 +217,12 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
             const int loc = nv[u] - g0;
             const bool inb = loc >= 0 && loc < rows;
             en[s] = inb ? loc : 0; ec[s] = inb ? cv[u] : 0.f;
+            if (POOL) ee[s] = ev[u];
             if (!inb) atomicOr(status, 16);
         }
     }
-    if (!UP) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
+    if (POOL && t < GC_N) gv_s[t] = gv;
+    if (MODE == 0) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
     ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) {
         float* d = Wt + (4 * n4) * GB_LDW + k;
         d[0] = v.x; d[GB_LDW] = v.y; d[2 * GB_LDW] = v.z; d[3 * GB_LDW] = v.w;
@@ -210,6 +235,33 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         v.z = (v.z * s - mean_s[k + 2]) * rstd_s[k + 2]; v.w = (v.w * s - mean_s[k + 3]) * rstd_s[k + 3];
         *reinterpret_cast<float4*>(Xs + i * GB_LDX + k) = v;
     });
+    if (POOL) {
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { ro_pin(by.v[u]); ro_pin(bz.v[u]); }
+        const int c = 4 * (t & 15);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int j = (t >> 4) + u * (GB_NT / 16);
+            if (j < rows) {
+                const float4 yv = by.v[u];
+                const float4 o = make_float4(yv.x > 0.f ? gv_s[c] : 0.f, yv.y > 0.f ? gv_s[c + 1] : 0.f,
+                                             yv.z > 0.f ? gv_s[c + 2] : 0.f, yv.w > 0.f ? gv_s[c + 3] : 0.f);
+                cs[0] += o.x; cs[1] += o.y; cs[2] += o.z; cs[3] += o.w;
+                *reinterpret_cast<float4*>(Ds + j * GB_LDD + c) = o;
+                *reinterpret_cast<float4*>(Zr + j * GB_LDD + c) = bz.v[u];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cs[q] += __shfl_xor(cs[q], 16, 64);
+            cs[q] += __shfl_xor(cs[q], 32, 64);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bs_s[t >> 6][lane][q] = cs[q];
+        }
+    }
     if (UP) {
         // dOut slice from the upper layer's partials: lane t always holds column group t % 16 (512 % 16 == 0), so
         // its column sums stay in registers until the cross-lane reduction below
@@ -251,11 +303,11 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     for (int i = t; i < (rowsP - rows) * GB_LDX; i += GB_NT) Xs[rows * GB_LDX + i] = 0.f;
     if (t < rows) {                                      // one lane per destination row j: its own row of the block
         const float dj = dis_s[t];
-        for (int s = ptr_s[t]; s < ptr_s[t + 1]; ++s) Ab[t * GB_LDJ + en[s]] += dj * ec[s];
+        for (int s = ptr_s[t]; s < ptr_s[t + 1]; ++s) { Ab[t * GB_LDJ + en[s]] += dj * ec[s]; if (POOL) er[s] = (short)t; }
         Ab[t * GB_LDJ + t] += dj * dj * loop_w;
     }
     __syncthreads();
-    if (UP && t < GC_N) {
+    if ((UP || POOL) && t < GC_N) {
         double tot = 0.0;
 #pragma unroll
         for (int k = 0; k < GB_NT / 64; ++k) tot += (double)bs_s[k][t >> 2][t & 3];
@@ -270,6 +322,27 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
         if (rt < R) gb_mma<1, 1, GB_LDJ, GB_LDD>(Ab + rt * 32 + li, nullptr, Ds + ct * 32 + li, nullptr, rowsP, lk, ident, acc);
+        if (POOL && w >= 4) {
+            // waves 4-7 (idle during P1): gn / gself of this slice, 4 lanes per item (16 columns each) straight from LDS
+            const int q4 = (t - 256) & 3, it0 = (t - 256) >> 2;
+            float* gn = br.gn + (size_t)sl * br.gn_stride;
+            float* gs = br.gself + (size_t)sl * br.gself_stride;
+            for (int it = it0; it - it0 < ne + rows; it += 64) {
+                const bool ok = it < ne + rows, isedge = it < ne;
+                const int itc = ok ? it : 0;
+                const int jd = isedge ? er[itc] : itc - ne, js = isedge ? en[itc] : itc - ne;      // destination / source row
+                const float4* a = reinterpret_cast<const float4*>(Ds + (ok ? jd : 0) * GB_LDD + 16 * q4);
+                const float4* bsrc = reinterpret_cast<const float4*>(Zr + (ok ? js : 0) * GB_LDD + 16 * q4);
+                float p = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p = dot4(a[k], bsrc[k], p);
+                p += __shfl_xor(p, 1, 64);
+                p += __shfl_xor(p, 2, 64);
+                if (ok && q4 == 0) {
+                    if (isedge) gn[ee[itc]] = p; else gs[g0 + itc - ne] = p;
+                }
+            }
+        }
         __syncthreads();                                 // every wave is done reading dOut
         if (rt < R) {
 #pragma unroll

@@ -755,20 +755,23 @@ __global__ void __launch_bounds__(256) k_sddmm2(const int* __restrict__ row32, c
 __global__ void __launch_bounds__(256) k_normbwd_node2(const CSR gs, const CSR gd, const float* __restrict__ att,
                                                        const float* __restrict__ dis, const float* __restrict__ gn,
                                                        const float* __restrict__ gself, float* __restrict__ ddeg,
-                                                       float loop_w, int N, int64_t E) {
+                                                       float loop_w, int N, int64_t E, const float* __restrict__ gn2,
+                                                       const float* __restrict__ gself2) {
+    // gn2 / gself2: second partial of gn / gself (one per 64-column slice of the per-graph fused backward) or null
     const int brn = blockIdx.y;
     const float* w = att + (size_t)brn * E;
     const float* di = dis + (size_t)brn * N;
     const float* g = gn + (size_t)brn * E;
+    const float* g2 = gn2 ? gn2 + (size_t)brn * E : nullptr;
     const int v = blockIdx.x * 32 + threadIdx.x / 8, l = threadIdx.x % 8;
     if (v >= N) return;
     float acc = 0.f;
-    for (int s = gs.ptr[v] + l; s < gs.ptr[v + 1]; s += 8) { const int e = gs.eid[s]; acc += g[e] * w[e] * di[gs.nbr[s]]; }
-    for (int s = gd.ptr[v] + l; s < gd.ptr[v + 1]; s += 8) { const int e = gd.eid[s]; acc += g[e] * w[e] * di[gd.nbr[s]]; }
+    for (int s = gs.ptr[v] + l; s < gs.ptr[v + 1]; s += 8) { const int e = gs.eid[s]; acc += (g[e] + (g2 ? g2[e] : 0.f)) * w[e] * di[gs.nbr[s]]; }
+    for (int s = gd.ptr[v] + l; s < gd.ptr[v + 1]; s += 8) { const int e = gd.eid[s]; acc += (g[e] + (g2 ? g2[e] : 0.f)) * w[e] * di[gd.nbr[s]]; }
     acc = group_sum<8>(acc);
     if (l == 0) {
         const float d = di[v];
-        acc += 2.f * gself[(size_t)brn * N + v] * d * loop_w;
+        acc += 2.f * (gself[(size_t)brn * N + v] + (gself2 ? gself2[(size_t)brn * N + v] : 0.f)) * d * loop_w;
         ddeg[(size_t)brn * N + v] = -0.5f * d * d * d * acc;
     }
 }
@@ -776,13 +779,14 @@ __global__ void __launch_bounds__(256) k_normbwd_node2(const CSR gs, const CSR g
 // d edge_weight of both branches -> d(edge logit 0): dl[e] = a0 a1 (dw_c - dw_o)  (softmax2 backward)
 __global__ void k_normbwd_edge(const int* __restrict__ row32, const int* __restrict__ col32, const float* __restrict__ att,
                                const float* __restrict__ dis, const float* __restrict__ gn, const float* __restrict__ ddeg,
-                               float* __restrict__ dl, int N, int64_t E) {
+                               float* __restrict__ dl, int N, int64_t E, const float* __restrict__ gn2) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const int r = row32[e], c = col32[e];
     if (r == c) { dl[e] = 0.f; return; }
-    const float dwc = gn[e] * dis[r] * dis[c] + ddeg[r];
-    const float dwo = gn[E + e] * dis[(size_t)N + r] * dis[(size_t)N + c] + ddeg[(size_t)N + r];
+    const float gc = gn[e] + (gn2 ? gn2[e] : 0.f), go = gn[E + e] + (gn2 ? gn2[E + e] : 0.f);
+    const float dwc = gc * dis[r] * dis[c] + ddeg[r];
+    const float dwo = go * dis[(size_t)N + r] * dis[(size_t)N + c] + ddeg[(size_t)N + r];
     dl[e] = att[e] * att[E + e] * (dwc - dwo);
 }
 
