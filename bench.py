@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (batch assembly included) figure")
+    ap.add_argument("--no-sequence", action="store_true", help="one hipGraph launch per step instead of one per pass over the resident batches")
     ap.add_argument("--no-engine", action="store_true", help="operator-level autograd path instead of the native step engine")
     return ap.parse_args()
 
@@ -340,12 +341,27 @@ def main():
         torch.cuda.synchronize()
 
     nb = len(batches)
-    for i in range(a.warmup):
-        trainer.step(batches[i % nb])
+    # steps i, i+1, .. walk the resident batches cyclically; on one GPU nb consecutive steps share one hipGraph launch
+    # (CausalTrainer.step_sequence), the remainder runs as single-step graphs -- K steps are K full train steps either way
+    seq = mode == "graph" and not a.no_sequence and trainer.can_sequence() and nb > 1
+
+    def run(first, count):
+        stats, i = None, first
+        while count > 0:
+            if seq and i % nb == 0 and count >= nb:
+                stats = trainer.step_sequence(batches)
+                i += nb; count -= nb
+            else:
+                stats = trainer.step(batches[i % nb])
+                i += 1; count -= 1
+        return stats
+
+    if seq:
+        trainer.step_sequence(batches)          # capture (and one run) before anything is timed
+    run(0, a.warmup)
     barrier()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        stats = trainer.step(batches[i % nb])
+    stats = run(a.warmup, a.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -365,7 +381,7 @@ def main():
         "config": {"workload": a.workload, "model": wl["model"], "batch_per_gpu": wl["batch"],
                    "global_batch": wl["batch"] * world, "hidden": wl["hidden"], "layers": wl["layers"],
                    "node_num": wl["node_num"], "mean_nodes_per_batch": nodes, "mean_edges_per_batch": edges,
-                   "launch": mode, "path": "native step engine" if trainer.engine is not None else "operator-level autograd", "parallelism": "dp%d" % world, "resident_batches": nb,
+                   "launch": mode + ("(%d steps per graph launch)" % nb if seq else ""), "path": "native step engine" if trainer.engine is not None else "operator-level autograd", "parallelism": "dp%d" % world, "resident_batches": nb,
                    "final_loss": final[0]},
     }
     if rank == 0 and world == 1:

@@ -102,6 +102,7 @@ class CausalTrainer:
             self.opt = torch.optim.Adam([self.flat_p], lr=self.lr, weight_decay=weight_decay,
                                         capturable=use_graph)
         self._graphs: Dict[int, _Captured] = {}
+        self._seqs: Dict[tuple, tuple] = {}
         self._pool = torch.cuda.graph_pool_handle() if use_graph else None
         self._opt_graph: Optional[torch.cuda.CUDAGraph] = None
         self.stats = torch.zeros(5, dtype=torch.float32, device=self.flat_p.device)
@@ -284,6 +285,39 @@ class CausalTrainer:
             self._captured(batch, self._use_device_perm(batch.num_graphs))
             if self._opt_graph is None and not self.fused_opt:
                 self._build_opt_graph()
+
+    # A hipGraph launch costs ~10 us of idle GPU between two replays of a ~0.3 ms step.  When the coming steps are
+    # known (an epoch over resident batches) they can share ONE graph: step_sequence(batches) runs len(batches)
+    # consecutive train steps -- permutation draw, forward, backward, Adam each -- per launch.  Single-GPU engine
+    # path only (with more GPUs the gradient all-reduce sits between backward and Adam, outside the graphs).
+    def can_sequence(self) -> bool:
+        return self.use_graph and self.fused_opt and self.engine is not None
+
+    def step_sequence(self, batches) -> torch.Tensor:
+        """len(batches) consecutive train steps (in this order) as one graph launch; returns the device stats tensor
+        of the LAST step.  The captured sequence is cached per tuple of batch objects."""
+        if not self.can_sequence() or not all(self._use_device_perm(b.num_graphs) for b in batches):
+            stats = None
+            for b in batches:
+                stats = self.step(b)
+            return stats
+        key = tuple(id(b) for b in batches)
+        seq = self._seqs.get(key)
+        if seq is None:
+            for b in batches:                     # per-batch state (perm buffers, warm-up) comes from the single-step capture
+                self.prepare(b)
+            caps = [self._graphs[id(b)] for b in batches]
+            snap = self._snapshot()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._pool):
+                for b, cap in zip(batches, caps):
+                    if self._shuffles():
+                        self._device_perm_into(cap.perm, b.num_graphs)
+                    stats = self._fwd_bwd(b, cap.perm, cap.stats)
+            self._restore(snap)
+            seq = self._seqs[key] = (g, stats, list(batches))
+        seq[0].replay()
+        return seq[1]
 
     def _captured(self, batch, dev_perm: bool) -> _Captured:
         cap = self._graphs.get(id(batch))

@@ -449,3 +449,40 @@ def test_per_graph_plan_equals_generic_plan_and_flags_violations():
     bad2.batch[0] = 1
     eng.forward(bad2, perm, training=True)
     assert int(eng.buffer("status", 1, dtype=torch.int32).item()) & 2
+
+
+def test_step_sequence_equals_single_steps():
+    """CausalTrainer.step_sequence (several train steps per hipGraph launch) against the same steps launched one by one:
+    identical parameters (the permutations come from the same device counter stream)."""
+    from cal_amd import model as M
+    from cal_amd.trainer import CausalTrainer
+    import random
+    _, b1 = _config2_batch(32, seed=1)
+    _, b2 = _config2_batch(32, seed=2)
+    _, b3 = _config2_batch(24, seed=3)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=32, layers=2)
+    outs = []
+    for seqmode in (False, True):
+        random.seed(7)
+        m = M.CausalGCN(10, 4, _args(layers=2, hidden=32))
+        m.load_state_dict(sd)
+        tr = CausalTrainer(m.to(DEV), _args(layers=2, hidden=32), lr=1e-2, use_graph=True)
+        tr.reserve_for([b1, b2, b3])
+        for b in (b1, b2, b3):
+            tr.prepare(b)
+        tr._perm_counter.zero_()                  # captures / warm-ups advanced it: same stream for both runs
+        snap = {k: v.clone() for k, v in m.state_dict().items()}
+        if seqmode:
+            tr.step_sequence([b1, b2, b3])        # capture pass (also a real pass): rewind everything it changed
+            m.load_state_dict(snap)
+            tr.engine.exp_avg.zero_(); tr.engine.exp_avg_sq.zero_(); tr.engine.step_count.zero_()
+            tr._perm_counter.zero_()
+        for rep in range(2):
+            if seqmode:
+                stats = tr.step_sequence([b1, b2, b3])
+            else:
+                for b in (b1, b2, b3):
+                    stats = tr.step(b)
+        outs.append((stats.clone(), tr.flat_p.clone()))
+    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-6)
+    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-6)
