@@ -1016,6 +1016,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         }));
         CAL_CHECK_LAUNCH("k_att_bwd"); STAGE();
     }
+    bool feat_done = false;     // the per-graph feature-layer backward (k_feat_bwd) has run
     // Q. backbone layers, last to first
     for (int i = L; i >= 1; --i) {
         float* dzi = e->dzi + (size_t)(i - 1) * NH;     // per layer: the side-stream dW GEMM reads it later
@@ -1045,7 +1046,25 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             double* dsum[1] = {bn_dsum(c, i)}; double* dprod[1] = {bn_dprod(c, i)};
             { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false)); } STAGE();
             RC(flush_finals(c)); STAGE();
-            if (i == 1) {       // the feature layer below is a plain GEMM: materialise dZ for it
+            if (i == 1 && F <= FB_F && H <= FB_H) {
+                // the feature layer's backward per graph, fed from this layer's partial dX' (no k_bn_bwd, no dZ round trip)
+                FeatBwdArgs fb;
+                memset(&fb, 0, sizeof(fb));
+                fb.dy0 = p0; fb.dy1 = H > GC_N ? dzi : nullptr; fb.y = hin;
+                fb.ubn = bnref(c, 1, N, 0); fb.udot_sum = bn_dsum(c, 1); fb.udot_prod = bn_dprod(c, 1);
+                fb.x0 = x0; fb.W = e->P + e->o_feat_w; fb.bn0 = bnref(c, 0, N, 0);
+                const size_t need = (size_t)B * F * H;
+                if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
+                fb.slab = e->slabs + slab_off;
+                fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, B};
+                slab_off += need;
+                d_bn0.p = parts_alloc(c, (size_t)B * 2 * F); d_bn0.P = B; d_bn0.stride = 2 * F;
+                if (!d_bn0.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+                fb.parts = d_bn0.p;
+                hipLaunchKernelGGL(k_feat_bwd, dim3(B), dim3(GB_NT), 0, st, e->gptr, fb, H, F, e->status);
+                CAL_CHECK_LAUNCH("k_feat_bwd"); STAGE();
+                feat_done = true;
+            } else if (i == 1) {       // the feature layer below is a plain GEMM: materialise dZ for it
                 BnBwdProb p{p0, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i), Acc(), H > GC_N ? dzi : nullptr};
                 RC(with_g(H, [&](auto g) {
                     constexpr int G = decltype(g)::value;
@@ -1092,7 +1111,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         }
     }
     // S. conv_feat weight and bn_feat affine gradients
-    {
+    if (!feat_done) {
         GemmArgs a = gemm_args(F, H, N, true, false, 0);
         a.p[0].A = x0; a.p[0].B = e->dZ;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 0);

@@ -401,4 +401,146 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     BLK_CLK(1);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of the feature layer h0 = relu(BN0(x0) W_feat) (model.py:90-91, a GCNConv with gfn=True: no aggregation)
+// per graph, fed like the UP variant above: dZ = BatchNorm_1-backward(dy0 + dy1) masked by h0 > 0 is built in LDS
+// from the first backbone layer's partial dX', then
+//     dW_feat (this graph's slab [F,H]) = x0_hat'^T dZ,   (sum dX0, sum dX0 * x0_hat) per feature with dX0 = dZ W_feat^T
+// (the BatchNorm_0 affine gradients).  F is small (10 for SPMotif): plain FMA loops on LDS operands; replaces k_bn_bwd +
+// the dual GEMM of the unfused path.  grid (B), 512 threads, graphs of at most FB_T nodes, F <= FB_F.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FB_T = 64, FB_F = 64, FB_H = 128;
+struct FeatBwdArgs {
+    const float* dy0; const float* dy1;      // partials of the first backbone layer's dX' (dy1 null when H == 64)
+    const float* y;                          // h0 [N,H]
+    BNRef ubn; const double* udot_sum; const double* udot_prod;     // BatchNorm_1
+    const float* x0;                         // [N,F]
+    const float* W;                          // [F,H]
+    BNRef bn0;
+    float* slab;                             // [B][F,H]
+    double* parts;                           // [B][2F]: (sum dX0, sum dX0 * x0_hat)
+};
+__global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr, const FeatBwdArgs a, int H, int F,
+                                                  int* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) float Dz[FB_T * (FB_H + 4)];     // dZ rows [j][n]
+    __shared__ float Xn[FB_T * FB_F];                    // x0_hat rows [j][f] (normalised, no affine)
+    __shared__ __attribute__((aligned(16))) float Ws[FB_F * (FB_H + 4)];     // W_feat [f][n]
+    __shared__ float um_s[FB_H], ur_s[FB_H], ug_s[FB_H], u1_s[FB_H], u2_s[FB_H];
+    __shared__ float m0_s[FB_F], r0_s[FB_F], g0_s[FB_F], b0_s[FB_F];
+    __shared__ float dX0[FB_T * FB_F];
+    const int b = blockIdx.x, t = threadIdx.x, LDZ = FB_H + 4;
+    const int g0 = gptr[b], rows = gptr[b + 1] - g0;
+    float* slab = a.slab + (size_t)b * F * H;
+    double* parts = a.parts + (size_t)b * 2 * F;
+    if (rows <= 0 || rows > FB_T) {
+        if (rows > 0 && t == 0) atomicOr(status, 8);
+        for (int i = t; i < F * H; i += GB_NT) slab[i] = 0.f;
+        for (int i = t; i < 2 * F; i += GB_NT) parts[i] = 0.0;
+        return;
+    }
+    const int H4 = H >> 2;
+    // all loads first: the two partials and h0 (rows x H/4 float4 each, <= 8 per lane), x0, W, BN constants
+    RoBatch<float4, 4> b0, b1, by, bwt;
+    const float* d1 = a.dy1 ? a.dy1 : a.dy0;
+    ro_issue<GB_NT>(b0, rows, H4, [&](int j, int c) { return *reinterpret_cast<const float4*>(a.dy0 + (size_t)(g0 + j) * H + 4 * c); });
+    ro_issue<GB_NT>(b1, rows, H4, [&](int j, int c) { return *reinterpret_cast<const float4*>(d1 + (size_t)(g0 + j) * H + 4 * c); });
+    ro_issue<GB_NT>(bwt, F, H4, [&](int f, int c) { return *reinterpret_cast<const float4*>(a.W + (size_t)f * H + 4 * c); });
+    ro_issue<GB_NT>(by, rows, H4, [&](int j, int c) { return *reinterpret_cast<const float4*>(a.y + (size_t)(g0 + j) * H + 4 * c); });
+    float xr[8];                                         // x0[g0 .. g0 + rows) is contiguous: rows * F <= 4096 floats
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xr[u] = a.x0[(size_t)g0 * F + min(t + u * GB_NT, rows * F - 1)];
+    if (t < H) {
+        float m1[1], r1[1];
+        bn_mean_rstd_v<1>(a.ubn, t, m1, r1);
+        um_s[t] = m1[0]; ur_s[t] = r1[0];
+        ug_s[t] = (a.ubn.gamma ? a.ubn.gamma[t] : 1.f) * r1[0];
+        u1_s[t] = (float)(a.udot_sum[t] * (double)a.ubn.inv_n);
+        u2_s[t] = (float)(a.udot_prod[t] * (double)a.ubn.inv_n);
+    } else if (t - 128 < F && t >= 128) {
+        const int f = t - 128;
+        float m1[1], r1[1];
+        bn_mean_rstd_v<1>(a.bn0, f, m1, r1);
+        m0_s[f] = m1[0]; r0_s[f] = r1[0];
+        g0_s[f] = a.bn0.gamma ? a.bn0.gamma[f] : 1.f;
+        b0_s[f] = a.bn0.beta ? a.bn0.beta[f] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(xr[u]));
+    ro_commit<GB_NT>(bwt, F, H4, [&](int f, int c, const float4 v) { *reinterpret_cast<float4*>(Ws + f * LDZ + 4 * c) = v; });
+    __syncthreads();
+    {
+        const bool two = a.dy1 != nullptr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ro_pin(b1.v[u]); ro_pin(by.v[u]); }
+        // item (u, t) of a rows x H4 grid: walked like ro_commit does
+        const int q = GB_NT / H4, r = GB_NT % H4;
+        int row = t / H4, col = t % H4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ro_pin(b0.v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (t + u * GB_NT < rows * H4) {
+                const float4 v0 = b0.v[u], v1 = b1.v[u], yv = by.v[u];
+                const int c = 4 * col;
+                const float d[4] = {v0.x + (two ? v1.x : 0.f), v0.y + (two ? v1.y : 0.f), v0.z + (two ? v1.z : 0.f), v0.w + (two ? v1.w : 0.f)};
+                const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float yn = (yy[k] - um_s[c + k]) * ur_s[c + k];
+                    const float g1 = ug_s[c + k] * (d[k] - u1_s[c + k] - yn * u2_s[c + k]);
+                    o[k] = yy[k] > 0.f ? g1 : 0.f;
+                }
+                *reinterpret_cast<float4*>(Dz + row * LDZ + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            row += q; col += r;
+            if (col >= H4) { col -= H4; ++row; }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = t + u * GB_NT;
+            if (i < rows * F) { const int f = i % F; Xn[(i / F) * FB_F + f] = (xr[u] - m0_s[f]) * r0_s[f]; }
+        }
+    }
+    __syncthreads();
+    // dW_feat slab: output (f, 4 consecutive n), reduction over the graph's rows; x0_hat' = gamma0 x0_hat + beta0
+    for (int o = t; o < F * H4; o += GB_NT) {
+        const int f = o / H4, n = 4 * (o % H4);
+        const float gam = g0_s[f], bet = b0_s[f];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int j = 0; j < rows; ++j) {
+            const float xv = fmaf(Xn[j * FB_F + f], gam, bet);
+            const float4 d = *reinterpret_cast<const float4*>(Dz + j * LDZ + n);
+            acc.x = fmaf(xv, d.x, acc.x); acc.y = fmaf(xv, d.y, acc.y); acc.z = fmaf(xv, d.z, acc.z); acc.w = fmaf(xv, d.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(slab + (size_t)f * H + n) = acc;
+    }
+    // BatchNorm_0 backward sums: dX0[j][f] = <dZ[j], W[f]>: lane = (row j = t / 4, quarter qn of the H columns) keeps its
+    // quarter row of dZ in registers and walks the features; then one lane per feature sums over the rows (fixed order)
+    {
+        const int j = (t & 255) >> 2, qn = t & 3, nq4 = H >> 4;  // float4s per quarter row (H % 16 == 0)
+        const int fh = (F + 1) >> 1, f_lo = t < 256 ? 0 : fh, f_hi = t < 256 ? fh : F;     // the two halves of the block split the features
+        float4 dz[FB_H / 16];
+#pragma unroll
+        for (int k = 0; k < FB_H / 16; ++k)
+            dz[k] = k < nq4 ? *reinterpret_cast<const float4*>(Dz + min(j, rows - 1) * LDZ + 4 * (qn * nq4 + k)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int f = f_lo; f < f_hi; ++f) {
+            const float4* wr = reinterpret_cast<const float4*>(Ws + f * LDZ) + qn * nq4;
+            float p = 0.f;
+#pragma unroll
+            for (int k = 0; k < FB_H / 16; ++k) if (k < nq4) p = dot4(dz[k], wr[k], p);
+            p += __shfl_xor(p, 1, 64);
+            p += __shfl_xor(p, 2, 64);
+            if (qn == 0 && j < rows) dX0[j * FB_F + f] = p;
+        }
+    }
+    __syncthreads();
+    if (t < F) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int j = 0; j < rows; ++j) { const double v = (double)dX0[j * FB_F + t]; s1 += v; s2 += v * (double)Xn[j * FB_F + t]; }
+        parts[t] = s1; parts[F + t] = s2;
+    }
+}
+
 }  // namespace cal
