@@ -606,6 +606,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     const size_t NH = (size_t)N * H;
     // per-graph plan (engine_plan.hpp) when the host vouches for the batch layout
     const bool fast_plan = e->node_ptr && e->edge_ptr && B > 0 && e->max_nodes > 0 && e->max_nodes <= GP_T && e->max_edges <= GP_E;
+    const bool plan_stats = fast_plan && c.training && F <= 64;      // bn_feat's statistics ride in k_plan_graph
     // 0. zero the fp64 arena and the GraphPlan counters (one kernel, not memset nodes)
     {
         const int64_t ni = fast_plan ? 0 : 4 * ((int64_t)N + 1);
@@ -617,7 +618,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     if (fast_plan) {
         hipLaunchKernelGGL(k_plan_graph, dim3(B), dim3(256), 0, st, edge_index, E, N, B, e->node_ptr, e->edge_ptr, batch, e->loop_w,
                            e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src, e->row32, e->col32,
-                           e->gptr, e->eptr, e->dis_unit, e->status);
+                           e->gptr, e->eptr, e->dis_unit, e->status, plan_stats ? x0 : nullptr, F, bn_stsum(c, 0), bn_stsq(c, 0));
         CAL_CHECK_LAUNCH("k_plan_graph"); STAGE();
     } else {
         RC(plan_build(edge_index, E, N, e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
@@ -629,7 +630,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     const CSR gd{e->rowptr_dst, e->nbr_dst, e->eid_dst, (int)c.E}, gs{e->rowptr_src, e->nbr_src, e->eid_src, (int)c.E};
     (void)gs;
     // 2. bn_feat statistics (model.py:90)
-    if (c.training) {
+    if (c.training && !plan_stats) {
         int tc = std::min(256, pow2ceil(F));
         int rpb = std::max(128, cdiv(N, 256));
         hipLaunchKernelGGL(k_colstats, dim3(cdiv(N, rpb)), dim3(256), 0, st, x0, N, F, tc, rpb, Acc(bn_stsum(c, 0)), Acc(bn_stsq(c, 0)));

@@ -25,7 +25,12 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
                                                     int* __restrict__ ptr_dst, int* __restrict__ nbr_dst, int* __restrict__ eid_dst,
                                                     int* __restrict__ ptr_src, int* __restrict__ nbr_src, int* __restrict__ eid_src,
                                                     int* __restrict__ row32, int* __restrict__ col32, int* __restrict__ gptr,
-                                                    int* __restrict__ eptr, float* __restrict__ dis_unit, int* __restrict__ status) {
+                                                    int* __restrict__ eptr, float* __restrict__ dis_unit, int* __restrict__ status,
+                                                    const float* __restrict__ x0, int F, double* __restrict__ st_sum,
+                                                    double* __restrict__ st_sq) {
+    // x0 != null: also the column sums / sums of squares of the raw features (bn_feat's batch statistics, model.py:90;
+    // F <= 64), pre-reduced per graph in LDS and added to the zeroed accumulators with F fp64 atomics per workgroup
+    __shared__ double fs[2][64];
     __shared__ int deg_in[GP_T], deg_out[GP_T], off_in[GP_T + 1], off_out[GP_T + 1], cur_in[GP_T], cur_out[GP_T];
     __shared__ short rl[GP_E], cl[GP_E];                 // local endpoints of the graph's edges (edge-id order)
     __shared__ short tn_d[GP_E], te_d[GP_E], tn_s[GP_E], te_s[GP_E];     // unordered row contents: neighbour, local edge id
@@ -50,7 +55,22 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     }
     const int64_t bv = rows > 0 ? batch[g0 + min(t, rows - 1)] : (int64_t)b;
     if (t < GP_T) { deg_in[t] = 0; deg_out[t] = 0; cur_in[t] = 0; cur_out[t] = 0; }
+    if (t < 128) fs[t >> 6][t & 63] = 0.0;
     __syncthreads();
+    if (x0) {
+        for (int i0 = t; i0 - t < rows * F; i0 += 4 * 256) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x0[(size_t)g0 * F + min(i0 + u * 256, rows * F - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                if (i < rows * F) { const double d = (double)v[u]; atomicAdd(&fs[0][i % F], d); atomicAdd(&fs[1][i % F], d * d); }
+            }
+        }
+    }
     if (t < rows && bv != b) atomicOr(status, 2);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -85,6 +105,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
         if (l == 63) off[rows] = x;                      // the total (rows == 128 has no lane for it above)
     }
     __syncthreads();
+    if (x0 && t < F) { atomicAdd(st_sum + t, fs[0][t]); atomicAdd(st_sq + t, fs[1][t]); }
     if (t < rows) {
         ptr_dst[g0 + t] = (int)e0 + off_in[t];
         ptr_src[g0 + t] = (int)e0 + off_out[t];
