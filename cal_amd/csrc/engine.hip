@@ -686,8 +686,23 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         RC(flush_finals(c)); STAGE();
     }
     const float* x = e->h + (size_t)L * NH;
+    // 5+6 per graph: node attention, edge softmax and weighted degrees in one kernel (4 rows per lane group)
+    const bool att_graph = gc && e->max_nodes <= 4 * (512 / group_for(H, 4));
+    if (att_graph) {
+        const Acc a0 = graph_acc(c, bn_stsum(c, L + 1), H), a1 = graph_acc(c, bn_stsq(c, L + 1), H);
+        const Acc a2 = graph_acc(c, bn_stsum(c, L + 2), H), a3 = graph_acc(c, bn_stsq(c, L + 2), H);
+        RC(with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL((k_att_fwd_graph<4, G>), dim3(B), dim3(512), 0, st, e->gptr, gs, x, e->P + e->o_natt_w, e->P + e->o_natt_b,
+                               e->P + e->o_eatt_w, e->P + e->o_eatt_b, e->anode, e->pq, e->att, e->dis_co, e->dis_co + N, a0, a1, a2, a3,
+                               e->loop_w, H, E, e->status);
+            return 0;
+        }));
+        CAL_CHECK_LAUNCH("k_att_fwd_graph"); STAGE();
+        RC(flush_finals(c)); STAGE();
+    }
     // 5. node attention, edge projections, bnc/bno statistics (model.py:97-111)
-    {
+    if (!att_graph) {
         const Acc a0 = node_acc(c, bn_stsum(c, L + 1), H), a1 = node_acc(c, bn_stsq(c, L + 1), H);
         const Acc a2 = node_acc(c, bn_stsum(c, L + 2), H), a3 = node_acc(c, bn_stsq(c, L + 2), H);
         RC(with_g(H, [&](auto g) {
@@ -700,9 +715,11 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         RC(flush_finals(c)); STAGE();
     }
     // 6. edge softmax + weighted degrees (model.py:102-104, gcn_conv.py:63-68)
-    hipLaunchKernelGGL(k_edge_att_deg, dim3(cdiv(N, 32)), dim3(256), 0, st, gs, e->pq, e->P + e->o_eatt_b, e->att, e->dis_co,
-                       e->dis_co + N, e->loop_w, N, E);
-    CAL_CHECK_LAUNCH("k_edge_att_deg"); STAGE();
+    if (!att_graph) {
+        hipLaunchKernelGGL(k_edge_att_deg, dim3(cdiv(N, 32)), dim3(256), 0, st, gs, e->pq, e->P + e->o_eatt_b, e->att, e->dis_co,
+                           e->dis_co + N, e->loop_w, N, E);
+        CAL_CHECK_LAUNCH("k_edge_att_deg"); STAGE();
+    }
     // 7-9 fused: both weighted convolutions and the add-pool in one per-graph launch
     if (gc) {
         GconvBranch gb[2];

@@ -143,4 +143,103 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Node attention + edge attention + weighted degrees of one graph in one kernel (k_node_att_fwd's fast path followed
+// by k_edge_att_deg, model.py:97-111, gcn_conv.py:63-68): an edge's two endpoints are in the same graph, so the edge
+// softmax reads the projections P[row] / Q[col] from LDS right after they are computed.
+//   grid (B), 512 threads = 512/G row groups of G lanes x VEC columns; at most 4 rows per group (64 nodes at H = 128).
+//   Column statistics of a0 x / a1 x: one partial row per graph (Acc.parts indexed by blockIdx.x).
+// ------------------------------------------------------------------------------------------------------------------
+template <int VEC, int G>
+__global__ void __launch_bounds__(512) k_att_fwd_graph(const int* __restrict__ gptr, const CSR gs, const float* __restrict__ x,
+                                                       const float* __restrict__ Wn, const float* __restrict__ bn,
+                                                       const float* __restrict__ We, const float* __restrict__ be,
+                                                       float* __restrict__ anode, float* __restrict__ pq, float* __restrict__ att,
+                                                       float* __restrict__ dis_c, float* __restrict__ dis_o, const Acc stc_sum,
+                                                       const Acc stc_sq, const Acc sto_sum, const Acc sto_sq, float loop_w, int H,
+                                                       int64_t E, int* __restrict__ status) {
+    constexpr int RPB = 512 / G, MAXR = 4 * RPB;
+    __shared__ double lds[4 * 512 * (VEC == 4 ? 4 : 1)];
+    __shared__ float4 pq_s[MAXR];
+    const int b = blockIdx.x, t = threadIdx.x, grp = t / G, l = t % G;
+    const int g0 = gptr[b], rows = gptr[b + 1] - g0;
+    using V = Vec<VEC>;
+    const int c = l * VEC, cc = min(c, H - VEC);
+    const bool cok = c < H;
+    double sc1[VEC], sc2[VEC], so1[VEC], so2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sc1[j] = sc2[j] = so1[j] = so2[j] = 0.0; }
+    if (rows > MAXR) { if (t == 0) atomicOr(status, 8); }
+    else if (rows > 0) {
+        V w[6], xv[4];
+        w[0] = V::ld(Wn + cc); w[1] = V::ld(Wn + H + cc); w[2] = V::ld(We + cc);
+        w[3] = V::ld(We + 2 * H + cc); w[4] = V::ld(We + H + cc); w[5] = V::ld(We + 3 * H + cc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = V::ld(x + (size_t)(g0 + min(grp + u * RPB, rows - 1)) * H + cc);
+        const float b0 = bn[0], b1 = bn[1];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) w[u].pin();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xv[u].pin(); if (!cok) xv[u] = V::zero(); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = grp + u * RPB;
+            const float l0 = group_sum<G>(xv[u].dot(w[0])) + b0, l1 = group_sum<G>(xv[u].dot(w[1])) + b1;
+            const float p0 = group_sum<G>(xv[u].dot(w[2])), p1 = group_sum<G>(xv[u].dot(w[3]));
+            const float q0 = group_sum<G>(xv[u].dot(w[4])), q1 = group_sum<G>(xv[u].dot(w[5]));
+            const float m = fmaxf(l0, l1);
+            const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+            const float inv = 1.f / (e0 + e1), a0 = e0 * inv, a1 = e1 * inv;
+            if (i < rows) {
+                if (l == 0) {
+                    const size_t v = (size_t)(g0 + i);
+                    anode[2 * v] = a0;
+                    anode[2 * v + 1] = a1;
+                    const float4 pv = make_float4(p0, p1, q0, q1);
+                    *reinterpret_cast<float4*>(pq + 4 * v) = pv;
+                    pq_s[i] = pv;
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const double xc = (double)(a0 * xv[u].get(j)), xo = (double)(a1 * xv[u].get(j));
+                    sc1[j] += xc; sc2[j] += xc * xc; so1[j] += xo; so2[j] += xo * xo;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {                      // (also the barrier that publishes pq_s)
+        const double v4[4] = {sc1[j], sc2[j], so1[j], so2[j]};
+        double o4[4];
+        block_col_sums<4>(v4, l * VEC + j, grp, RPB, G * VEC, cok, lds, o4);
+        if (grp == 0 && cok) { stc_sum.add(c + j, o4[0]); stc_sq.add(c + j, o4[1]); sto_sum.add(c + j, o4[2]); sto_sq.add(c + j, o4[3]); }
+    }
+    if (rows <= 0 || rows > MAXR) return;
+    // edge softmax (model.py:102-104) + weighted degrees, 8 lanes per source node over its out-edges
+    const float e_b0 = be[0], e_b1 = be[1];
+    for (int i = t >> 3; i < rows; i += 64) {
+        const int l8 = t & 7, v = g0 + i;
+        const float4 pv = pq_s[i];
+        float dc = 0.f, dq = 0.f;
+        for (int s = gs.ptr[v] + l8; s < gs.ptr[v + 1]; s += 8) {
+            const int d = gs.nbr[s] - g0, e = gs.eid[s];
+            const float4 qd = pq_s[min(max(d, 0), rows - 1)];
+            const float l0 = pv.x + qd.z + e_b0, l1 = pv.y + qd.w + e_b1;
+            const float m = fmaxf(l0, l1);
+            const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+            const float inv = 1.f / (e0 + e1);
+            const float a0 = e0 * inv, a1 = e1 * inv;
+            att[e] = a0;
+            att[E + e] = a1;
+            dc += a0; dq += a1;
+        }
+        dc = group_sum<8>(dc); dq = group_sum<8>(dq);
+        if (l8 == 0) {
+            dc += loop_w; dq += loop_w;
+            dis_c[v] = dc == 0.f ? 0.f : 1.0f / sqrtf(dc);
+            dis_o[v] = dq == 0.f ? 0.f : 1.0f / sqrtf(dq);
+        }
+    }
+}
+
 }  // namespace cal
