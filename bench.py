@@ -29,9 +29,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (model, node_num, hidden, layers, batch, num_features, num_classes)
-    "spmotif_b0.9_causalgcn_h128_l3_bs128": dict(model="CausalGCN", node_num=7, hidden=128, layers=3, batch=128),
-    "spmotif_b0.9_causalgat_h128_l3_bs128": dict(model="CausalGAT", node_num=7, hidden=128, layers=3, batch=128),
+    # BASELINE.json configs[1] (the headline) first; the others are SURVEY.md 8d's configs 3-5 on synthetic
+    # stand-ins (cal_amd/synth.py), selectable with --workload -- the default run measures the headline only
+    "spmotif_b0.9_causalgcn_h128_l3_bs128": dict(model="CausalGCN", data="spmotif", node_num=7, hidden=128, layers=3, batch=128, nfeat=10, ncls=4),
+    "spmotif_b0.9_causalgat_h128_l3_bs128": dict(model="CausalGAT", data="spmotif", node_num=7, hidden=128, layers=3, batch=128, nfeat=10, ncls=4),
+    "mutaglike_causalgat_h128_l3_bs64": dict(model="CausalGAT", data="mutag", node_num=18, hidden=128, layers=3, batch=64, nfeat=109, ncls=2),
+    "nci1like_causalgcn_h128_l3_bs512": dict(model="CausalGCN", data="nci1", node_num=30, hidden=128, layers=3, batch=512, nfeat=139, ncls=2),
+    "ba5000_causalgat_h256_l3_bs32": dict(model="CausalGAT", data="ba", node_num=5000, hidden=256, layers=3, batch=32, nfeat=10, ncls=4),
+    "ba5000_causalgcn_h256_l3_bs32": dict(model="CausalGCN", data="ba", node_num=5000, hidden=256, layers=3, batch=32, nfeat=10, ncls=4),
 }
 
 
@@ -58,10 +63,18 @@ def model_args(wl):
                               fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
 
 
+def make_graphs(wl, n, seed):
+    from cal_amd import spmotif, synth
+    if wl["data"] == "spmotif":
+        return spmotif.train_mix(n, bias=0.9, node_num=wl["node_num"], seed=seed)
+    if wl["data"] == "ba":
+        return synth.ba_graphs(n, n=wl["node_num"], seed=seed)
+    return synth.tu_like(n, kind=wl["data"], seed=seed)
+
+
 def make_batches(wl, nb, seed):
-    from cal_amd import spmotif
     from cal_amd.data import Batch
-    gs = spmotif.train_mix(nb * wl["batch"], bias=0.9, node_num=wl["node_num"], seed=seed)
+    gs = make_graphs(wl, nb * wl["batch"], seed)
     return [Batch.from_data_list(gs[i * wl["batch"]:(i + 1) * wl["batch"]]) for i in range(nb)]
 
 
@@ -73,8 +86,8 @@ def cpu_baseline(wl, batches_cpu, seconds):
     from oracle import cal_oracle as O
     cores = os.cpu_count() or 1
     torch.manual_seed(666)
-    sd = O.init_state(wl["model"], 10, 4, hidden=wl["hidden"], layers=wl["layers"], heads=4)
-    tr = O.CpuTrainer(wl["model"], sd, 4, lr=1e-3, layers=wl["layers"], heads=4)
+    sd = O.init_state(wl["model"], wl["nfeat"], wl["ncls"], hidden=wl["hidden"], layers=wl["layers"], heads=4)
+    tr = O.CpuTrainer(wl["model"], sd, wl["ncls"], lr=1e-3, layers=wl["layers"], heads=4)
     nb = len(batches_cpu)
 
     def one(i):
@@ -239,15 +252,15 @@ def end_to_end(wl, margs, steps=60):
     shuffled permutation, on-device collate of a device-resident dataset (cal_collate), eager
     engine step (shapes change every step, so no graph replay) -- next to the same loop fed by the
     host-side Python collate the reference's DataLoader does."""
-    from cal_amd import model as M, spmotif
+    from cal_amd import model as M
     from cal_amd.data import DataLoader
     from cal_amd.device_data import DeviceDataset, DeviceLoader
     from cal_amd.trainer import CausalTrainer
-    gs = spmotif.train_mix(16 * wl["batch"], bias=0.9, node_num=wl["node_num"], seed=4242)
+    gs = make_graphs(wl, 16 * wl["batch"], seed=4242)
     res = {}
     for kind in ("device_collate", "host_collate"):
         torch.manual_seed(1)
-        model = getattr(M, wl["model"])(10, 4, margs).cuda()
+        model = getattr(M, wl["model"])(wl["nfeat"], wl["ncls"], margs).cuda()
         tr = CausalTrainer(model, margs, lr=1e-3, use_graph=False)
         ds = DeviceDataset(gs) if kind == "device_collate" else None
 
@@ -311,7 +324,7 @@ def main():
     np.random.seed(seed)
     random.seed(seed + rank)
     margs = model_args(wl)
-    model = getattr(M, wl["model"])(10, 4, margs).cuda()
+    model = getattr(M, wl["model"])(wl["nfeat"], wl["ncls"], margs).cuda()
     if world > 1:   # identical replicas
         for p in model.parameters():
             dist.broadcast(p.data, 0)
@@ -331,7 +344,7 @@ def main():
         except Exception as exc:   # capture unsupported -> measured eagerly, and said so
             sys.stderr.write("graph capture failed (%r); falling back to eager launches\n" % (exc,))
             mode = "eager"
-            model = getattr(M, wl["model"])(10, 4, margs).cuda()
+            model = getattr(M, wl["model"])(wl["nfeat"], wl["ncls"], margs).cuda()
             trainer = CausalTrainer(model, margs, lr=1e-3, use_graph=False, world_size=world, use_engine=use_engine)
             trainer.reserve_for(batches)
 

@@ -145,6 +145,13 @@ struct Engine {
     float* coef;                // [3][E] edge coefficients dis_j * w_e in CSR-by-destination slot order: unit, context, objects
     int max_nodes, max_edges;   // per-graph bounds of the coming batches (0 = unknown): cal_engine_set_graph_bounds
     const int64_t *node_ptr, *edge_ptr;   // [B+1] device arrays of the coming batch (null = unknown): cal_engine_set_graph_ptrs
+    // GATConv backbone (CausalGAT, model.py:340,390): K heads (0 = GCNConv backbone), attention dropout p with
+    // per-layer seeds and an optional device step counter, att [K, 2D] parameter offsets
+    int K; float gat_p, gat_slope;
+    uint64_t gat_seed[MAX_LAYERS];
+    unsigned long long* gat_ctr;
+    int o_conv_att[MAX_LAYERS];
+    float *gz, *gsc, *gws;      // per layer: z = BN(h) W [L][N,H]; a_dst, a_src, max, denominator [L][4][N,K]; backward scratch
 };
 
 static size_t al(size_t n) { return (n + 63) / 64 * 64; }   // 256 B granules (in floats/ints)
@@ -154,10 +161,21 @@ static size_t al(size_t n) { return (n + 63) / 64 * 64; }   // 256 B granules (i
 using namespace cal;
 
 namespace cal {
+int gat_forward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst, const float* z,
+                const float* att, const float* bias, int relu, float slope, float p, uint64_t seed, const uint64_t* ctr,
+                float* out, float* adst, float* asrc, float* mx, float* den, int64_t N, int64_t E,
+                int64_t K, int64_t D, hipStream_t stream);
+int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst,
+                 const int32_t* rowptr_src, const int32_t* nbr_src, const int32_t* eid_src, const float* z,
+                 const float* att, const float* adst, const float* asrc, const float* mx, const float* den,
+                 const float* gout, float slope, float p, uint64_t seed, const uint64_t* ctr, float* dz, float* datt,
+                 float* ws, int64_t N, int64_t E, int64_t K, int64_t D, hipStream_t stream);
 int plan_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
                int32_t* rowptr_src, int32_t* nbr_src, int32_t* eid_src, int32_t* row32, int32_t* col32, int32_t* work,
                int32_t* status, bool prezeroed, hipStream_t stream);
 }
+
+extern "C" int64_t cal_gat_bwd_ws(int64_t N, int64_t E, int64_t K, int64_t D);
 
 // cfg: [F, H, C, L].  Returns an opaque handle (0 on failure).
 CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
@@ -284,7 +302,28 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     I32(e->iperm, B);
     I32(e->eptr, B + 1);
     F32(e->coef, 3 * E);
+    if (e->K > 0) {
+        const size_t K = e->K;
+        F32(e->gz, (L > 0 ? L : 1) * N * H); F32(e->gsc, (L > 0 ? L : 1) * 4 * al(N * K));
+        F32(e->gws, (size_t)cal_gat_bwd_ws(N, E, K, H / K));
+    }
     return off * 4;
+}
+
+// Switch the backbone to GATConv(H, H/heads, heads, dropout=p) layers (model.py:340,390).  att_offs[i]: float offset of
+// convs.i.att [heads, 2*H/heads] inside P / G; seeds[i]: attention-dropout seed of layer i; ctr: device counter the
+// engine advances once per training step and folds into the seeds (null: the seeds are used as given -- tests).
+// Call before cal_engine_workspace_bytes / cal_engine_set_workspace (the layout grows by the saved GAT activations).
+CAL_EXPORT int cal_engine_set_gat(void* h, int64_t heads, float p, float slope, const int64_t* att_offs,
+                                  const uint64_t* seeds, void* ctr) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(heads > 0 && e->H % heads == 0, "heads must divide hidden");
+    const int64_t D = e->H / heads;
+    CAL_REQUIRE(D % 4 == 0 && ((D / 4) & (D / 4 - 1)) == 0, "head dim must be 4 * a power of two");
+    CAL_REQUIRE(p >= 0.f && p < 1.f, "dropout p must be in [0,1)");
+    e->K = (int)heads; e->gat_p = p; e->gat_slope = slope; e->gat_ctr = (unsigned long long*)ctr;
+    for (int i = 0; i < e->L; ++i) { e->o_conv_att[i] = (int)att_offs[i]; e->gat_seed[i] = seeds[i]; }
+    return 0;
 }
 
 CAL_EXPORT int64_t cal_engine_workspace_bytes(void* h, int64_t N, int64_t E, int64_t B) {
@@ -611,7 +650,8 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     {
         const int64_t ni = fast_plan ? 0 : 4 * ((int64_t)N + 1);
         hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256)), dim3(256), 0, st, e->arena,
-                           (int64_t)e->arena_n, e->work, ni, e->status);
+                           (int64_t)e->arena_n, e->work, ni, e->status,
+                           (e->K > 0 && c.training && want_grad) ? e->gat_ctr : nullptr);
         CAL_CHECK_LAUNCH("k_zero_f64"); STAGE();
     }
     // 1. GraphPlan
@@ -647,8 +687,34 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     }
     // 4. backbone: h_i = relu(A_hat (BN_i(h_{i-1}) @ W_i) + b_i)   (model.py:93-95)
     const bool gc = use_gc(c);
+    const bool gat = e->K > 0;
     for (int i = 1; i <= L; ++i) {
-        if (gc) {        // GEMM + aggregation + statistics in one per-graph kernel
+        if (gat) {       // z = BN_i(h) W_i; attention scores, edge softmax (+dropout), aggregation, bias, ReLU (GATConv)
+            const int K = e->K, D = H / K;
+            float* zi = e->gz + (size_t)(i - 1) * NH;
+            float* sc = e->gsc + (size_t)(i - 1) * 4 * al((size_t)e->capN * K);
+            const size_t nk = al((size_t)e->capN * K);
+            GemmArgs a = gemm_args(N, H, H, false, false, 0);
+            a.p[0].A = e->h + (size_t)(i - 1) * NH; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = zi;
+            a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 1);
+            { ProfScope ps(st, 0, 2.0 * N * H * H); RC(fwd_gemm(c, false, a, 1)); } STAGE();
+            float* hi = e->h + (size_t)i * NH;
+            {
+                ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * (8 + 12.0 * K) + (N + 1) * 4.0);
+                RC(gat_forward(e->rowptr_dst, e->nbr_dst, e->eid_dst, zi, e->P + e->o_conv_att[i - 1], e->P + e->o_conv_b[i - 1], 1,
+                               e->gat_slope, c.training ? e->gat_p : 0.f, e->gat_seed[i - 1], (const uint64_t*)e->gat_ctr, hi,
+                               sc, sc + nk, sc + 2 * nk, sc + 3 * nk, N, E, K, D, st));
+            }
+            STAGE();
+            if (c.training && i < L) {
+                int tc = std::min(256, pow2ceil(H));
+                int rpb = std::max(32, cdiv(N, 1024));
+                hipLaunchKernelGGL(k_colstats, dim3(cdiv(N, rpb)), dim3(256), 0, st, hi, N, H, tc, rpb, Acc(bn_stsum(c, i + 1)), Acc(bn_stsq(c, i + 1)));
+                CAL_CHECK_LAUNCH("k_colstats"); STAGE();
+            }
+            continue;
+        }
+        if (gc) {        // GCNConv: GEMM + aggregation + statistics in one per-graph kernel
             GconvBranch gb;
             memset(&gb, 0, sizeof(gb));
             gb.x = e->h + (size_t)(i - 1) * NH; gb.W = e->P + e->o_conv_w[i - 1]; gb.bias = e->P + e->o_conv_b[i - 1];
@@ -1038,7 +1104,8 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     // Q. backbone layers, last to first
     for (int i = L; i >= 1; --i) {
         float* dzi = e->dzi + (size_t)(i - 1) * NH;     // per layer: the side-stream dW GEMM reads it later
-        if (gcb) {
+        const bool gat = e->K > 0;
+        if (gcb && !gat) {
             // Layer i reads dOut = e->dZ (i == L, written by k_att_bwd) or builds it while staging from layer i+1's
             // partial dX' (BatchNorm_{i+1}-backward + ReLU mask fused in: no k_bn_bwd launch, no dZ round trip);
             // slice-0 partials ping-pong between dXh and z (idle in the fused forward), slice-1 partials are per layer.
@@ -1093,16 +1160,26 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             }
             continue;
         }
-        SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
-        {
+        if (gat) {       // dz_i and d att_i from dOut_i (GATConv backward; alpha recomputed from the saved max / denominator)
+            const int K = e->K, D = H / K;
+            const size_t nk = al((size_t)e->capN * K);
+            const float* sc = e->gsc + (size_t)(i - 1) * 4 * nk;
+            ProfScope ps(st, 1, 4.0 * N * H * 4 + (double)(c.E + N) * (16 + 24.0 * K));
+            RC(gat_backward(e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
+                            e->gz + (size_t)(i - 1) * NH, e->P + e->o_conv_att[i - 1], sc, sc + nk, sc + 2 * nk, sc + 3 * nk, e->dZ,
+                            e->gat_slope, c.training ? e->gat_p : 0.f, e->gat_seed[i - 1], (const uint64_t*)e->gat_ctr, dzi,
+                            e->G + e->o_conv_att[i - 1], e->gws, N, c.E, K, D, st));
+        } else {
+            SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
             ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0);
             RC(with_g(H, [&](auto g) {
                 constexpr int G = decltype(g)::value;
                 hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, br, br, 0, e->loop_w, N, H, spmm_rpb(H, false));
                 return 0;
             }));
+            CAL_CHECK_LAUNCH("k_espmm(T)");
         }
-        CAL_CHECK_LAUNCH("k_espmm(T)"); STAGE();
+        STAGE();
         const float* hin = e->h + (size_t)(i - 1) * NH;
         {
             GemmArgs a = gemm_args(H, H, N, true, false, 0);

@@ -115,11 +115,14 @@ __global__ void __launch_bounds__(256) k_stats_final(const FinalArgs fa) {
 }
 
 // zero the fp64 arena, the GraphPlan degree counters / cursors and the status word in one launch
-__global__ void k_zero_f64(double* __restrict__ a, int64_t n, int* __restrict__ ints, int64_t ni, int* __restrict__ status) {
+// (and, for a GAT backbone in training, advance the attention-dropout step counter: one fresh mask per step)
+__global__ void k_zero_f64(double* __restrict__ a, int64_t n, int* __restrict__ ints, int64_t ni, int* __restrict__ status,
+                           unsigned long long* __restrict__ tick) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = 0.0;
     if (i < ni) ints[i] = 0;
     if (i == 0 && status) *status = 0;
+    if (i == 0 && tick) *tick += 1;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -29,6 +29,12 @@ __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t id, int k, in
     return ((float)r * (1.0f / 4294967296.0f)) >= p ? inv_keep : 0.f;
 }
 
+// Inside a replayed hipGraph the seed argument is frozen; the engine passes the address of its per-step device
+// counter so every training step still draws a fresh mask (null: the seed is used as given).
+__device__ __forceinline__ uint64_t step_seed(uint64_t seed, const uint64_t* ctr) {
+    return ctr ? seed + *ctr * 0x9E3779B97F4A7C15ull : seed;
+}
+
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 
 // thread per (node, head)
@@ -55,8 +61,10 @@ __global__ void __launch_bounds__(256) k_gat_fwd(const int* __restrict__ rowptr,
                                                  const float* __restrict__ adst, const float* __restrict__ asrc,
                                                  const float* __restrict__ bias, int relu, float slope, float p,
                                                  uint64_t seed, int64_t E, float* __restrict__ out,
-                                                 float* __restrict__ mx, float* __restrict__ den, int N, int K, int D) {
+                                                 float* __restrict__ mx, float* __restrict__ den, int N, int K, int D,
+                                                 const uint64_t* __restrict__ ctr) {
     constexpr int RPB = 256 / G;
+    seed = step_seed(seed, ctr);
     const int g = threadIdx.x / G, l = threadIdx.x % G;
     const int i = blockIdx.x * RPB + g;
     if (i >= N) return;
@@ -102,8 +110,10 @@ __global__ void __launch_bounds__(256) k_gat_bwd_dst(const int* __restrict__ row
                                                      const float* __restrict__ mx, const float* __restrict__ den,
                                                      const float* __restrict__ gout, float slope, float p,
                                                      uint64_t seed, int64_t E, float* __restrict__ draw,
-                                                     float* __restrict__ dadst, int N, int K, int D) {
+                                                     float* __restrict__ dadst, int N, int K, int D,
+                                                     const uint64_t* __restrict__ ctr) {
     constexpr int RPB = 256 / G;
+    seed = step_seed(seed, ctr);
     const int g = threadIdx.x / G, l = threadIdx.x % G;
     const int i = blockIdx.x * RPB + g;
     if (i >= N) return;
@@ -167,8 +177,10 @@ __global__ void __launch_bounds__(256) k_gat_bwd_src(const int* __restrict__ row
                                                      const float* __restrict__ mx, const float* __restrict__ den,
                                                      const float* __restrict__ gout, const float* __restrict__ dadst,
                                                      const float* __restrict__ dasrc, float slope, float p,
-                                                     uint64_t seed, int64_t E, float* __restrict__ dz, int N, int K, int D) {
+                                                     uint64_t seed, int64_t E, float* __restrict__ dz, int N, int K, int D,
+                                                     const uint64_t* __restrict__ ctr) {
     constexpr int RPB = 256 / G;
+    seed = step_seed(seed, ctr);
     const int g = threadIdx.x / G, l = threadIdx.x % G;
     const int j = blockIdx.x * RPB + g;
     if (j >= N) return;
@@ -240,11 +252,11 @@ static inline int gat_rows_per_block(int64_t N) {
 // Outputs: out [N,K*D]; saved for backward: adst, asrc, mx, den, each [N,K].
 // p > 0 applies attention dropout with the counter-based mask of `seed` (cal_gat_dropout_mask
 // materialises the same mask for tests).
-CAL_EXPORT int cal_gat_fwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst, const float* z,
-                           const float* att, const float* bias, int relu, float slope, float p, uint64_t seed,
-                           float* out, float* adst, float* asrc, float* mx, float* den, int64_t N, int64_t E,
-                           int64_t K, int64_t D, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+namespace cal {
+int gat_forward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst, const float* z,
+                const float* att, const float* bias, int relu, float slope, float p, uint64_t seed, const uint64_t* ctr,
+                float* out, float* adst, float* asrc, float* mx, float* den, int64_t N, int64_t E,
+                int64_t K, int64_t D, hipStream_t stream) {
     if (N == 0) return 0;
     CAL_REQUIRE(K > 0 && D > 0, "bad head shape");
     CAL_REQUIRE(p >= 0.f && p < 1.f, "dropout p must be in [0,1)");
@@ -254,10 +266,19 @@ CAL_EXPORT int cal_gat_fwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, co
     bool vec_ok = (D % 4 == 0) && aligned16(z) && aligned16(out) && (!bias || aligned16(bias));
     CAL_DISPATCH_VG((int)H, vec_ok, {
         hipLaunchKernelGGL((k_gat_fwd<VEC, G>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst,
-                           z, adst, asrc, bias, relu, slope, p, seed, E, out, mx, den, (int)N, (int)K, (int)D);
+                           z, adst, asrc, bias, relu, slope, p, seed, E, out, mx, den, (int)N, (int)K, (int)D, ctr);
     });
     CAL_CHECK_LAUNCH("k_gat_fwd");
     return 0;
+}
+}  // namespace cal
+
+CAL_EXPORT int cal_gat_fwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst, const float* z,
+                           const float* att, const float* bias, int relu, float slope, float p, uint64_t seed,
+                           float* out, float* adst, float* asrc, float* mx, float* den, int64_t N, int64_t E,
+                           int64_t K, int64_t D, void* stream_) {
+    return gat_forward(rowptr_dst, nbr_dst, eid_dst, z, att, bias, relu, slope, p, seed, nullptr, out, adst, asrc, mx, den,
+                       N, E, K, D, (hipStream_t)stream_);
 }
 
 CAL_EXPORT int64_t cal_gat_bwd_ws(int64_t N, int64_t E, int64_t K, int64_t D) {
@@ -267,12 +288,12 @@ CAL_EXPORT int64_t cal_gat_bwd_ws(int64_t N, int64_t E, int64_t K, int64_t D) {
 
 // gout [N,K*D]: gradient at the layer output (already masked by the ReLU if one was fused).
 // Outputs dz [N,K*D], datt [K,2D].  ws: cal_gat_bwd_ws floats.
-CAL_EXPORT int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst,
-                           const int32_t* rowptr_src, const int32_t* nbr_src, const int32_t* eid_src, const float* z,
-                           const float* att, const float* adst, const float* asrc, const float* mx, const float* den,
-                           const float* gout, float slope, float p, uint64_t seed, float* dz, float* datt, float* ws,
-                           int64_t N, int64_t E, int64_t K, int64_t D, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+namespace cal {
+int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst,
+                 const int32_t* rowptr_src, const int32_t* nbr_src, const int32_t* eid_src, const float* z,
+                 const float* att, const float* adst, const float* asrc, const float* mx, const float* den,
+                 const float* gout, float slope, float p, uint64_t seed, const uint64_t* ctr, float* dz, float* datt,
+                 float* ws, int64_t N, int64_t E, int64_t K, int64_t D, hipStream_t stream) {
     int64_t H = K * D;
     int rpb = gat_rows_per_block(N);
     int nb = N == 0 ? 0 : cdiv(N, rpb);
@@ -285,14 +306,14 @@ CAL_EXPORT int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, co
         CAL_REQUIRE(vec_ok || pow2(D), "head dim must be a power of two (or 4 * a power of two)");
         CAL_DISPATCH_VG((int)H, vec_ok, {
             hipLaunchKernelGGL((k_gat_bwd_dst<VEC, G>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr_dst, nbr_dst,
-                               eid_dst, z, adst, asrc, mx, den, gout, slope, p, seed, E, draw, dadst, (int)N, (int)K, (int)D);
+                               eid_dst, z, adst, asrc, mx, den, gout, slope, p, seed, E, draw, dadst, (int)N, (int)K, (int)D, ctr);
         });
         CAL_CHECK_LAUNCH("k_gat_bwd_dst");
         hipLaunchKernelGGL(k_gat_bwd_dasrc, dim3(cdiv(N * K, 256)), dim3(256), 0, stream, rowptr_src, eid_src, draw, E, dasrc, (int)N, (int)K);
         CAL_CHECK_LAUNCH("k_gat_bwd_dasrc");
         CAL_DISPATCH_VG((int)H, vec_ok, {
             hipLaunchKernelGGL((k_gat_bwd_src<VEC, G>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr_src, nbr_src,
-                               eid_src, att, adst, asrc, mx, den, gout, dadst, dasrc, slope, p, seed, E, dz, (int)N, (int)K, (int)D);
+                               eid_src, att, adst, asrc, mx, den, gout, dadst, dasrc, slope, p, seed, E, dz, (int)N, (int)K, (int)D, ctr);
         });
         CAL_CHECK_LAUNCH("k_gat_bwd_src");
         int threads = (int)(H > 256 ? 256 : ((H + 63) / 64) * 64);
@@ -302,6 +323,16 @@ CAL_EXPORT int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, co
     hipLaunchKernelGGL(k_gat_datt_finish, dim3(cdiv(2 * H, 16)), dim3(256), 0, stream, part, nb, (int)(2 * H), datt);
     CAL_CHECK_LAUNCH("k_gat_datt_finish");
     return 0;
+}
+}  // namespace cal
+
+CAL_EXPORT int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst,
+                           const int32_t* rowptr_src, const int32_t* nbr_src, const int32_t* eid_src, const float* z,
+                           const float* att, const float* adst, const float* asrc, const float* mx, const float* den,
+                           const float* gout, float slope, float p, uint64_t seed, float* dz, float* datt, float* ws,
+                           int64_t N, int64_t E, int64_t K, int64_t D, void* stream_) {
+    return gat_backward(rowptr_dst, nbr_dst, eid_dst, rowptr_src, nbr_src, eid_src, z, att, adst, asrc, mx, den, gout, slope, p,
+                        seed, nullptr, dz, datt, ws, N, E, K, D, (hipStream_t)stream_);
 }
 
 CAL_EXPORT int cal_gat_dropout_mask(uint64_t seed, int64_t E, int64_t N, int64_t K, float p, float* mask, void* stream_) {

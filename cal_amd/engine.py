@@ -25,13 +25,27 @@ from .plan import _p, _stream
 _BN_ORDER_TAIL = ["bnc", "bno", "fc1_bn_c", "fc2_bn_c", "fc1_bn_o", "fc2_bn_o", "fc1_bn_co", "fc2_bn_co"]
 
 
+def _gat_heads(model) -> int:
+    """Heads of a GATConv backbone (CausalGAT, model.py:340,390); 0 for the GCNConv backbone."""
+    from .gat_conv import GATConv
+    convs = list(model.convs)
+    return int(convs[0].heads) if convs and isinstance(convs[0], GATConv) else 0
+
+
 def supported(model) -> bool:
-    from .model import CausalGCN
+    from .model import CausalGCN, CausalGAT
     a = model.args
     h = a.hidden
-    return (isinstance(model, CausalGCN) and a.cat_or_add == "add" and not model.without_node_attention
-            and not model.without_edge_attention and h % 4 == 0 and h <= 256 and a.layers <= 6
-            and model.num_classes <= 64 and not any(c.improved for c in model.convs))
+    if not (isinstance(model, (CausalGCN, CausalGAT)) and a.cat_or_add == "add"
+            and not getattr(model, "without_node_attention", False) and not getattr(model, "without_edge_attention", False)
+            and h % 4 == 0 and h <= 256 and a.layers <= 6 and model.num_classes <= 64):
+        return False
+    if isinstance(model, CausalGAT):
+        k = _gat_heads(model)
+        d = h // k if k else 0
+        return (k > 0 and h % k == 0 and d % 4 == 0 and (d // 4) & (d // 4 - 1) == 0
+                and all(c.heads == k and c.bias is not None for c in model.convs))
+    return not any(c.improved for c in model.convs)
 
 
 def _slot_names(layers: int):
@@ -51,7 +65,7 @@ class StepEngine:
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, flat=None):
         if not supported(model):
-            raise ValueError("StepEngine covers CausalGCN (cat_or_add='add', attentions on, hidden % 4 == 0, <= 256)")
+            raise ValueError("StepEngine covers CausalGCN / CausalGAT (cat_or_add='add', attentions on, hidden % 4 == 0, <= 256)")
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise _lib.CalError("StepEngine needs the model on the GPU (no CPU fallback)")
@@ -89,6 +103,19 @@ class StepEngine:
         _lib.call("cal_engine_bind", self._h, _p(self.flat_p), _p(self.flat_g), _p(self.exp_avg), _p(self.exp_avg_sq),
                   _p(self.step_count), _p(self.lr), self.flat_p.numel(), self._offs, self._bn,
                   betas[0], betas[1], eps, weight_decay)
+        # GATConv backbone: att offsets, dropout seeds, the per-step device counter the masks are keyed by
+        self.heads = _gat_heads(model)
+        self._gat_seeds = None
+        if self.heads:
+            self.gat_ctr = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self._gat_base = int(torch.initial_seed() * 1000003 + 7919) & ((1 << 62) - 1)
+            att = []
+            for conv in model.convs:
+                off = (conv.att.data_ptr() - base) // 4
+                assert 0 <= off and off + conv.att.numel() <= self.flat_p.numel()
+                att.append(off)
+            self._att_offs = (ctypes.c_int64 * len(att))(*att)
+            self._sync_gat()
         self._ws: Optional[torch.Tensor] = None
         self._cap = (0, 0, 0)
         self._bounds = (0, 0)
@@ -102,6 +129,24 @@ class StepEngine:
                 self._h = None
         except Exception:
             pass
+
+    def _sync_gat(self):
+        """(Re)send the GAT settings when a layer's fixed dropout seed (GATConv.seed, tests) or p changed.  With no
+        fixed seed the masks are keyed by (base seed + layer, device step counter): fresh per step even inside a
+        replayed hipGraph; with fixed seeds the counter is off and layer i uses exactly GATConv.seed."""
+        convs = list(self.model.convs)
+        key = tuple((c.seed, float(c.dropout), float(c.negative_slope)) for c in convs)
+        if key == self._gat_seeds:
+            return
+        fixed = any(c.seed is not None for c in convs)
+        seeds = [int(c.seed) if c.seed is not None else (self._gat_base + 0x9E3779B1 * (i + 1)) & ((1 << 63) - 1)
+                 for i, c in enumerate(convs)]
+        arr = (ctypes.c_uint64 * len(seeds))(*seeds)
+        _lib.call("cal_engine_set_gat", self._h, self.heads, float(convs[0].dropout), float(convs[0].negative_slope),
+                  self._att_offs, arr, None if fixed else _p(self.gat_ctr))
+        self._gat_seeds = key
+        self.gat_layer_seeds = seeds
+        self.gat_fixed = fixed
 
     # ---------------------------------------------------------------- workspace
     def reserve(self, N: int, E: int, B: int):
@@ -135,6 +180,8 @@ class StepEngine:
         N, E, B = x.size(0), ei.size(1), int(batch.num_graphs)
         if x.dtype != torch.float32 or x.size(1) != self.F:
             raise ValueError("features must be float32 [N, %d]" % self.F)
+        if self.heads:
+            self._sync_gat()
         self.reserve(N, E, B)
         self._last_B = B
         # layout facts of a collated batch -> one-kernel per-graph CSR build (the tensors stay referenced by the batch)

@@ -73,13 +73,13 @@ class _CausalBase(torch.nn.Module):
     def _backbone(self, x, edge_index, plan):
         raise NotImplementedError
 
-    #: CausalGCN only: run forward/backward on the native step engine (cal_amd/csrc/engine.hip)
+    #: CausalGCN / CausalGAT: run forward/backward on the native step engine (cal_amd/csrc/engine.hip)
     #: behind this same nn.Module / autograd surface.  Set False for the operator-level path.
     use_engine = os.environ.get("CAL_AMD_ENGINE", "1") != "0"
 
     def _engine_for(self, x):
         from . import engine as eng_mod
-        if not (self.use_engine and x.is_cuda and isinstance(self, CausalGCN) and eng_mod.supported(self)):
+        if not (self.use_engine and x.is_cuda and isinstance(self, (CausalGCN, CausalGAT)) and eng_mod.supported(self)):
             return None
         eng = getattr(self, "_engine", None)
         p0 = next(self.parameters())

@@ -134,6 +134,14 @@ CAL_API int cal_collate(const float* X, const int64_t* EI, int64_t sumE, int64_t
  * *counter (a device uint64), so a replayed hipGraph draws a fresh permutation every step.  B <= 4096 */
 CAL_API int cal_randperm(int64_t* perm, int64_t B, uint64_t seed, uint64_t* counter, void* stream);
 
+/* CausalGAT (model.py:315-409): switch the engine's backbone layers to GATConv(H, H/heads, heads, dropout=p)
+ * (PyG GATConv at model.py:340,390).  att_offs[i] = float offset of convs.i.att [heads, 2H/heads] in the bound
+ * parameter buffer; seeds[i] = attention-dropout seed of layer i; ctr = device uint64 the engine advances once
+ * per training step and folds into the seeds so a replayed hipGraph still draws fresh masks (NULL: seeds as given).
+ * Call before cal_engine_workspace_bytes / cal_engine_set_workspace. */
+CAL_API int cal_engine_set_gat(void* engine, int64_t heads, float p, float slope, const int64_t* att_offs,
+                               const uint64_t* seeds, void* ctr);
+
 /* ---- native CausalGCN step engine ------------------------------------------------
  * The whole train step of train_causal.py:173-192 on model.py:85-164 (forward, 3-term loss,
  * backward, Adam) as one call enqueuing ~55 fused kernels; see cal_amd/csrc/engine.hip for the

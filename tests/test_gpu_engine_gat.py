@@ -1,0 +1,181 @@
+"""GPU parity of the native step engine with a GATConv backbone (CausalGAT, model.py:315-409) against the CPU
+oracle: the committed golden fixture, multi-step training WITH attention dropout (same masks fed to the oracle),
+the device step counter that keys the masks inside replayed hipGraphs, and the configs 3 / 4 stand-in shapes
+(SURVEY.md 8d).  Logit tolerance 1e-4 (north_star)."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cal_oracle as O
+from tests.helpers import GOLDEN, ref_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+LOGIT_TOL = 1e-4
+GOLD = 0x9E3779B97F4A7C15      # cal_amd/csrc/gat.hip step_seed()
+
+
+def _args(**kw):
+    d = dict(layers=3, hidden=128, with_random=True, without_node_attention=False,
+             without_edge_attention=False, fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def _engine(sd, args, nfeat=10, ncls=4, lr=1e-3, dropout=0.2, name="CausalGAT"):
+    from cal_amd import model as M
+    from cal_amd.engine import StepEngine
+    m = getattr(M, name)(nfeat, ncls, args)
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    if name == "CausalGAT":
+        for c in m.convs:
+            c.dropout = dropout
+    return m, StepEngine(m, lr=lr)
+
+
+def _masks(seeds, bd, b, heads, p):
+    """The keep masks the kernels draw for `seeds`, in the oracle's slot order (edges without self loops, then
+    one loop per node)."""
+    from cal_amd import ops
+    from cal_amd.plan import plan_of
+    plan = plan_of(bd)
+    row, col = b.edge_index
+    keep_e = (row != col).nonzero().view(-1)
+    out = []
+    for s in seeds:
+        full = ops.gat_dropout_mask(int(s), plan, heads, p).cpu()
+        out.append(torch.cat([full[keep_e], full[plan.E:]], 0))
+    return out
+
+
+def test_gat_golden_fixture_train_step_on_engine():
+    fx = np.load(os.path.join(GOLDEN, "causal_gat_batch8.npz"))
+    sd = {k[3:]: torch.from_numpy(fx[k]).clone() for k in fx.files if k.startswith("sd.")}
+    m, eng = _engine(sd, _args(layers=2, hidden=32), dropout=0.0)
+    assert eng.heads == 4
+    bd = ref_batch(list(fx["ids"])).to(DEV)
+    perm = torch.from_numpy(fx["perm"]).to(DEV)
+    ev = eng.forward(bd, perm, training=False)
+    for n, t in zip(("c", "o", "co"), ev):
+        assert np.abs(t.cpu().numpy() - fx[f"eval_logits_{n}"]).max() < LOGIT_TOL, n
+    stats = eng.train_step(bd, perm, adam=True).cpu().numpy()
+    lp = eng.buffer("logp", 3 * 8 * 4).view(3, 8, 4).cpu().numpy()
+    for i, n in enumerate(("c", "o", "co")):
+        assert np.abs(lp[i] - fx[f"train_logits_{n}"]).max() < LOGIT_TOL, n
+    assert np.allclose(stats[:4], fx["loss"], atol=1e-4)
+    for k, p in m.named_parameters():
+        g = fx[f"grad.{k}"]
+        if g.size:
+            assert np.allclose(p.grad.cpu().numpy(), g, atol=2e-5, rtol=1e-3), k
+    post = m.state_dict()
+    for k, p in m.named_parameters():
+        g = fx[f"grad.{k}"]
+        if g.size:
+            mask = np.abs(g) > 1e-6
+            assert np.allclose(post[k].cpu().numpy()[mask], fx[f"post.{k}"][mask], atol=2e-5, rtol=1e-4), k
+
+
+def test_gat_steps_with_dropout_track_the_oracle():
+    """Three Adam steps with p = 0.2 attention dropout; every step's masks (fixed per-layer seeds) go to the oracle."""
+    ids = list(range(16))
+    b, bd = ref_batch(ids), ref_batch(ids).to(DEV)
+    torch.manual_seed(4)
+    sd = O.init_state("CausalGAT", 10, 4, hidden=32, layers=2, heads=4)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(layers=2, hidden=32), lr=1e-2)
+    tr = O.CpuTrainer("CausalGAT", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-2, layers=2, heads=4, gat_dropout=0.2)
+    g = torch.Generator().manual_seed(0)
+    for step in range(3):
+        perm = torch.randperm(len(ids), generator=g)
+        for i, c in enumerate(m.convs):
+            c.seed = 1000 + 10 * step + i
+        tr.fw["gat_masks"] = _masks([c.seed for c in m.convs], bd, b, 4, 0.2)
+        loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+        stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu()
+        assert eng.gat_fixed
+        if step == 0:
+            lp = eng.buffer("logp", 3 * len(ids) * 4).view(3, len(ids), 4).cpu()
+            for r, t in zip(logits, lp):
+                assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+            for k, p in m.named_parameters():
+                gref = tr.sd[k].grad
+                if gref is not None:
+                    assert torch.allclose(p.grad.cpu(), gref, atol=5e-5, rtol=2e-3), k
+        assert abs(stats[0].item() - loss.item()) < 2e-3 * (step + 1), step
+    assert int(eng.step_count.item()) == 3
+
+
+def test_gat_step_counter_keys_the_masks_and_replays_draw_fresh_ones():
+    """No fixed seeds: layer i draws from seed_i + counter * GOLD, the counter advancing once per training step.
+    The same masks must be used by the forward and the backward of a step (gradients match the oracle fed with the
+    masks of the effective seeds), and a replayed hipGraph must not repeat them."""
+    from cal_amd import model as M
+    from cal_amd.trainer import CausalTrainer
+    ids = list(range(12))
+    b, bd = ref_batch(ids), ref_batch(ids).to(DEV)
+    torch.manual_seed(9)
+    sd = O.init_state("CausalGAT", 10, 4, hidden=32, layers=2, heads=4)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(layers=2, hidden=32))
+    perm = torch.randperm(len(ids))
+    eng.train_step(bd, perm.to(DEV), adam=False)
+    assert not eng.gat_fixed
+    v = int(eng.gat_ctr.item())
+    assert v == 1
+    eff = [(s + v * GOLD) % (1 << 64) for s in eng.gat_layer_seeds]
+    tr = O.CpuTrainer("CausalGAT", {k: v_.clone() for k, v_ in sd.items()}, 4, lr=1e-3, layers=2, heads=4, gat_dropout=0.2,
+                      gat_masks=_masks(eff, bd, b, 4, 0.2))
+    loss, *_ = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    assert abs(eng.buffer("stats", 5)[0].item() - loss.item()) < 1e-4
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is not None:
+            assert torch.allclose(p.grad.cpu(), gref, atol=5e-5, rtol=2e-3), k
+    # eval forwards leave the counter alone
+    eng.forward(bd, perm.to(DEV), training=False)
+    assert int(eng.gat_ctr.item()) == 1
+    # graph replay: lr = 0 keeps the weights, so any change of the loss between replays is the mask
+    m2 = M.CausalGAT(10, 4, _args(layers=2, hidden=32))
+    m2.load_state_dict(sd)
+    m2 = m2.to(DEV)
+    trn = CausalTrainer(m2, _args(layers=2, hidden=32), lr=0.0, use_graph=True)
+    assert trn.engine is not None and trn.engine.heads == 4
+    losses = []
+    for _ in range(4):
+        losses.append(float(trn.step(bd, perm=perm.to(DEV))[0].item()))
+    assert len({round(x, 6) for x in losses}) == 4, losses
+    c0 = int(trn.engine.gat_ctr.item())
+    trn.step(bd, perm=perm.to(DEV))
+    assert int(trn.engine.gat_ctr.item()) == c0 + 1
+    for c in m2.convs:      # p = 0: replays are bit-identical
+        c.dropout = 0.0
+    trn2 = CausalTrainer(m2, _args(layers=2, hidden=32), lr=0.0, use_graph=True)
+    l0 = [float(trn2.step(bd, perm=perm.to(DEV))[0].item()) for _ in range(3)]
+    assert l0[0] == l0[1] == l0[2]
+
+
+@pytest.mark.parametrize("name,kind,nfeat,batch", [("CausalGAT", "mutag", 109, 64), ("CausalGCN", "nci1", 139, 512)])
+def test_config3_config4_standin_shapes_match_oracle(name, kind, nfeat, batch):
+    """SURVEY.md 8d configs 3 (CausalGAT, MUTAG-like, F = 109, B = 64) and 4 (CausalGCN, NCI1-like, F = 139,
+    B = 512 per GPU) on the synthetic stand-ins of cal_amd/synth.py: one full train step against the oracle."""
+    from cal_amd import synth
+    from cal_amd.data import Batch
+    gs = synth.tu_like(batch, kind=kind, seed=5)
+    b, bd = Batch.from_data_list(gs), Batch.from_data_list(gs).to(DEV)
+    torch.manual_seed(6)
+    sd = O.init_state(name, nfeat, 2, hidden=128, layers=3, heads=4)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(), nfeat=nfeat, ncls=2, dropout=0.0, name=name)
+    perm = torch.randperm(batch)
+    tr = O.CpuTrainer(name, {k: v.clone() for k, v in sd.items()}, 2, lr=1e-3, layers=3, heads=4, gat_dropout=0.0)
+    loss, lc, lo, lco, logits = tr.step(b.x, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
+    lp = eng.buffer("logp", 3 * batch * 2).view(3, batch, 2).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is not None:
+            assert torch.allclose(p.grad.cpu(), gref, atol=1e-4, rtol=3e-3), k

@@ -36,10 +36,11 @@ def _build(name, nfeat, ncls, args, sd=None, use_engine=None):
 
 @pytest.mark.parametrize("name,fname,use_engine", [("CausalGCN", "causal_gcn_batch8.npz", False),
                                                    ("CausalGCN", "causal_gcn_batch8.npz", True),
-                                                   ("CausalGAT", "causal_gat_batch8.npz", False)])
+                                                   ("CausalGAT", "causal_gat_batch8.npz", False),
+                                                   ("CausalGAT", "causal_gat_batch8.npz", True)])
 def test_golden_fixture_eval_and_train_step(name, fname, use_engine):
-    """nn.Module surface + torch loss + torch Adam, on the operator-level path and (CausalGCN) on the
-    native engine behind the same autograd surface."""
+    """nn.Module surface + torch loss + torch Adam, on the operator-level path and on the native engine
+    behind the same autograd surface."""
     fx = np.load(os.path.join(GOLDEN, fname))
     b = ref_batch(list(fx["ids"]))
     sd = {k[3:]: torch.from_numpy(fx[k]).clone() for k in fx.files if k.startswith("sd.")}
