@@ -28,6 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+HEADLINE = "spmotif_b0.9_causalgcn_h128_l3_bs128"
 WORKLOADS = {
     # BASELINE.json configs[1] (the headline) first; the others are SURVEY.md 8d's configs 3-5 on synthetic
     # stand-ins (cal_amd/synth.py), selectable with --workload -- the default run measures the headline only
@@ -172,7 +173,7 @@ def spmm_roofline(trainer, batches, wl, iters=20):
                      "(launch/latency-bound by construction, SURVEY.md 8d)")
 
 
-def engine_roofline(trainer, batches, iters=20):
+def engine_roofline(trainer, batches, workload, iters=20):
     """Live HIP-event timing (on the launch stream) of the two kernels the north star names, as
     launched inside the native step: the dense [N,H]x[H,H] MFMA GEMM of every backbone layer
     (dominant by time -> primary roofline, bound = mfma) and the CSR aggregation k_espmm (bound =
@@ -208,11 +209,16 @@ def engine_roofline(trainer, batches, iters=20):
     pmc = {}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pmc.get("workload", HEADLINE) != workload:      # the counters were collected on another workload
+            pmc = {}
     except Exception:
         pass
-    note = ("config-2 working set (3.7 MB activations) is cache-resident and every launch is a few hundred "
-            "workgroups of one ~10 us dependent chain: the step is latency-bound by construction (SURVEY.md 8d); "
-            "event pairs include the launch gap")
+    if workload == HEADLINE:
+        note = ("config-2 working set (3.7 MB activations) is cache-resident and every launch is a few hundred "
+                "workgroups of one ~10 us dependent chain: the step is latency-bound by construction (SURVEY.md 8d); "
+                "event pairs include the launch gap")
+    else:
+        note = "event pairs include the launch gap; no PMC pass was collected for this workload (traffic null)"
     mfma = {
         "gemm": ("k_gemm", "k_gemm<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers, unfused path)", "k_gemm_backbone"),
         "gconv": ("k_gconv_fwd", "k_gconv_fwd: per-graph fused BN + [n,H]x[H,64] MFMA GEMM + dense-block aggregation MFMA + "
@@ -387,7 +393,8 @@ def main():
     edges = float(np.mean([b.edge_index.size(1) for b in batches]))
 
     out = {
-        "metric": "graphs/sec (train step) on SPMotif b=0.9 batch=128",
+        "metric": "graphs/sec (train step) on SPMotif b=0.9 batch=128" if wl["data"] == "spmotif" else
+                  "graphs/sec (train step) on %s batch=%d" % (a.workload, wl["batch"]),
         "value": graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -401,7 +408,7 @@ def main():
         if not a.no_roofline:
             try:
                 if trainer.engine is not None:
-                    out.update(engine_roofline(trainer, batches))
+                    out.update(engine_roofline(trainer, batches, a.workload))
                 else:
                     out["roofline"] = spmm_roofline(trainer, batches, wl)
             except Exception as exc:

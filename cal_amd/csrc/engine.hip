@@ -281,7 +281,11 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     // split-K slabs: worst case per weight gradient (S <= 256, but S*tiles ~ 512 => S*M*N <= ~512*64*64 + M*N)
     size_t slab = 0;
     // (per-graph fused backward: one [M,N] slab per graph)
-    auto slab_of = [&](size_t M, size_t Nn) { return std::max<size_t>(512 * 64 * 64, (size_t)B * M * Nn) + 2 * M * Nn; };
+    // (big batches: one slab per 1024-node split-K slice of the 128x128 gradient kernel, gemm_big.hip)
+    auto slab_of = [&](size_t M, size_t Nn) {
+        const size_t big = gemm_big_grad((int)M, (int)Nn, (int)N) ? (size_t)gemm_big_grad_splits((int)N) * M * Nn : 0;
+        return std::max<size_t>(std::max<size_t>(512 * 64 * 64, (size_t)B * M * Nn), big) + 2 * M * Nn;
+    };
     slab += slab_of(F, H) + (L + 2) * slab_of(H, H) + 3 * slab_of(H, H) + 3 * slab_of(C, H);
     if (assign) e->slab_floats = slab;
     F32(e->slabs, slab);
@@ -444,9 +448,9 @@ int fwd_gemm(Ctx& c, bool transB, const GemmArgs& a, int nbatch) {
     return use_ks(a.M) ? launch_gemm_ks(transB, a, nbatch, c.st) : launch_gemm(false, transB, a, nbatch, c.st);
 }
 // same for a GEMM epilogue (two sums per column, P = row tiles)
-void gemm_stats(Ctx& c, GemmProb& pr, int M, int N, double* d0, double* d1, bool dot) {
+void gemm_stats(Ctx& c, GemmProb& pr, int M, int N, double* d0, double* d1, bool dot, int K = 0) {
     if (dot) { pr.dot_sum = d0; pr.dot_prod = d1; } else { pr.st_sum = d0; pr.st_sq = d1; }
-    const int P = use_ks(M) ? gemm_ks_row_tiles(M) : gemm_row_tiles(M);
+    const int P = use_ks(M) ? gemm_ks_row_tiles(M) : gemm_row_tiles(M, K);
     if ((size_t)P * N * 2 <= 4096) return;
     double* p = parts_alloc(c, (size_t)P * 2 * N);
     if (!p) return;
@@ -681,7 +685,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         GemmArgs a = gemm_args(N, H, F, false, false, 1);
         a.p[0].A = x0; a.p[0].B = e->P + e->o_feat_w; a.p[0].C = e->h;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 1);
-        if (c.training && L > 0) gemm_stats(c, a.p[0], N, H, bn_stsum(c, 1), bn_stsq(c, 1), false);
+        if (c.training && L > 0) gemm_stats(c, a.p[0], N, H, bn_stsum(c, 1), bn_stsq(c, 1), false, F);
         RC(fwd_gemm(c, false, a, 1)); STAGE();
         RC(flush_finals(c)); STAGE();
     }
@@ -827,9 +831,16 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     // 9. add-pool (model.py:115-116)
     if (!gc) {
         int tc = std::min(256, pow2ceil(H / 4));
-        hipLaunchKernelGGL((k_pool2<4>), dim3(B, 2), dim3(256), 0, st, e->hco, e->hco + NH, e->gptr, e->pooled,
-                           e->pooled + (size_t)B * H, H, tc);
-        CAL_CHECK_LAUNCH("k_pool2"); STAGE();
+        // few large graphs: split every graph's rows over S workgroups (slices parked in dZco, a backward-only buffer)
+        const int S = std::max(1, std::min(32, N / std::max(1, B * 1024)));
+        hipLaunchKernelGGL((k_pool2<4>), dim3(B, 2, S), dim3(256), 0, st, e->hco, e->hco + NH, e->gptr, e->pooled,
+                           e->pooled + (size_t)B * H, H, tc, e->dZco);
+        CAL_CHECK_LAUNCH("k_pool2");
+        if (S > 1) {
+            hipLaunchKernelGGL(k_pool2_sum, dim3(cdiv(2 * (int64_t)B * H, 256)), dim3(256), 0, st, e->dZco, S, 2 * (int64_t)B * H, e->pooled);
+            CAL_CHECK_LAUNCH("k_pool2_sum");
+        }
+        STAGE();
     }
     // 10. readouts (model.py:125-164)
     if (use_ro(c)) {
@@ -1075,7 +1086,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[k].A = e->dzco + (size_t)k * NH; a.p[k].B = e->P + (k ? e->o_ow : e->o_cw); a.p[k].C = e->dXhco + (size_t)k * NH;
             a.p[k].aux = x; a.p[k].aux_rs = e->anode + k; a.p[k].aux_rs_stride = 2; a.p[k].has_aux = 1;
             a.p[k].aux_bn = bnref(c, L + 1 + k, N, 0);
-            gemm_stats(c, a.p[k], N, H, bn_dsum(c, L + 1 + k), bn_dprod(c, L + 1 + k), true);
+            gemm_stats(c, a.p[k], N, H, bn_dsum(c, L + 1 + k), bn_dprod(c, L + 1 + k), true, H);
         }
         RC(dual_gemm(c, a, 2, aw, 2, dst, fa, slab_off)); STAGE();
         RC(flush_finals(c)); STAGE();
@@ -1190,7 +1201,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a = gemm_args(N, H, H, false, true, 0);
             a.p[0].A = dzi; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->dXh;
             a.p[0].aux = hin; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, i, N, 0);
-            gemm_stats(c, a.p[0], N, H, bn_dsum(c, i), bn_dprod(c, i), true);
+            gemm_stats(c, a.p[0], N, H, bn_dsum(c, i), bn_dprod(c, i), true, H);
             { ProfScope ps(st, 3, 4.0 * N * H * H); RC(dual_gemm(c, a, 1, aw, 1, dst, fa, slab_off)); } STAGE();
             RC(flush_finals(c)); STAGE();
         }
@@ -1217,7 +1228,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         a.p[0].aux = x0; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, 0, N, 0);
         a.p[0].dot_sum = bn_dsum(c, 0); a.p[0].dot_prod = bn_dprod(c, 0);
         {   // bn_feat's sums are only needed by the commit: keep the partial rows, no finalise launch
-            const int P0 = use_ks(N) ? gemm_ks_row_tiles(N) : gemm_row_tiles(N);
+            const int P0 = use_ks(N) ? gemm_ks_row_tiles(N) : gemm_row_tiles(N, H);
             if ((size_t)P0 * F * 2 > 4096) {
                 d_bn0.p = parts_alloc(c, (size_t)P0 * 2 * F); d_bn0.P = P0; d_bn0.stride = 2 * F;
                 a.p[0].parts = d_bn0.p;

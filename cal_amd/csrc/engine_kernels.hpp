@@ -397,13 +397,20 @@ __global__ void __launch_bounds__(256) k_edge_att_deg(const CSR gs, const float*
 template <int VEC>
 __global__ void __launch_bounds__(256) k_pool2(const float* __restrict__ hc, const float* __restrict__ ho,
                                                const int* __restrict__ gptr, float* __restrict__ pc,
-                                               float* __restrict__ po, int H, int tc) {
+                                               float* __restrict__ po, int H, int tc, float* __restrict__ slices) {
     __shared__ float lds[256 * 4];
     const float* h = blockIdx.y ? ho : hc;
-    float* out = blockIdx.y ? po : pc;
     const int b = blockIdx.x;
+    // gridDim.z > 1 (graphs of thousands of nodes, few graphs): row slice z of the graph goes to slices[z][branch][b][:]
+    // and k_pool2_sum adds the slices in a fixed order -- B x 2 workgroups alone read config 5's 328 MB at 1 TB/s
+    float* out = gridDim.z > 1 ? slices + ((size_t)blockIdx.z * 2 + blockIdx.y) * gridDim.x * H : (blockIdx.y ? po : pc);
     const int nrl = 256 / tc, cl = threadIdx.x % tc, rl = threadIdx.x / tc;
-    const int n0 = gptr[b], n1 = gptr[b + 1];
+    int n0 = gptr[b], n1 = gptr[b + 1];
+    if (gridDim.z > 1) {
+        const int len = (n1 - n0 + gridDim.z - 1) / gridDim.z;
+        n0 = min(n1, n0 + (int)blockIdx.z * len);
+        n1 = min(n1, n0 + len);
+    }
     using V = Vec<VEC>;
     for (int c = cl * VEC; c - cl * VEC < H; c += tc * VEC) {
         const bool cok = c < H;
@@ -430,6 +437,15 @@ __global__ void __launch_bounds__(256) k_pool2(const float* __restrict__ hc, con
         }
         __syncthreads();
     }
+}
+
+// pooled[branch][b][:] = sum over the S row slices written by k_pool2 (n = 2 * B * H floats per slice)
+__global__ void k_pool2_sum(const float* __restrict__ slices, int S, int64_t n, float* __restrict__ pooled) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slices[(size_t)z * n + i];
+    pooled[i] = s;
 }
 
 // ------------------------------------------------------------------------------------------------

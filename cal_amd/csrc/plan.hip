@@ -84,6 +84,60 @@ __global__ void __launch_bounds__(1024) k_plan_scan(const int* __restrict__ cnt_
     if (threadIdx.x == 0) ptr[n] = carry_s;
 }
 
+// Large batches (config 5: 160k nodes = 20 serial passes of the single-workgroup scan, 145 us): two launches instead --
+// per-chunk totals, then every chunk scans itself on top of the sum of the totals before it.  grid (chunks, 2 arrays).
+__global__ void __launch_bounds__(1024) k_plan_scan_tot(const int* __restrict__ cnt_a, const int* __restrict__ cnt_b, int n,
+                                                        int* __restrict__ tot) {
+    const int* cnt = blockIdx.y == 0 ? cnt_a : cnt_b;
+    __shared__ int wave_tot[16];
+    const int i0 = blockIdx.x * 8192 + threadIdx.x * 8;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (i0 + j < n) ? cnt[i0 + j] : 0;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < 16; ++w) t += wave_tot[w];
+        tot[blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+__global__ void __launch_bounds__(1024) k_plan_scan_chunk(const int* __restrict__ cnt_a, int* __restrict__ ptr_a,
+                                                          const int* __restrict__ cnt_b, int* __restrict__ ptr_b, int n,
+                                                          const int* __restrict__ tot) {
+    const int* cnt = blockIdx.y == 0 ? cnt_a : cnt_b;
+    int* ptr = blockIdx.y == 0 ? ptr_a : ptr_b;
+    __shared__ int wave_tot[16];
+    __shared__ int red[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // carry = sum of the totals of the chunks before this one
+    int c = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 1024) c += tot[blockIdx.y * gridDim.x + b];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) red[wid] = c;
+    const int i0 = blockIdx.x * 8192 + threadIdx.x * 8;
+    int v[8];
+    int tsum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = (i0 + j < n) ? cnt[i0 + j] : 0; tsum += v[j]; }
+    int x = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wave_tot[wid] = x;
+    __syncthreads();
+    int carry = 0, woff = 0;
+    for (int w = 0; w < 16; ++w) carry += red[w];
+    for (int w = 0; w < wid; ++w) woff += wave_tot[w];
+    int run = carry + woff + x - tsum;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { if (i0 + j < n) ptr[i0 + j] = run; run += v[j]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023) ptr[n] = carry + woff + x;
+}
+
 __global__ void k_plan_fill(const int* __restrict__ row32, const int* __restrict__ col32, int64_t E,
                             const int* __restrict__ ptr_dst, const int* __restrict__ ptr_src,
                             int* __restrict__ cur_dst, int* __restrict__ cur_src,
@@ -178,8 +232,17 @@ int plan_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr_
                            cnt_dst, cnt_src, row32, col32, status);
         CAL_CHECK_LAUNCH("k_plan_count");
     }
-    hipLaunchKernelGGL(k_plan_scan, dim3(2), dim3(1024), 0, stream, cnt_dst, rowptr_dst, cnt_src, rowptr_src, n);
-    CAL_CHECK_LAUNCH("k_plan_scan");
+    if (n > 4 * 8192 && E >= 2 * (int64_t)cdiv(n, 8192)) {
+        // chunk totals live in the (not yet written) sort scratch: 2 * chunks ints
+        const int chunks = cdiv(n, 8192);
+        hipLaunchKernelGGL(k_plan_scan_tot, dim3(chunks, 2), dim3(1024), 0, stream, cnt_dst, cnt_src, n, tn_d);
+        CAL_CHECK_LAUNCH("k_plan_scan_tot");
+        hipLaunchKernelGGL(k_plan_scan_chunk, dim3(chunks, 2), dim3(1024), 0, stream, cnt_dst, rowptr_dst, cnt_src, rowptr_src, n, tn_d);
+        CAL_CHECK_LAUNCH("k_plan_scan_chunk");
+    } else {
+        hipLaunchKernelGGL(k_plan_scan, dim3(2), dim3(1024), 0, stream, cnt_dst, rowptr_dst, cnt_src, rowptr_src, n);
+        CAL_CHECK_LAUNCH("k_plan_scan");
+    }
     if (E > 0) {
         hipLaunchKernelGGL(k_plan_fill, dim3(cdiv(E, 256)), dim3(256), 0, stream, row32, col32, E,
                            rowptr_dst, rowptr_src, cur_dst, cur_src, tn_d, te_d, tn_s, te_s);

@@ -179,3 +179,32 @@ def test_config3_config4_standin_shapes_match_oracle(name, kind, nfeat, batch):
         gref = tr.sd[k].grad
         if gref is not None:
             assert torch.allclose(p.grad.cpu(), gref, atol=1e-4, rtol=3e-3), k
+
+
+@pytest.mark.parametrize("name", ["CausalGCN", "CausalGAT"])
+def test_big_batch_takes_the_throughput_gemm_and_matches_oracle(name):
+    """A config-5-like batch (4 BA graphs of 5000 nodes: N = 20000 >= 16k rows) runs its node-level products on the
+    128x128 MFMA kernel (gemm_big.hip: 128-row statistic tiles, 1024-node split-K slabs): one train step vs the oracle."""
+    from cal_amd import synth
+    from cal_amd.data import Batch
+    gs = synth.ba_graphs(4, n=5000, seed=3)
+    b, bd = Batch.from_data_list(gs), Batch.from_data_list(gs).to(DEV)
+    torch.manual_seed(8)
+    sd = O.init_state(name, 10, 4, hidden=64, layers=2, heads=4)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(hidden=64, layers=2), dropout=0.0, name=name)
+    perm = torch.randperm(4)
+    tr = O.CpuTrainer(name, {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=2, heads=4, gat_dropout=0.0)
+    loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
+    lp = eng.buffer("logp", 3 * 4 * 4).view(3, 4, 4).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is not None:
+            # sums over 20000 nodes through a readout BatchNorm over only 4 graphs: fp32 summation-order noise is
+            # amplified, so the bound is relative to the gradient's largest entry
+            scale = max(1.0, gref.abs().max().item())
+            err = (p.grad.cpu() - gref).abs().max().item()
+            assert err <= 1e-3 * scale, (k, err, scale)
