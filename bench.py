@@ -94,7 +94,7 @@ def cpu_baseline(wl, batches_cpu, seconds):
     def one(i):
         b = batches_cpu[i % nb]
         perm = torch.tensor(O.intervention_perm(b.num_graphs, True, True, wl["model"]))
-        tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+        tr.step((b.x if b.x is not None else b.feat), b.edge_index, b.batch, b.y, perm=perm)
         return b.num_graphs
 
     cands = sorted({t for t in (1, 4, 8, 16, 32, 64, 128) if t <= cores})
@@ -118,7 +118,7 @@ def cpu_baseline(wl, batches_cpu, seconds):
         steps += 1
     dt = time.perf_counter() - t0
     return dict(value=n / dt, unit="graphs/s", cores=best_t, kind="port", host_cores=cores,
-                sample="%d train steps of batch %d (same synthetic SPMotif batches, %.1f s) through "
+                sample="%d train steps of batch %d (same synthetic batches, %.1f s) through "
                        "oracle/cal_oracle.py (unfused restatement of the PyG path); torch threads=%d "
                        "chosen by calibration %s ms/step" % (steps, wl["batch"], dt, best_t, calib),
                 ms_per_step=1e3 * dt / steps)
@@ -196,7 +196,7 @@ def engine_roofline(trainer, batches, workload, iters=20):
     n = int(h.cal_engine_profile_read(buf, cap))
     rec = np.array(buf[:3 * n], dtype=np.float64).reshape(n, 3)
     out = {}
-    for cls, key in ((0, "gemm"), (1, "spmm"), (2, "gconv"), (3, "dual"), (4, "gconv_bwd")):
+    for cls, key in ((0, "gemm"), (1, "spmm"), (2, "gconv"), (3, "dual"), (4, "gconv_bwd"), (5, "gat_fwd"), (6, "gat_bwd")):
         r = rec[(rec[:, 0] == cls) & (rec[:, 1] > 0)]
         if len(r) == 0:
             continue
@@ -220,12 +220,12 @@ def engine_roofline(trainer, batches, workload, iters=20):
     else:
         note = "event pairs include the launch gap; no PMC pass was collected for this workload (traffic null)"
     mfma = {
-        "gemm": ("k_gemm", "k_gemm<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers, unfused path)", "k_gemm_backbone"),
+        "gemm": ("k_gemm", "k_gemm / k_gemm_big<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers, unfused path; 128x128 tiles from 16k rows)", "k_gemm_backbone"),
         "gconv": ("k_gconv_fwd", "k_gconv_fwd: per-graph fused BN + [n,H]x[H,64] MFMA GEMM + dense-block aggregation MFMA + "
                                  "bias/ReLU/BN statistics (backbone layers, forward)", "k_gconv_fwd"),
         "gconv_bwd": ("k_gconv_bwd", "k_gconv_bwd: per-graph fused backward -- dense-block transposed aggregation + dX' = dz W^T (BN-backward "
                                      "sums) + dW = x'^T dz, all on MFMA (backbone layers, backward)", "k_gconv_bwd"),
-        "dual": ("k_gemm_dual", "k_gemm_dual: dX = dZ W^T (NT, BN-backward sums) + dW = BN(h)^T dZ (TN, split-K) in one grid "
+        "dual": ("k_gemm_dual", "k_gemm_dual / k_gemm_big_dual: dX = dZ W^T (NT, BN-backward sums) + dW = BN(h)^T dZ (TN, split-K) in one grid "
                                 "(backbone layers, backward)", "k_gemm_dual"),
     }
     # primary roofline = the MFMA kernel class that takes the most time per step
@@ -250,6 +250,16 @@ def engine_roofline(trainer, batches, workload, iters=20):
                                             traffic=pmc.get("k_espmm", {}).get("bytes_per_launch"),
                                             avg_launch_us=dur * 1e6, algorithmic_bytes_per_launch=work,
                                             timed_launches_per_step=per_step)
+    # GATConv layers (CausalGAT): scores + edge softmax + aggregation (forward), the five backward kernels
+    # algorithmic bytes: z and the output once each, CSR slot + 3 logits-sized [E',K] passes (+3*E'*K*4)
+    for key, label in (("gat_fwd", "GATConv forward: k_gat_scores + k_gat_fwd (edge softmax, dropout, aggregation, bias, ReLU)"),
+                       ("gat_bwd", "GATConv backward: k_gat_bwd_dst / _dasrc / _src / datt (alpha recomputed)")):
+        if key in out:
+            dur, work, per_step = out[key]
+            ach = work / dur / 1e9
+            roof["roofline_" + key] = dict(bound="hbm", kernel=label, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
+                                           traffic=None, avg_launch_us=dur * 1e6, algorithmic_bytes_per_launch=work,
+                                           timed_launches_per_step=per_step)
     return roof
 
 

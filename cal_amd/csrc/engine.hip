@@ -704,7 +704,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             { ProfScope ps(st, 0, 2.0 * N * H * H); RC(fwd_gemm(c, false, a, 1)); } STAGE();
             float* hi = e->h + (size_t)i * NH;
             {
-                ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * (8 + 12.0 * K) + (N + 1) * 4.0);
+                ProfScope ps(st, 5, 2.0 * N * H * 4 + (double)(c.E + N) * (8 + 12.0 * K) + (N + 1) * 4.0);
                 RC(gat_forward(e->rowptr_dst, e->nbr_dst, e->eid_dst, zi, e->P + e->o_conv_att[i - 1], e->P + e->o_conv_b[i - 1], 1,
                                e->gat_slope, c.training ? e->gat_p : 0.f, e->gat_seed[i - 1], (const uint64_t*)e->gat_ctr, hi,
                                sc, sc + nk, sc + 2 * nk, sc + 3 * nk, N, E, K, D, st));
@@ -1175,7 +1175,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             const int K = e->K, D = H / K;
             const size_t nk = al((size_t)e->capN * K);
             const float* sc = e->gsc + (size_t)(i - 1) * 4 * nk;
-            ProfScope ps(st, 1, 4.0 * N * H * 4 + (double)(c.E + N) * (16 + 24.0 * K));
+            ProfScope ps(st, 6, 4.0 * N * H * 4 + (double)(c.E + N) * (16 + 24.0 * K));
             RC(gat_backward(e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
                             e->gz + (size_t)(i - 1) * NH, e->P + e->o_conv_att[i - 1], sc, sc + nk, sc + 2 * nk, sc + 3 * nk, e->dZ,
                             e->gat_slope, c.training ? e->gat_p : 0.f, e->gat_seed[i - 1], (const uint64_t*)e->gat_ctr, dzi,
