@@ -188,7 +188,13 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch b0,
     constexpr int RPB = 256 / G;
     const SpmmBranch& br = blockIdx.y ? b1 : b0;
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
+    // XCD-contiguous row blocks: workgroups are dealt to the 8 XCDs round-robin, and a row's neighbours live in its
+    // own graph (block-diagonal batch).  Workgroup w therefore takes row block (w % 8) * (blocks / 8) + w / 8 -- each
+    // XCD walks one contiguous eighth of the rows, so the ~5 gathers of every feature row hit ONE L2 instead of being
+    // spread over eight (big batches: the gather volume E'*H*4 is 2.4x the algorithmic bytes and it was all fabric traffic)
+    const int per = gridDim.x >> 3;
+    const int bxr = (int)blockIdx.x < 8 * per ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int rbeg = bxr * rows_per_block, rend = min(N, rbeg + rows_per_block);
     using V = Vec<VEC>;
     const bool want = br.st_sum.on();
     BLK_CLK(0);

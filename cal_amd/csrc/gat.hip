@@ -36,6 +36,13 @@ __device__ __forceinline__ uint64_t step_seed(uint64_t seed, const uint64_t* ctr
     return ctr ? seed + *ctr * 0x9E3779B97F4A7C15ull : seed;
 }
 
+// XCD-contiguous row blocks (see k_espmm): workgroup w takes block (w % 8) * (blocks / 8) + w / 8, so each XCD's L2 serves
+// the gathers of one contiguous eighth of the (block-diagonal) batch
+__device__ __forceinline__ int xcd_block() {
+    const int per = gridDim.x >> 3;
+    return (int)blockIdx.x < 8 * per ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+}
+
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 
 // thread per (node, head)
@@ -90,7 +97,7 @@ __global__ void __launch_bounds__(256) k_gat_fwd(const int* __restrict__ rowptr,
     constexpr int RPB = 256 / G;
     seed = step_seed(seed, ctr);
     const int g = threadIdx.x / G, l = threadIdx.x % G;
-    const int i = blockIdx.x * RPB + g;
+    const int i = xcd_block() * RPB + g;
     if (i >= N) return;
     const int H = K * D;
     const int s0 = rowptr[i], s1 = rowptr[i + 1];
@@ -139,7 +146,7 @@ __global__ void __launch_bounds__(256) k_gat_bwd_dst(const int* __restrict__ row
     constexpr int RPB = 256 / G;
     seed = step_seed(seed, ctr);
     const int g = threadIdx.x / G, l = threadIdx.x % G;
-    const int i = blockIdx.x * RPB + g;
+    const int i = xcd_block() * RPB + g;
     if (i >= N) return;
     const int H = K * D;
     const int LH = D / VEC;
@@ -206,7 +213,7 @@ __global__ void __launch_bounds__(256) k_gat_bwd_src(const int* __restrict__ row
     constexpr int RPB = 256 / G;
     seed = step_seed(seed, ctr);
     const int g = threadIdx.x / G, l = threadIdx.x % G;
-    const int j = blockIdx.x * RPB + g;
+    const int j = xcd_block() * RPB + g;
     if (j >= N) return;
     const int H = K * D;
     const int s0 = rowptr[j], s1 = rowptr[j + 1];
