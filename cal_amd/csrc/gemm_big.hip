@@ -374,8 +374,7 @@ int launch_gemm_big(bool transA, bool transB, const GemmArgs& a, int nbatch, hip
     const dim3 grid(cdiv(a.M, big::T), cdiv(a.N, big::T), nbatch * a.nsplit);
     using namespace big;
     if (a_kc && !b_kc) {
-        static const int dynlds = getenv("CAL_BIG_DYNLDS") ? atoi(getenv("CAL_BIG_DYNLDS")) : 0;   // probe: extra LDS to force 1 workgroup per CU
-        if (xa == 0) hipLaunchKernelGGL((k_gemm_big<true, false, 0>), grid, dim3(256), dynlds, stream, a);
+        if (xa == 0) hipLaunchKernelGGL((k_gemm_big<true, false, 0>), grid, dim3(256), 0, stream, a);
         else if (xa == 1) hipLaunchKernelGGL((k_gemm_big<true, false, 1>), grid, dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((k_gemm_big<true, false, 2>), grid, dim3(256), 0, stream, a);
     } else if (a_kc && b_kc) {
