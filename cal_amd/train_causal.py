@@ -120,3 +120,58 @@ def train_causal_syn(train_set, val_set, test_set, model_func=None, args=None, l
         args.bias, val_acc_o * 100, update_test_acc_co * 100, update_test_acc_c * 100,
         update_test_acc_o * 100, update_epoch))
     return model, history
+
+
+def train_causal_real(dataset=None, model_func=None, args=None, log=print):
+    """train_causal.py:63-160: stratified k-fold cross-validation on a TU dataset (cal_amd/tu.py): per fold a fresh model
+    and Adam(lr, weight_decay), every epoch one training pass and one evaluation of the test fold; the reported test
+    accuracy is taken at the epoch whose fold-mean test accuracy is highest (``test_acc`` / ``test_acc_c``) and at the
+    one whose fold-mean ``test_acc_o`` is highest (``test_acc_o``), mean and std over folds.
+    Returns a dict with those figures and the per-fold / per-epoch tensors."""
+    from .tu import k_fold
+    device = _device()
+    train_accs, test_accs, test_accs_c, test_accs_o = [], [], [], []
+    random_guess = 1.0 / dataset.num_classes
+    for fold, (train_idx, test_idx, val_idx) in enumerate(zip(*k_fold(dataset, args.folds, args.epoch_select))):
+        best_test_acc, best_epoch, best_test_acc_c, best_test_acc_o = 0, 0, 0, 0
+        train_loader = DataLoader(dataset[train_idx], args.batch_size, shuffle=True)
+        test_loader = DataLoader(dataset[test_idx], args.batch_size, shuffle=False)
+        model = model_func(dataset.num_features, dataset.num_classes).to(device)
+        optimizer = Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        for epoch in range(1, args.epochs + 1):
+            train_loss, loss_c, loss_o, loss_co, train_acc = train_causal_epoch(model, optimizer, train_loader, device, args)
+            test_acc, test_acc_c, test_acc_o = eval_acc_causal(model, test_loader, device, args)
+            train_accs.append(train_acc)
+            test_accs.append(test_acc)
+            test_accs_c.append(test_acc_c)
+            test_accs_o.append(test_acc_o)
+            if test_acc > best_test_acc:
+                best_test_acc, best_epoch, best_test_acc_c, best_test_acc_o = test_acc, epoch, test_acc_c, test_acc_o
+            log("Causal | dataset:[{}] fold:[{}] | Epoch:[{}/{}] Loss:[{:.4f}={:.4f}+{:.4f}+{:.4f}] Train:[{:.4f}] "
+                "Test:[{:.2f}] Test_o:[{:.2f}] Test_c:[{:.2f}] (RG:{:.2f}) | Best Test:[{:.2f}] at Epoch:[{}] | "
+                "Test_o:[{:.2f}] Test_c:[{:.2f}]".format(
+                    getattr(args, "dataset", dataset.name), fold, epoch, args.epochs, train_loss, loss_c, loss_o, loss_co,
+                    train_acc * 100, test_acc * 100, test_acc_o * 100, test_acc_c * 100, random_guess * 100,
+                    best_test_acc * 100, best_epoch, best_test_acc_o * 100, best_test_acc_c * 100))
+    shape = (args.folds, args.epochs)
+    train_acc = torch.tensor(train_accs, dtype=torch.float64).view(shape)
+    test_acc = torch.tensor(test_accs, dtype=torch.float64).view(shape)
+    test_acc_c = torch.tensor(test_accs_c, dtype=torch.float64).view(shape)
+    test_acc_o = torch.tensor(test_accs_o, dtype=torch.float64).view(shape)
+    sel = test_acc.mean(dim=0).argmax().repeat(args.folds)
+    sel_o = test_acc_o.mean(dim=0).argmax().repeat(args.folds)
+    ar = torch.arange(args.folds)
+    pick, pick_c, pick_o = test_acc[ar, sel], test_acc_c[ar, sel], test_acc_o[ar, sel_o]
+
+    def std(t):
+        return t.std().item() if t.numel() > 1 else 0.0
+
+    res = dict(train_acc_mean=train_acc[:, -1].mean().item(), test_acc_mean=pick.mean().item(), test_acc_std=std(pick),
+               test_acc_c_mean=pick_c.mean().item(), test_acc_c_std=std(pick_c), test_acc_o_mean=pick_o.mean().item(),
+               test_acc_o_std=std(pick_o), random_guess=random_guess, train_acc=train_acc, test_acc=test_acc,
+               test_acc_c=test_acc_c, test_acc_o=test_acc_o)
+    log("sydall Final: Causal | Dataset:[{}] Model:[{}] | Test Acc: {:.2f}±{:.2f} | OTest: {:.2f}±{:.2f}, CTest: {:.2f}±{:.2f} "
+        "(RG:{:.2f})".format(getattr(args, "dataset", dataset.name), getattr(args, "model", "?"), res["test_acc_mean"] * 100,
+                             res["test_acc_std"] * 100, res["test_acc_o_mean"] * 100, res["test_acc_o_std"] * 100,
+                             res["test_acc_c_mean"] * 100, res["test_acc_c_std"] * 100, random_guess * 100))
+    return res
