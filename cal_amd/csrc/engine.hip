@@ -28,7 +28,7 @@
 namespace cal {
 
 constexpr int MAX_LAYERS = 6;
-constexpr int MAX_SLABS = 16;
+constexpr int MAX_SLABS = 24;
 constexpr int MAX_COMMITS = 64;
 
 struct FinishArgs {
@@ -169,7 +169,8 @@ int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_
                  const int32_t* rowptr_src, const int32_t* nbr_src, const int32_t* eid_src, const float* z,
                  const float* att, const float* adst, const float* asrc, const float* mx, const float* den,
                  const float* gout, float slope, float p, uint64_t seed, const uint64_t* ctr, float* dz, float* datt,
-                 float* ws, int64_t N, int64_t E, int64_t K, int64_t D, hipStream_t stream);
+                 float* ws, int64_t N, int64_t E, int64_t K, int64_t D, hipStream_t stream, float* part_out, int* nparts);
+int gat_datt_parts(int64_t N);
 int plan_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
                int32_t* rowptr_src, int32_t* nbr_src, int32_t* eid_src, int32_t* row32, int32_t* col32, int32_t* work,
                int32_t* status, bool prezeroed, hipStream_t stream);
@@ -287,6 +288,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
         return std::max<size_t>(std::max<size_t>(512 * 64 * 64, (size_t)B * M * Nn), big) + 2 * M * Nn;
     };
     slab += slab_of(F, H) + (L + 2) * slab_of(H, H) + 3 * slab_of(H, H) + 3 * slab_of(C, H);
+    if (e->K > 0) slab += L * (size_t)1024 * H;      // GATConv: <= 512 partial rows of d att [2H] per layer
     if (assign) e->slab_floats = slab;
     F32(e->slabs, slab);
     {
@@ -1176,10 +1178,17 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             const size_t nk = al((size_t)e->capN * K);
             const float* sc = e->gsc + (size_t)(i - 1) * 4 * nk;
             ProfScope ps(st, 6, 4.0 * N * H * 4 + (double)(c.E + N) * (16 + 24.0 * K));
+            // d att: per-block partial rows parked in the slab area, summed by the final k_finish (no finishing launch)
+            const size_t need = (size_t)gat_datt_parts(N) * 2 * H;
+            if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
+            float* part = e->slabs + slab_off;
+            int nparts = 0;
             RC(gat_backward(e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
                             e->gz + (size_t)(i - 1) * NH, e->P + e->o_conv_att[i - 1], sc, sc + nk, sc + 2 * nk, sc + 3 * nk, e->dZ,
                             e->gat_slope, c.training ? e->gat_p : 0.f, e->gat_seed[i - 1], (const uint64_t*)e->gat_ctr, dzi,
-                            e->G + e->o_conv_att[i - 1], e->gws, N, c.E, K, D, st));
+                            e->G + e->o_conv_att[i - 1], e->gws, N, c.E, K, D, st, part, &nparts));
+            fa.st[fa.nst++] = SlabTask{part, e->G + e->o_conv_att[i - 1], 2 * H, nparts};
+            slab_off += need;
         } else {
             SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
             ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0);

@@ -187,18 +187,6 @@ __global__ void __launch_bounds__(256) k_gat_bwd_dst(const int* __restrict__ row
     }
 }
 
-// thread per (node j, head k): dasrc[j,k] = sum over edges leaving j (+ its loop) of draw
-__global__ void k_gat_bwd_dasrc(const int* __restrict__ ptr_src, const int* __restrict__ eid_src,
-                                const float* __restrict__ draw, int64_t E, float* __restrict__ dasrc, int N, int K) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= N * K) return;
-    int j = t / K, k = t % K;
-    float s = 0.f;
-    for (int q = ptr_src[j]; q < ptr_src[j + 1]; ++q) s += draw[(int64_t)eid_src[q] * K + k];
-    s += draw[(E + j) * K + k];
-    dasrc[t] = s;
-}
-
 // dz[j,k,:] = sum_{s: src = j} alpha~_s g[dst_s,k,:] + alpha~_loop g[j,k,:]
 //           + dadst[j,k] att[k,:D] + dasrc[j,k] att[k,D:]
 template <int VEC, int G>
@@ -207,7 +195,7 @@ __global__ void __launch_bounds__(256) k_gat_bwd_src(const int* __restrict__ row
                                                      const float* __restrict__ adst, const float* __restrict__ asrc,
                                                      const float* __restrict__ mx, const float* __restrict__ den,
                                                      const float* __restrict__ gout, const float* __restrict__ dadst,
-                                                     const float* __restrict__ dasrc, float slope, float p,
+                                                     const float* __restrict__ draw, float* __restrict__ dasrc, float slope, float p,
                                                      uint64_t seed, int64_t E, float* __restrict__ dz, int N, int K, int D,
                                                      const uint64_t* __restrict__ ctr) {
     constexpr int RPB = 256 / G;
@@ -223,14 +211,17 @@ __global__ void __launch_bounds__(256) k_gat_bwd_src(const int* __restrict__ row
         const int k = c / D, d = c % D;
         const float as = asrc[(size_t)j * K + k];
         V acc = V::zero();
+        float das = 0.f;      // d a_src[j,k] = sum of d(raw logit) over the edges leaving j and its loop (was a kernel of its own)
         for (int s = s0; s <= s1; ++s) {
             const int i = s < s1 ? nbr[s] : j;
             const int64_t id = s < s1 ? (int64_t)eid[s] : E + j;
             const float alpha = expf(lrelu(adst[(size_t)i * K + k] + as, slope) - mx[(size_t)i * K + k]) / den[(size_t)i * K + k];
             acc.fma(alpha * keep_scale(seed, id, k, K, p, inv_keep), V::ld(gout + (size_t)i * H + c));
+            das += draw[id * K + k];
         }
+        if (d == 0) dasrc[(size_t)j * K + k] = das;
         acc.fma(dadst[(size_t)j * K + k], V::ld(att + (size_t)k * 2 * D + d));
-        acc.fma(dasrc[(size_t)j * K + k], V::ld(att + (size_t)k * 2 * D + D + d));
+        acc.fma(das, V::ld(att + (size_t)k * 2 * D + D + d));
         acc.st(dz + (size_t)j * H + c);
     }
 }
@@ -345,14 +336,17 @@ int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_
                  const int32_t* rowptr_src, const int32_t* nbr_src, const int32_t* eid_src, const float* z,
                  const float* att, const float* adst, const float* asrc, const float* mx, const float* den,
                  const float* gout, float slope, float p, uint64_t seed, const uint64_t* ctr, float* dz, float* datt,
-                 float* ws, int64_t N, int64_t E, int64_t K, int64_t D, hipStream_t stream) {
+                 float* ws, int64_t N, int64_t E, int64_t K, int64_t D, hipStream_t stream, float* part_out, int* nparts) {
+    // part_out != null: the per-block partial sums of d att go there ([*nparts][2 K D] floats, cal_gat_datt_parts(N) rows)
+    // and the caller reduces them (the step engine folds that into its final k_finish); datt is not written then
     int64_t H = K * D;
     int rpb = gat_rows_per_block(N);
     int nb = N == 0 ? 0 : cdiv(N, rpb);
     float* draw = ws;
     float* dadst = draw + ((E + N) * K + 3) / 4 * 4;
     float* dasrc = dadst + (N * K + 3) / 4 * 4;
-    float* part = dasrc + (N * K + 3) / 4 * 4;
+    float* part = part_out ? part_out : dasrc + (N * K + 3) / 4 * 4;
+    if (nparts) *nparts = nb;
     if (N > 0) {
         bool vec_ok = (D % 4 == 0) && pow2(D / 4) && aligned16(z) && aligned16(gout) && aligned16(dz) && aligned16(att);
         CAL_REQUIRE(vec_ok || pow2(D), "head dim must be a power of two (or 4 * a power of two)");
@@ -361,21 +355,22 @@ int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_
                                eid_dst, z, adst, asrc, mx, den, gout, slope, p, seed, E, draw, dadst, (int)N, (int)K, (int)D, ctr);
         });
         CAL_CHECK_LAUNCH("k_gat_bwd_dst");
-        hipLaunchKernelGGL(k_gat_bwd_dasrc, dim3(cdiv(N * K, 256)), dim3(256), 0, stream, rowptr_src, eid_src, draw, E, dasrc, (int)N, (int)K);
-        CAL_CHECK_LAUNCH("k_gat_bwd_dasrc");
         CAL_DISPATCH_VG((int)H, vec_ok, {
             hipLaunchKernelGGL((k_gat_bwd_src<VEC, G>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr_src, nbr_src,
-                               eid_src, att, adst, asrc, mx, den, gout, dadst, dasrc, slope, p, seed, E, dz, (int)N, (int)K, (int)D, ctr);
+                               eid_src, att, adst, asrc, mx, den, gout, dadst, draw, dasrc, slope, p, seed, E, dz, (int)N, (int)K, (int)D, ctr);
         });
         CAL_CHECK_LAUNCH("k_gat_bwd_src");
         int threads = (int)(H > 256 ? 256 : ((H + 63) / 64) * 64);
         hipLaunchKernelGGL(k_gat_datt_part, dim3(nb), dim3(threads), 0, stream, z, dadst, dasrc, part, (int)N, (int)K, (int)D, rpb);
         CAL_CHECK_LAUNCH("k_gat_datt_part");
     }
-    hipLaunchKernelGGL(k_gat_datt_finish, dim3(cdiv(2 * H, 16)), dim3(256), 0, stream, part, nb, (int)(2 * H), datt);
-    CAL_CHECK_LAUNCH("k_gat_datt_finish");
+    if (!part_out) {
+        hipLaunchKernelGGL(k_gat_datt_finish, dim3(cdiv(2 * H, 16)), dim3(256), 0, stream, part, nb, (int)(2 * H), datt);
+        CAL_CHECK_LAUNCH("k_gat_datt_finish");
+    }
     return 0;
 }
+int gat_datt_parts(int64_t N) { return N == 0 ? 0 : (int)cdiv(N, gat_rows_per_block(N)); }
 }  // namespace cal
 
 CAL_EXPORT int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst,
@@ -384,7 +379,7 @@ CAL_EXPORT int cal_gat_bwd(const int32_t* rowptr_dst, const int32_t* nbr_dst, co
                            const float* gout, float slope, float p, uint64_t seed, float* dz, float* datt, float* ws,
                            int64_t N, int64_t E, int64_t K, int64_t D, void* stream_) {
     return gat_backward(rowptr_dst, nbr_dst, eid_dst, rowptr_src, nbr_src, eid_src, z, att, adst, asrc, mx, den, gout, slope, p,
-                        seed, nullptr, dz, datt, ws, N, E, K, D, (hipStream_t)stream_);
+                        seed, nullptr, dz, datt, ws, N, E, K, D, (hipStream_t)stream_, nullptr, nullptr);
 }
 
 CAL_EXPORT int cal_gat_dropout_mask(uint64_t seed, int64_t E, int64_t N, int64_t K, float p, float* mask, void* stream_) {
