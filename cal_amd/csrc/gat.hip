@@ -107,15 +107,37 @@ __global__ void __launch_bounds__(256) k_gat_fwd(const int* __restrict__ rowptr,
         const int k = c / D;
         const float ad = adst[(size_t)i * K + k];
         const float eself = lrelu(ad + asrc[(size_t)i * K + k], slope);
+        // neighbours four at a time: ids, then the four source scores (pass 1) / the four z rows (pass 2) are requested
+        // together from clamped slots -- one dependent round trip per FOUR neighbours instead of per neighbour
         float m = eself;
-        for (int s = s0; s < s1; ++s) m = fmaxf(m, lrelu(ad + asrc[(size_t)nbr[s] * K + k], slope));
+        for (int s = s0; s < s1; s += 4) {
+            int j[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) j[q] = nbr[min(s + q, s1 - 1)];
+            float as[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) as[q] = asrc[(size_t)j[q] * K + k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m = fmaxf(m, lrelu(ad + as[q], slope));      // a repeated last slot does not change a max
+        }
         float lsum = 0.f;
         V acc = V::zero();
-        for (int s = s0; s < s1; ++s) {
-            const int j = nbr[s];
-            float pe = expf(lrelu(ad + asrc[(size_t)j * K + k], slope) - m);
-            lsum += pe;
-            acc.fma(pe * keep_scale(seed, eid[s], k, K, p, inv_keep), V::ld(z + (size_t)j * H + c));
+        for (int s = s0; s < s1; s += 4) {
+            int j[4], id[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int sq = min(s + q, s1 - 1); j[q] = nbr[sq]; id[q] = eid[sq]; }
+            float as[4];
+            V zv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { as[q] = asrc[(size_t)j[q] * K + k]; zv[q] = V::ld(z + (size_t)j[q] * H + c); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zv[q].pin();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float pe = s + q < s1 ? expf(lrelu(ad + as[q], slope) - m) : 0.f;
+                lsum += pe;
+                acc.fma(pe * keep_scale(seed, id[q], k, K, p, inv_keep), zv[q]);
+            }
         }
         {
             float pe = expf(eself - m);
@@ -159,29 +181,60 @@ __global__ void __launch_bounds__(256) k_gat_bwd_dst(const int* __restrict__ row
         const float ad = adst[(size_t)i * K + k];
         const float m = mx[(size_t)i * K + k], dn = den[(size_t)i * K + k];
         const V gi = V::ld(gout + (size_t)i * H + c);
+        // slots s0..s1 (s1 = the node's own loop), four at a time with every load of a batch requested together
         float S = 0.f;
-        for (int s = s0; s <= s1; ++s) {
-            const int j = s < s1 ? nbr[s] : i;
-            const int64_t id = s < s1 ? (int64_t)eid[s] : E + i;
-            float dot = gi.dot(V::ld(z + (size_t)j * H + c));
-            for (int o = LH / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
-            const float alpha = expf(lrelu(ad + asrc[(size_t)j * K + k], slope) - m) / dn;
-            const float dalpha = dot * keep_scale(seed, id, k, K, p, inv_keep);
-            S = fmaf(alpha, dalpha, S);
-            if (head_lead) draw[id * K + k] = dalpha;
+        for (int s = s0; s <= s1; s += 4) {
+            int j[4];
+            int64_t id[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sq = min(s + q, s1);
+                j[q] = sq < s1 ? nbr[min(sq, max(s1 - 1, 0))] : i;
+                id[q] = sq < s1 ? (int64_t)eid[min(sq, max(s1 - 1, 0))] : E + i;
+            }
+            V zv[4];
+            float as[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { zv[q] = V::ld(z + (size_t)j[q] * H + c); as[q] = asrc[(size_t)j[q] * K + k]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zv[q].pin();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float dot = gi.dot(zv[q]);
+                for (int o = LH / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+                const float alpha = expf(lrelu(ad + as[q], slope) - m) / dn;
+                const float dalpha = dot * keep_scale(seed, id[q], k, K, p, inv_keep);
+                if (s + q <= s1) {
+                    S = fmaf(alpha, dalpha, S);
+                    if (head_lead) draw[id[q] * K + k] = dalpha;
+                }
+            }
         }
         float rowsum = 0.f;
-        for (int s = s0; s <= s1; ++s) {
-            const int j = s < s1 ? nbr[s] : i;
-            const int64_t id = s < s1 ? (int64_t)eid[s] : E + i;
-            const float raw = ad + asrc[(size_t)j * K + k];
-            const float alpha = expf(lrelu(raw, slope) - m) / dn;
-            float dalpha = draw[id * K + k];        // written by this head's lead lane above
-            dalpha = __shfl(dalpha, (threadIdx.x & 63) & ~(LH - 1), 64);
-            const float de = alpha * (dalpha - S);
-            const float dr = de * (raw > 0.f ? 1.f : slope);
-            rowsum += dr;
-            if (head_lead) draw[id * K + k] = dr;
+        for (int s = s0; s <= s1; s += 4) {
+            int j[4];
+            int64_t id[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sq = min(s + q, s1);
+                j[q] = sq < s1 ? nbr[min(sq, max(s1 - 1, 0))] : i;
+                id[q] = sq < s1 ? (int64_t)eid[min(sq, max(s1 - 1, 0))] : E + i;
+            }
+            float as[4], da[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { as[q] = asrc[(size_t)j[q] * K + k]; da[q] = draw[id[q] * K + k]; }   // written by this head's lead lane above
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float raw = ad + as[q];
+                const float alpha = expf(lrelu(raw, slope) - m) / dn;
+                const float dalpha = __shfl(da[q], (threadIdx.x & 63) & ~(LH - 1), 64);
+                const float de = alpha * (dalpha - S);
+                const float dr = de * (raw > 0.f ? 1.f : slope);
+                if (s + q <= s1) {
+                    rowsum += dr;
+                    if (head_lead) draw[id[q] * K + k] = dr;
+                }
+            }
         }
         if (head_lead) dadst[(size_t)i * K + k] = rowsum;
     }
@@ -212,12 +265,32 @@ __global__ void __launch_bounds__(256) k_gat_bwd_src(const int* __restrict__ row
         const float as = asrc[(size_t)j * K + k];
         V acc = V::zero();
         float das = 0.f;      // d a_src[j,k] = sum of d(raw logit) over the edges leaving j and its loop (was a kernel of its own)
-        for (int s = s0; s <= s1; ++s) {
-            const int i = s < s1 ? nbr[s] : j;
-            const int64_t id = s < s1 ? (int64_t)eid[s] : E + j;
-            const float alpha = expf(lrelu(adst[(size_t)i * K + k] + as, slope) - mx[(size_t)i * K + k]) / den[(size_t)i * K + k];
-            acc.fma(alpha * keep_scale(seed, id, k, K, p, inv_keep), V::ld(gout + (size_t)i * H + c));
-            das += draw[id * K + k];
+        for (int s = s0; s <= s1; s += 4) {
+            int i4[4];
+            int64_t id[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sq = min(s + q, s1);
+                i4[q] = sq < s1 ? nbr[min(sq, max(s1 - 1, 0))] : j;
+                id[q] = sq < s1 ? (int64_t)eid[min(sq, max(s1 - 1, 0))] : E + j;
+            }
+            V gv[4];
+            float ad4[4], mx4[4], dn4[4], dr4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gv[q] = V::ld(gout + (size_t)i4[q] * H + c);
+                ad4[q] = adst[(size_t)i4[q] * K + k]; mx4[q] = mx[(size_t)i4[q] * K + k]; dn4[q] = den[(size_t)i4[q] * K + k];
+                dr4[q] = draw[id[q] * K + k];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gv[q].pin();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = s + q <= s1;
+                const float alpha = expf(lrelu(ad4[q] + as, slope) - mx4[q]) / dn4[q];
+                acc.fma(ok ? alpha * keep_scale(seed, id[q], k, K, p, inv_keep) : 0.f, gv[q]);
+                das += ok ? dr4[q] : 0.f;
+            }
         }
         if (d == 0) dasrc[(size_t)j * K + k] = das;
         acc.fma(dadst[(size_t)j * K + k], V::ld(att + (size_t)k * 2 * D + d));
