@@ -192,6 +192,8 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch b0,
     // own graph (block-diagonal batch).  Workgroup w therefore takes row block (w % 8) * (blocks / 8) + w / 8 -- each
     // XCD walks one contiguous eighth of the rows, so the ~5 gathers of every feature row hit ONE L2 instead of being
     // spread over eight (big batches: the gather volume E'*H*4 is 2.4x the algorithmic bytes and it was all fabric traffic)
+    // (Measured and rejected: sweeping the columns in 2 / 4 windows per ~graph-sized row chunk so that a window of the
+    // graph's features fits the 4 MB L2 -- 151 -> 158 / 166 us at config 5: the kernel is not bound by gather traffic.)
     const int per = gridDim.x >> 3;
     const int bxr = (int)blockIdx.x < 8 * per ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int rbeg = bxr * rows_per_block, rend = min(N, rbeg + rows_per_block);
