@@ -23,6 +23,7 @@
 #include "engine_readout.hpp"
 #include "engine_gconv.hpp"
 #include "engine_gconv_bwd.hpp"
+#include "engine_ggat.hpp"
 #include "engine_plan.hpp"
 
 namespace cal {
@@ -700,6 +701,23 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             float* zi = e->gz + (size_t)(i - 1) * NH;
             float* sc = e->gsc + (size_t)(i - 1) * 4 * al((size_t)e->capN * K);
             const size_t nk = al((size_t)e->capN * K);
+            if (gc && gc_small(c) && (D == 32 || D == 64) && e->max_edges <= GG_E) {      // the whole layer per graph (engine_ggat.hpp)
+                GgatArgs ga;
+                memset(&ga, 0, sizeof(ga));
+                ga.x = e->h + (size_t)(i - 1) * NH; ga.W = e->P + e->o_conv_w[i - 1]; ga.bias = e->P + e->o_conv_b[i - 1];
+                ga.att = e->P + e->o_conv_att[i - 1]; ga.bn = bnref(c, i, N, 1); ga.out = e->h + (size_t)i * NH; ga.z = zi;
+                ga.adst = sc; ga.asrc = sc + nk; ga.mx = sc + 2 * nk; ga.den = sc + 3 * nk;
+                if (c.training && i < L) { ga.st_sum = graph_acc(c, bn_stsum(c, i + 1), H); ga.st_sq = graph_acc(c, bn_stsq(c, i + 1), H); }
+                ga.heads = K; ga.D = D; ga.slope = e->gat_slope; ga.p = c.training ? e->gat_p : 0.f;
+                ga.seed = e->gat_seed[i - 1]; ga.ctr = (const uint64_t*)e->gat_ctr; ga.E = E;
+                {
+                    ProfScope ps(st, 7, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H);
+                    hipLaunchKernelGGL(k_ggat_fwd, dim3(B, H / GC_N), dim3(256), 0, st, gd, e->gptr, e->eptr, ga, H, H, e->status);
+                }
+                CAL_CHECK_LAUNCH("k_ggat_fwd"); STAGE();
+                RC(flush_finals(c)); STAGE();
+                continue;
+            }
             GemmArgs a = gemm_args(N, H, H, false, false, 0);
             a.p[0].A = e->h + (size_t)(i - 1) * NH; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = zi;
             a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 1);

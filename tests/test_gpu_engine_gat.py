@@ -208,3 +208,39 @@ def test_big_batch_takes_the_throughput_gemm_and_matches_oracle(name):
             scale = max(1.0, gref.abs().max().item())
             err = (p.grad.cpu() - gref).abs().max().item()
             assert err <= 1e-3 * scale, (k, err, scale)
+
+
+def test_fused_per_graph_gat_forward_with_dropout_matches_oracle():
+    """hidden 128 / 4 heads (D = 32) on SPMotif graphs (<= 64 nodes): the backbone layers run on k_ggat_fwd (engine_ggat.hpp);
+    one train step with p = 0.2 attention dropout and fixed per-layer seeds, masks fed to the oracle."""
+    ids = list(range(24))
+    b, bd = ref_batch(ids), ref_batch(ids).to(DEV)
+    assert 0 < bd.max_nodes <= 64
+    torch.manual_seed(11)
+    sd = O.init_state("CausalGAT", 10, 4, hidden=128, layers=3, heads=4)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args())
+    for i, c in enumerate(m.convs):
+        c.seed = 500 + i
+    tr = O.CpuTrainer("CausalGAT", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=3, heads=4, gat_dropout=0.2,
+                      gat_masks=_masks([c.seed for c in m.convs], bd, b, 4, 0.2))
+    perm = torch.randperm(len(ids))
+    loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
+    lp = eng.buffer("logp", 3 * len(ids) * 4).view(3, len(ids), 4).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is not None:
+            assert torch.allclose(p.grad.cpu(), gref, atol=5e-5, rtol=2e-3), k
+    # the status word stays clean and the unfused path (no per-graph bounds) gives the same logits
+    assert int(eng.buffer("status", 1, torch.int32)[0].item()) == 0
+    bd2 = ref_batch(ids).to(DEV)
+    bd2.max_nodes = bd2.max_edges = 0
+    m2, eng2 = _engine({k: v.clone() for k, v in sd.items()}, _args())
+    for i, c in enumerate(m2.convs):
+        c.seed = 500 + i
+    eng2.train_step(bd2, perm.to(DEV), adam=False)
+    lp2 = eng2.buffer("logp", 3 * len(ids) * 4).view(3, len(ids), 4).cpu()
+    assert (lp - lp2).abs().max().item() < 2e-5
