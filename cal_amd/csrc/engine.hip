@@ -1136,6 +1136,48 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     for (int i = L; i >= 1; --i) {
         float* dzi = e->dzi + (size_t)(i - 1) * NH;     // per layer: the side-stream dW GEMM reads it later
         const bool gat = e->K > 0;
+        if (gat && gcb && (H / e->K == 32 || H / e->K == 64) && e->max_edges <= GGB_E) {
+            // GATConv layer backward per graph (engine_ggat.hpp): attention backward + dX' (two slice partials) + dW / d att slabs
+            const int K = e->K, D = H / K, nsl = H / GC_N;
+            const size_t nk = al((size_t)e->capN * K);
+            const float* sc = e->gsc + (size_t)(i - 1) * 4 * nk;
+            const float* hin = e->h + (size_t)(i - 1) * NH;
+            GgatBwdArgs ga;
+            memset(&ga, 0, sizeof(ga));
+            ga.dout = e->dZ; ga.x = hin; ga.W = e->P + e->o_conv_w[i - 1]; ga.att = e->P + e->o_conv_att[i - 1];
+            ga.z = e->gz + (size_t)(i - 1) * NH; ga.adst = sc; ga.asrc = sc + nk; ga.mx = sc + 2 * nk; ga.den = sc + 3 * nk;
+            ga.bn = bnref(c, i, N, 0); ga.dxp0 = e->dXh; ga.dxp1 = dzi;
+            ga.heads = K; ga.D = D; ga.slope = e->gat_slope; ga.p = c.training ? e->gat_p : 0.f;
+            ga.seed = e->gat_seed[i - 1]; ga.ctr = (const uint64_t*)e->gat_ctr; ga.E = c.E;
+            const size_t need_w = (size_t)B * H * H, need_a = (size_t)B * 2 * H;
+            if (slab_off + need_w + need_a > e->slab_floats || fa.nst + 2 > MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
+            ga.slab = e->slabs + slab_off;
+            fa.st[fa.nst++] = SlabTask{ga.slab, e->G + e->o_conv_w[i - 1], H * H, B};
+            slab_off += need_w;
+            ga.att_slab = e->slabs + slab_off;
+            fa.st[fa.nst++] = SlabTask{ga.att_slab, e->G + e->o_conv_att[i - 1], 2 * H, B};
+            slab_off += need_a;
+            double* pp = parts_alloc(c, (size_t)B * nsl * 2 * H);
+            if (!pp) { set_error("engine: partial-row workspace exhausted"); return 2; }
+            ga.dot_parts = pp;
+            final_task(c, pp, B * nsl, 2 * H, H, bn_dsum(c, i));
+            final_task(c, pp + H, B * nsl, 2 * H, H, bn_dprod(c, i));
+            {
+                ProfScope ps(st, 8, 4.0 * N * H * H + 4.0 * (double)(c.E + N) * H);
+                hipLaunchKernelGGL(k_ggat_bwd, dim3(B, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+            }
+            CAL_CHECK_LAUNCH("k_ggat_bwd"); STAGE();
+            RC(flush_finals(c)); STAGE();
+            BnBwdProb p{e->dXh, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i),
+                        i >= 2 ? deferred(H, d_convb[i - 2]) : Acc(), H > GC_N ? dzi : nullptr};
+            RC(with_g(H, [&](auto g) {
+                constexpr int G = decltype(g)::value;
+                hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
+                return 0;
+            }));
+            CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();
+            continue;
+        }
         if (gcb && !gat) {
             // Layer i reads dOut = e->dZ (i == L, written by k_att_bwd) or builds it while staging from layer i+1's
             // partial dX' (BatchNorm_{i+1}-backward + ReLU mask fused in: no k_bn_bwd launch, no dZ round trip);

@@ -18,7 +18,8 @@
 namespace cal {
 
 constexpr int GG_T = 64;                       // nodes per graph
-constexpr int GG_E = 1024;                     // stored edges per graph
+constexpr int GG_E = 1024;                     // stored edges per graph (forward)
+constexpr int GGB_E = 512;                     // ... for the fused backward (three per-slot arrays in LDS)
 
 struct GgatArgs {
     const float* x;          // [N,K] layer input (raw)
@@ -176,7 +177,13 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
     if (pair) {
         const float* zr = Zs + pi * GC_LDZ + ph * D;
         const float* av = att_s + ph * 2 * D;
-        for (int d = 0; d < D; ++d) { my_ad = fmaf(zr[d], av[d], my_ad); my_as = fmaf(zr[d], av[D + d], my_as); }
+        for (int d0 = 0; d0 < D; d0 += 8) {                  // 24 independent LDS reads per round (D is 32 or 64)
+            float zz[8], a1[8], a2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { zz[u] = zr[d0 + u]; a1[u] = av[d0 + u]; a2[u] = av[D + d0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { my_ad = fmaf(zz[u], a1[u], my_ad); my_as = fmaf(zz[u], a2[u], my_as); }
+        }
         ad_s[ph][pi] = my_ad; as_s[ph][pi] = my_as;
         a.adst[(size_t)(g0 + pi) * a.heads + h0 + ph] = my_ad;
         a.asrc[(size_t)(g0 + pi) * a.heads + h0 + ph] = my_as;
@@ -257,6 +264,312 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
     if (w < 2 && lk == 0 && want) {
         a.st_sum.add(col, red[w][0][li] + red[w + 2][0][li]);
         a.st_sq.add(col, red[w][1][li] + red[w + 2][1][li]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Per-graph fused GATConv layer, backward.  With g = dOut (gradient at the layer output, ReLU mask applied), per head:
+//     dalpha_ij = keep_ij <g_i, z_j>,   S_i = sum_j alpha_ij dalpha_ij,   de_ij = alpha_ij (dalpha_ij - S_i),
+//     dr_ij = de_ij lrelu'(a_dst_i + a_src_j),   d a_dst_i = sum_j dr_ij,   d a_src_j = sum_i dr_ij,
+//     dz_j = sum_i alpha_ij keep_ij g_i + d a_dst_j att_dst + d a_src_j att_src,   d att = (sum_j d a_dst_j z_j, sum_j d a_src_j z_j)
+// then, exactly as k_gconv_bwd (engine_gconv_bwd.hpp):  dX' = dz W^T (partial per 64-column slice, + BatchNorm-backward
+// sums),  dW = x'^T dz (per-graph slab).  One workgroup per (graph, 64-column slice = 64 / D heads), 512 threads; the
+// heads of the slice go one after the other through two dense 64 x 64 blocks in LDS: dalpha = G_h Z_h^T on MFMA, the two
+// passes over the CSR slots of every destination row, alpha~^T, dz_h = alpha~^T G_h on MFMA.  Replaces k_gat_bwd_dst /
+// _src / k_gat_datt_part + the dual GEMM; z and the saved scores / max / denominator come from the forward.
+// ------------------------------------------------------------------------------------------------------------------
+struct GgatBwdArgs {
+    const float* dout;       // [N,H]
+    const float* x;          // [N,K] raw layer input
+    const float* W;          // [K,H]
+    const float* att;        // [heads, 2 D]
+    const float* z;          // [N,H] BN(x) W of the forward
+    const float* adst; const float* asrc; const float* mx; const float* den;     // [N,heads] of the forward
+    BNRef bn;
+    float* dxp0; float* dxp1; // [N,K] partial dX' of output-column slice 0 / 1
+    float* slab;             // [B][K,H] per-graph dW
+    float* att_slab;         // [B][heads * 2 D] per-graph d att
+    double* dot_parts;       // [B * H/64][2K]
+    int heads, D;
+    float slope, p;
+    uint64_t seed;
+    const uint64_t* ctr;
+    int64_t E;
+};
+
+__global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
+                                                  const GgatBwdArgs a, int N, int H, int K, int* __restrict__ status) {
+    constexpr int T = GB_T;
+    __shared__ __attribute__((aligned(16))) float Bk[T * GB_LDJ];          // alpha~ of the current head: Bk[i][j] (edge j -> i)
+    __shared__ __attribute__((aligned(16))) float Ds[T * GB_LDD];          // dOut slice [j][n]; later dz [i][n]
+    __shared__ __attribute__((aligned(16))) float Zt[GC_N * GB_LDJ];       // dalpha of the current head [i][j]; later dz^T [n][i]
+    __shared__ __attribute__((aligned(16))) float Wt[GC_N * GB_LDW];       // W[:, ns]^T: Wt[n][k_in]
+    __shared__ __attribute__((aligned(16))) float Xs[T * GB_LDX];          // x_hat rows [i][k_in]
+    __shared__ __attribute__((aligned(16))) float Zr[T * GB_LDD];          // z slice [j][n]
+    __shared__ float mean_s[GC_K], rstd_s[GC_K], gam_s[GC_K], bet_s[GC_K];
+    __shared__ int ptr_s[T + 4];
+    __shared__ signed char en[GGB_E], er[GGB_E];        // source / destination node of a CSR slot, local to the graph
+    __shared__ int ee[GGB_E];
+    __shared__ float al_s[GGB_E + T], ak_s[GGB_E + T], dk_s[GGB_E + T], S_s[T];     // per slot (edges, then self loops), current head
+    __shared__ float att_s[2 * GC_N];
+    __shared__ float ad_s[2][T], as_s[2][T], mx_s[2][T], dn_s[2][T], dad_s[2][T], das_s[2][T];
+    const int b = blockIdx.x, sl = blockIdx.y, ns0 = sl * GC_N, t = threadIdx.x;
+    const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
+    const int lane = t & 63, li = lane & 31, lk = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int D = a.D, hs = GC_N / D, h0 = ns0 / D;
+    double* parts = a.dot_parts + ((size_t)sl * gridDim.x + b) * (2 * K);
+    float* slab = a.slab + (size_t)b * K * H;
+    float* aslab = a.att_slab + (size_t)b * a.heads * 2 * D + (size_t)h0 * 2 * D;      // this slice's hs * 2 D = 128 entries
+    if (rows <= 0 || rows > T || ne > GGB_E || ne < 0) {
+        if (rows > 0 && t == 0) atomicOr(status, 8);
+        for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
+        for (int i = t; i < K * GC_N; i += GB_NT) slab[(size_t)(i / GC_N) * H + ns0 + i % GC_N] = 0.f;
+        if (t < 2 * GC_N) aslab[t] = 0.f;
+        return;
+    }
+    const int rowsP = (rows + 31) & ~31, R = rowsP >> 5, K4 = K >> 2;
+    // ---- every global load of the kernel, issued before the first wait ------------------------------------------
+    RoBatch<float4, 2> bd, bz;                           // dOut / z [g0 + j][ns0 + 4 n4 ..]: rows x 16 float4
+    RoBatch<float4, 4> bx, bw;                           // x[g0 + i][4 k4 ..];  W[k_in][ns0 + 4 n4 ..]
+    ro_issue<GB_NT>(bd, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(a.dout + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+    ro_issue<GB_NT>(bz, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(a.z + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+    ro_issue<GB_NT>(bx, rows, K4, [&](int i, int k4) { return *reinterpret_cast<const float4*>(a.x + (size_t)(g0 + i) * K + 4 * k4); });
+    ro_issue<GB_NT>(bw, K, 16, [&](int k, int n4) { return *reinterpret_cast<const float4*>(a.W + (size_t)k * H + ns0 + 4 * n4); });
+    const int pv = g.ptr[g0 + min(t, rows)];
+    int nv[2], ev[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int s = e0 + max(min(t + u * GB_NT, ne - 1), 0);
+        nv[u] = ne > 0 ? g.nbr[s] : g0;
+        ev[u] = ne > 0 ? g.eid[s] : 0;
+    }
+    // forward scores of this slice's heads: lane (kind, head, node) = (t >> 7, (t >> 6) & 1, t & 63)
+    const int sn = t & 63, sh = (t >> 6) & 1, sk = t >> 7;
+    float scv = 0.f;
+    if (sh < hs) {
+        const float* src = sk == 0 ? a.adst : (sk == 1 ? a.asrc : (sk == 2 ? a.mx : a.den));
+        scv = src[(size_t)(g0 + min(sn, rows - 1)) * a.heads + h0 + sh];
+    }
+    const float attv = t < 2 * GC_N ? a.att[(size_t)h0 * 2 * D + t] : 0.f;
+    if (t < K) {
+        float m1[1], r1[1];
+        bn_mean_rstd_v<1>(a.bn, t, m1, r1);
+        mean_s[t] = m1[0]; rstd_s[t] = r1[0];
+        gam_s[t] = a.bn.gamma ? a.bn.gamma[t] : 1.f;
+        bet_s[t] = a.bn.beta ? a.bn.beta[t] : 0.f;
+    }
+    // ---- stage everything in LDS -----------------------------------------------------------------------------------
+    if (t <= rows) ptr_s[t] = pv - e0;
+    {
+        const int pn = g.ptr[g0 + min(t + 1, rows)];        // (second pointer of this lane's row: one more load in the first round)
+        if (t < rows) for (int s = pv - e0; s < pn - e0; ++s) er[s] = (signed char)t;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int s = t + u * GB_NT;
+        if (s < ne) {
+            const int loc = nv[u] - g0;
+            const bool inb = loc >= 0 && loc < rows;
+            en[s] = (signed char)(inb ? loc : -1); ee[s] = ev[u];
+            if (!inb) atomicOr(status, 16);
+        }
+    }
+    if (sh < hs) {
+        float* dst = sk == 0 ? &ad_s[sh][sn] : (sk == 1 ? &as_s[sh][sn] : (sk == 2 ? &mx_s[sh][sn] : &dn_s[sh][sn]));
+        *dst = sn < rows ? scv : (sk == 3 ? 1.f : 0.f);
+    }
+    if (t < 2 * GC_N) att_s[t] = attv;
+    if (t < 2 * T) { dad_s[t >> 6][t & 63] = 0.f; das_s[t >> 6][t & 63] = 0.f; }
+    ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
+    ro_commit<GB_NT>(bz, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Zr + j * GB_LDD + 4 * n4) = v; });
+    ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) {
+        float* d = Wt + (4 * n4) * GB_LDW + k;
+        d[0] = v.x; d[GB_LDW] = v.y; d[2 * GB_LDW] = v.z; d[3 * GB_LDW] = v.w;
+    });
+    __syncthreads();                                     // BN constants
+    ro_commit<GB_NT>(bx, rows, K4, [&](int i, int k4, float4 v) {
+        const int k = 4 * k4;
+        v.x = (v.x - mean_s[k]) * rstd_s[k]; v.y = (v.y - mean_s[k + 1]) * rstd_s[k + 1];
+        v.z = (v.z - mean_s[k + 2]) * rstd_s[k + 2]; v.w = (v.w - mean_s[k + 3]) * rstd_s[k + 3];
+        *reinterpret_cast<float4*>(Xs + i * GB_LDX + k) = v;
+    });
+    for (int i = t; i < (rowsP - rows) * GB_LDD; i += GB_NT) { Ds[rows * GB_LDD + i] = 0.f; Zr[rows * GB_LDD + i] = 0.f; }
+    for (int i = t; i < (rowsP - rows) * GB_LDX; i += GB_NT) Xs[rows * GB_LDX + i] = 0.f;
+    __syncthreads();
+    auto ident = [](float v) { return v; };
+    gc_f32x16 acc[2], dzacc[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dzacc[0][i] = 0.f; dzacc[1][i] = 0.f; }
+    const uint64_t seed = step_seed(a.seed, a.ctr);
+    const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
+    const int rt = w >> 1, ct = w & 1;                   // waves 0-3: the 32 x 32 tile (rt, ct) of a 64 x 64 product
+    // ---- the heads of the slice, one after the other ------------------------------------------------------------------
+    for (int h = 0; h < hs; ++h) {
+        const int hg = h0 + h;
+        // (a) dalpha block: Zt[i][j] = <g_i, z_j> over the head's D columns (rows i x columns j, reduction over D)
+        if (w < 4 && rt < R && ct < R) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+            gb_mma<1, 1, 1, 1>(Ds + (rt * 32 + li) * GB_LDD + h * D, nullptr, Zr + (ct * 32 + li) * GB_LDD + h * D, nullptr, D, lk, ident, acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                Zt[i * GB_LDJ + ct * 32 + li] = acc[0][r];
+            }
+        }
+        for (int i = t; i < (T * GB_LDJ) / 4; i += GB_NT) reinterpret_cast<float4*>(Bk)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        // (b1) one lane per slot -- the graph's edges, then one self loop per node: alpha, alpha * keep, keep * dalpha.
+        //      (One lane per destination ROW made the hub rows of a BA graph the critical path: 2 passes x 30 slots of
+        //      expf + mask hash in one lane, 7 us per head.)
+        for (int s = t; s < ne + rows; s += GB_NT) {
+            const bool self = s >= ne;
+            const int i = self ? s - ne : er[s], j = self ? s - ne : en[s];
+            float al = 0.f, kp = 0.f, dk = 0.f;
+            if (j >= 0) {
+                al = expf(gg_lrelu(ad_s[h][i] + as_s[h][j], a.slope) - mx_s[h][i]) / dn_s[h][i];
+                kp = keep_scale(seed, self ? a.E + g0 + i : (int64_t)ee[s], hg, a.heads, a.p, inv_keep);
+                dk = Zt[i * GB_LDJ + j] * kp;
+            }
+            al_s[s] = al; ak_s[s] = al * kp; dk_s[s] = dk;
+        }
+        __syncthreads();
+        // (b2) one lane per destination row: S_i = sum over its slots of alpha * dalpha (plain LDS sums, fixed order)
+        if (t < rows) {
+            float S = al_s[ne + t] * dk_s[ne + t];
+            const int s1 = ptr_s[t + 1];
+            for (int s = ptr_s[t]; s < s1; s += 8) {         // 16 independent LDS reads per round (a plain loop exposes every latency)
+                float x[8], y[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int sq = min(s + q, s1 - 1); x[q] = al_s[sq]; y[q] = dk_s[sq]; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) S = fmaf(s + q < s1 ? x[q] : 0.f, y[q], S);
+            }
+            S_s[t] = S;
+        }
+        __syncthreads();
+        // (b3) one lane per slot: d(raw logit) (over dk_s), alpha~ into the block (atomic: duplicate edges share an entry)
+        for (int s = t; s < ne + rows; s += GB_NT) {
+            const bool self = s >= ne;
+            const int i = self ? s - ne : er[s], j = self ? s - ne : en[s];
+            float dr = 0.f;
+            if (j >= 0) {
+                const float raw = ad_s[h][i] + as_s[h][j];
+                dr = al_s[s] * (dk_s[s] - S_s[i]) * (raw > 0.f ? 1.f : a.slope);
+                atomicAdd(&Bk[i * GB_LDJ + j], ak_s[s]);
+            }
+            dk_s[s] = dr;
+        }
+        __syncthreads();
+        // (c) waves 0-3: dz tile (rows j, 32 columns of this head) = alpha~^T G_h; waves 4-5: d a_dst_i (row sums of dr);
+        //     waves 6-7: d a_src_j (the slots whose source is j, scanned in slot order: deterministic)
+        if (w < 4) {
+            if (rt < R && (ct * 32) / D == h) gb_mma<1, 1, GB_LDJ, GB_LDD>(Bk + rt * 32 + li, nullptr, Ds + ct * 32 + li, nullptr, rowsP, lk, ident, dzacc);
+        } else if (w < 6) {
+            const int i = t - 256;
+            if (i < rows) {
+                float sd = dk_s[ne + i];
+                const int s1 = ptr_s[i + 1];
+                for (int s = ptr_s[i]; s < s1; s += 8) {
+                    float y[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) y[q] = dk_s[min(s + q, s1 - 1)];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sd += s + q < s1 ? y[q] : 0.f;
+                }
+                dad_s[h][i] = sd;
+            }
+        } else {
+            // two lanes per source node j, each scanning one half of the slots in order; lane 0 adds the halves
+            const int j = (t - 384) >> 1, half = (t - 384) & 1;
+            const int qb = half ? (ne + 1) / 2 : 0, qe = half ? ne : (ne + 1) / 2;
+            float sj = 0.f;
+            if (j < rows) {
+                for (int q0 = qb; q0 < qe; q0 += 8) {
+                    int e8[8];
+                    float y[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const int sq = min(q0 + q, qe - 1); e8[q] = en[sq]; y[q] = dk_s[sq]; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sj += (q0 + q < qe && e8[q] == j) ? y[q] : 0.f;
+                }
+            }
+            const float other = __shfl_xor(sj, 1, 64);
+            if (j < rows && half == 0) das_s[h][j] = dk_s[ne + j] + sj + other;
+        }
+        __syncthreads();
+    }
+    // ---- dz = aggregated part + the two rank-1 terms; d att of this slice's heads -----------------------------------------
+    if (w < 4 && rt < R) {
+        const int n = ct * 32 + li, hh = n / D, d = n % D;
+        const float a_dst = att_s[hh * 2 * D + d], a_src = att_s[hh * 2 * D + D + d];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float v = dzacc[0][r] + dad_s[hh][j] * a_dst + das_s[hh][j] * a_src;
+            Zt[n * GB_LDJ + j] = v;
+            Ds[j * GB_LDD + n] = v;
+        }
+    } else if (w >= 4 && t - 256 < 2 * GC_N) {
+        const int q = t - 256, hh = q / (2 * D), r2 = q % (2 * D);
+        if (hh < hs) {
+            const float* wv = r2 < D ? dad_s[hh] : das_s[hh];
+            const int c = hh * D + (r2 < D ? r2 : r2 - D);
+            float s = 0.f;
+            for (int j0 = 0; j0 < rows; j0 += 8) {            // 16 independent LDS reads per round
+                float x[8], y[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = min(j0 + u, rows - 1); x[u] = wv[j]; y[u] = Zr[j * GB_LDD + c]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = fmaf(j0 + u < rows ? x[u] : 0.f, y[u], s);
+            }
+            aslab[q] = s;
+        }
+    }
+    __syncthreads();
+    // ---- P2: partial dX'[:, :] = dz[:, ns] W[:, ns]^T (+ BatchNorm-backward sums), as k_gconv_bwd ---------------------------
+    if (w < 4 && w * 32 < K) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+        if (R == 2) gb_mma<2, 1, GB_LDJ, GB_LDW>(Zt + li, Zt + 32 + li, Wt + w * 32 + li, nullptr, GC_N, lk, ident, acc);
+        else gb_mma<1, 1, GB_LDJ, GB_LDW>(Zt + li, nullptr, Wt + w * 32 + li, nullptr, GC_N, lk, ident, acc);
+        const int k = w * 32 + li;
+        float* dxp = sl ? a.dxp1 : a.dxp0;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (q < R) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (i < rows) {
+                        const float v = acc[q][r];
+                        dxp[(size_t)(g0 + i) * K + k] = v;
+                        s1 += (double)v; s2 += (double)v * (double)Xs[i * GB_LDX + k];
+                    }
+                }
+            }
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lk == 0) { parts[k] = s1; parts[K + k] = s2; }
+    }
+    // ---- P3: dW[:, ns] (this graph) = x'^T dz[:, ns] ------------------------------------------------------------------------
+    if (w >= 4 && (w - 4) * 32 < K) {
+        const int wq = w - 4, k = wq * 32 + li;
+        const float gam = gam_s[k], bet = bet_s[k];
+        auto affine = [&](float v) { return fmaf(v, gam, bet); };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+        gb_mma<1, 2, GB_LDX, GB_LDD>(Xs + wq * 32 + li, nullptr, Ds + li, Ds + 32 + li, rowsP, lk, affine, acc);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kk = wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                slab[(size_t)kk * H + ns0 + q * 32 + li] = acc[q][r];
+            }
     }
 }
 
