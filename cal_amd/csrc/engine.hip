@@ -1137,18 +1137,33 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         float* dzi = e->dzi + (size_t)(i - 1) * NH;     // per layer: the side-stream dW GEMM reads it later
         const bool gat = e->K > 0;
         if (gat && gcb && (H / e->K == 32 || H / e->K == 64) && e->max_edges <= GGB_E) {
-            // GATConv layer backward per graph (engine_ggat.hpp): attention backward + dX' (two slice partials) + dW / d att slabs
+            // GATConv layer backward per graph (engine_ggat.hpp): attention backward + dX' (two slice partials) + dW / d att
+            // slabs.  As in the GCNConv path below, layer i < L builds its dOut from layer i+1's partials while staging
+            // (BatchNorm_{i+1}-backward + ReLU mask + bias sums: no k_bn_bwd launch, no dZ round trip); slice-0 partials
+            // ping-pong between dXh and z (idle in the fused forward), slice-1 partials are per layer.
             const int K = e->K, D = H / K, nsl = H / GC_N;
             const size_t nk = al((size_t)e->capN * K);
             const float* sc = e->gsc + (size_t)(i - 1) * 4 * nk;
             const float* hin = e->h + (size_t)(i - 1) * NH;
+            float* p0 = ((L - i) & 1) ? e->z : e->dXh;
             GgatBwdArgs ga;
             memset(&ga, 0, sizeof(ga));
-            ga.dout = e->dZ; ga.x = hin; ga.W = e->P + e->o_conv_w[i - 1]; ga.att = e->P + e->o_conv_att[i - 1];
+            ga.x = hin; ga.W = e->P + e->o_conv_w[i - 1]; ga.att = e->P + e->o_conv_att[i - 1];
             ga.z = e->gz + (size_t)(i - 1) * NH; ga.adst = sc; ga.asrc = sc + nk; ga.mx = sc + 2 * nk; ga.den = sc + 3 * nk;
-            ga.bn = bnref(c, i, N, 0); ga.dxp0 = e->dXh; ga.dxp1 = dzi;
+            ga.bn = bnref(c, i, N, 0); ga.dxp0 = p0; ga.dxp1 = dzi;
             ga.heads = K; ga.D = D; ga.slope = e->gat_slope; ga.p = c.training ? e->gat_p : 0.f;
             ga.seed = e->gat_seed[i - 1]; ga.ctr = (const uint64_t*)e->gat_ctr; ga.E = c.E;
+            if (i == L) ga.dout = e->dZ;
+            else {
+                ga.dy0 = ((L - i - 1) & 1) ? e->z : e->dXh;
+                ga.dy1 = H > GC_N ? e->dzi + (size_t)i * NH : nullptr;
+                ga.y = e->h + (size_t)i * NH;
+                ga.ubn = bnref(c, i + 1, N, 0); ga.udot_sum = bn_dsum(c, i + 1); ga.udot_prod = bn_dprod(c, i + 1);
+                Deferred& db = d_convb[i - 1];
+                db.p = parts_alloc(c, (size_t)B * H); db.P = B; db.stride = H;
+                if (!db.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+                ga.bias_parts = db.p;
+            }
             const size_t need_w = (size_t)B * H * H, need_a = (size_t)B * 2 * H;
             if (slab_off + need_w + need_a > e->slab_floats || fa.nst + 2 > MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
             ga.slab = e->slabs + slab_off;
@@ -1164,18 +1179,38 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             final_task(c, pp + H, B * nsl, 2 * H, H, bn_dprod(c, i));
             {
                 ProfScope ps(st, 8, 4.0 * N * H * H + 4.0 * (double)(c.E + N) * H);
-                hipLaunchKernelGGL(k_ggat_bwd, dim3(B, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+                if (i == L) hipLaunchKernelGGL((k_ggat_bwd<false>), dim3(B, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+                else hipLaunchKernelGGL((k_ggat_bwd<true>), dim3(B, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
             }
             CAL_CHECK_LAUNCH("k_ggat_bwd"); STAGE();
             RC(flush_finals(c)); STAGE();
-            BnBwdProb p{e->dXh, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i),
-                        i >= 2 ? deferred(H, d_convb[i - 2]) : Acc(), H > GC_N ? dzi : nullptr};
-            RC(with_g(H, [&](auto g) {
-                constexpr int G = decltype(g)::value;
-                hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
-                return 0;
-            }));
-            CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();
+            if (i == 1 && F <= FB_F && H <= FB_H) {
+                // the feature layer's backward per graph, fed from this layer's partial dX' (as in the GCNConv path)
+                FeatBwdArgs fb;
+                memset(&fb, 0, sizeof(fb));
+                fb.dy0 = p0; fb.dy1 = H > GC_N ? dzi : nullptr; fb.y = hin;
+                fb.ubn = bnref(c, 1, N, 0); fb.udot_sum = bn_dsum(c, 1); fb.udot_prod = bn_dprod(c, 1);
+                fb.x0 = x0; fb.W = e->P + e->o_feat_w; fb.bn0 = bnref(c, 0, N, 0);
+                const size_t need = (size_t)B * F * H;
+                if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
+                fb.slab = e->slabs + slab_off;
+                fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, B};
+                slab_off += need;
+                d_bn0.p = parts_alloc(c, (size_t)B * 2 * F); d_bn0.P = B; d_bn0.stride = 2 * F;
+                if (!d_bn0.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+                fb.parts = d_bn0.p;
+                hipLaunchKernelGGL(k_feat_bwd, dim3(B), dim3(GB_NT), 0, st, e->gptr, fb, H, F, e->status);
+                CAL_CHECK_LAUNCH("k_feat_bwd"); STAGE();
+                feat_done = true;
+            } else if (i == 1) {       // the feature layer below is a plain GEMM: materialise dZ for it
+                BnBwdProb p{p0, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i), Acc(), H > GC_N ? dzi : nullptr};
+                RC(with_g(H, [&](auto g) {
+                    constexpr int G = decltype(g)::value;
+                    hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
+                    return 0;
+                }));
+                CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();
+            }
             continue;
         }
         if (gcb && !gat) {

@@ -295,11 +295,22 @@ struct GgatBwdArgs {
     uint64_t seed;
     const uint64_t* ctr;
     int64_t E;
+    // UP variant (as k_gconv_bwd's): dOut is not materialised but built while it is staged from the layer ABOVE's two
+    // partial dX' (its BatchNorm-backward + this layer's ReLU mask); the per-graph column sums of dOut (this layer's
+    // bias gradient) go to bias_parts [B][H].
+    const float* dy0; const float* dy1;
+    const float* y;          // [N,H] this layer's output after ReLU = the upper BatchNorm's input
+    BNRef ubn;
+    const double* udot_sum; const double* udot_prod;
+    double* bias_parts;
 };
 
+template <bool UP>
 __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                   const GgatBwdArgs a, int N, int H, int K, int* __restrict__ status) {
     constexpr int T = GB_T;
+    __shared__ float um_s[GC_N], ur_s[GC_N], ug_s[GC_N], u1_s[GC_N], u2_s[GC_N];     // upper BatchNorm, this slice's columns
+    __shared__ float bs_s[GB_NT / 64][16][4];
     __shared__ __attribute__((aligned(16))) float Bk[T * GB_LDJ];          // alpha~ of the current head: Bk[i][j] (edge j -> i)
     __shared__ __attribute__((aligned(16))) float Ds[T * GB_LDD];          // dOut slice [j][n]; later dz [i][n]
     __shared__ __attribute__((aligned(16))) float Zt[GC_N * GB_LDJ];       // dalpha of the current head [i][j]; later dz^T [n][i]
@@ -326,13 +337,22 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
         for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
         for (int i = t; i < K * GC_N; i += GB_NT) slab[(size_t)(i / GC_N) * H + ns0 + i % GC_N] = 0.f;
         if (t < 2 * GC_N) aslab[t] = 0.f;
+        if (UP && t < GC_N) a.bias_parts[(size_t)b * H + ns0 + t] = 0.0;
         return;
     }
     const int rowsP = (rows + 31) & ~31, R = rowsP >> 5, K4 = K >> 2;
     // ---- every global load of the kernel, issued before the first wait ------------------------------------------
-    RoBatch<float4, 2> bd, bz;                           // dOut / z [g0 + j][ns0 + 4 n4 ..]: rows x 16 float4
+    RoBatch<float4, 2> bd, bd1, by, bz;                  // dOut (UP: dy0, dy1, y) / z [g0 + j][ns0 + 4 n4 ..]: rows x 16 float4
     RoBatch<float4, 4> bx, bw;                           // x[g0 + i][4 k4 ..];  W[k_in][ns0 + 4 n4 ..]
-    ro_issue<GB_NT>(bd, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(a.dout + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+    {
+        const float* d0 = UP ? a.dy0 : a.dout;
+        ro_issue<GB_NT>(bd, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(d0 + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+        if (UP) {
+            const float* d1 = a.dy1 ? a.dy1 : a.dy0;
+            ro_issue<GB_NT>(bd1, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(d1 + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+            ro_issue<GB_NT>(by, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(a.y + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
+        }
+    }
     ro_issue<GB_NT>(bz, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(a.z + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
     ro_issue<GB_NT>(bx, rows, K4, [&](int i, int k4) { return *reinterpret_cast<const float4*>(a.x + (size_t)(g0 + i) * K + 4 * k4); });
     ro_issue<GB_NT>(bw, K, 16, [&](int k, int n4) { return *reinterpret_cast<const float4*>(a.W + (size_t)k * H + ns0 + 4 * n4); });
@@ -381,7 +401,16 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     }
     if (t < 2 * GC_N) att_s[t] = attv;
     if (t < 2 * T) { dad_s[t >> 6][t & 63] = 0.f; das_s[t >> 6][t & 63] = 0.f; }
-    ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
+    if (UP && t >= 256 && t < 256 + GC_N) {              // upper BatchNorm constants of this slice's 64 columns
+        const int c = ns0 + t - 256;
+        float m1[1], r1[1];
+        bn_mean_rstd_v<1>(a.ubn, c, m1, r1);
+        um_s[t - 256] = m1[0]; ur_s[t - 256] = r1[0];
+        ug_s[t - 256] = (a.ubn.gamma ? a.ubn.gamma[c] : 1.f) * r1[0];
+        u1_s[t - 256] = (float)(a.udot_sum[c] * (double)a.ubn.inv_n);
+        u2_s[t - 256] = (float)(a.udot_prod[c] * (double)a.ubn.inv_n);
+    }
+    if (!UP) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
     ro_commit<GB_NT>(bz, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Zr + j * GB_LDD + 4 * n4) = v; });
     ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) {
         float* d = Wt + (4 * n4) * GB_LDW + k;
@@ -394,9 +423,51 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
         v.z = (v.z - mean_s[k + 2]) * rstd_s[k + 2]; v.w = (v.w - mean_s[k + 3]) * rstd_s[k + 3];
         *reinterpret_cast<float4*>(Xs + i * GB_LDX + k) = v;
     });
+    if (UP) {
+        // dOut slice from the upper layer's partials: lane t always holds column group t % 16, so its column sums stay
+        // in registers until the cross-lane reduction below
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool two = a.dy1 != nullptr;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { ro_pin(bd.v[u]); ro_pin(bd1.v[u]); ro_pin(by.v[u]); }
+        const int c = 4 * (t & 15);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                   // item (u, t) = row t / 16 + 32 u, column group t % 16
+            const int j = (t >> 4) + u * (GB_NT / 16);
+            if (j < rows) {
+                const float4 v0 = bd.v[u], v1 = bd1.v[u], yv = by.v[u];
+                const float d[4] = {v0.x + (two ? v1.x : 0.f), v0.y + (two ? v1.y : 0.f), v0.z + (two ? v1.z : 0.f), v0.w + (two ? v1.w : 0.f)};
+                const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+                float o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float yn = (yy[q] - um_s[c + q]) * ur_s[c + q];
+                    const float g1 = ug_s[c + q] * (d[q] - u1_s[c + q] - yn * u2_s[c + q]);
+                    o[q] = yy[q] > 0.f ? g1 : 0.f;
+                    cs[q] += o[q];
+                }
+                *reinterpret_cast<float4*>(Ds + j * GB_LDD + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cs[q] += __shfl_xor(cs[q], 16, 64);
+            cs[q] += __shfl_xor(cs[q], 32, 64);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bs_s[t >> 6][lane][q] = cs[q];
+        }
+    }
     for (int i = t; i < (rowsP - rows) * GB_LDD; i += GB_NT) { Ds[rows * GB_LDD + i] = 0.f; Zr[rows * GB_LDD + i] = 0.f; }
     for (int i = t; i < (rowsP - rows) * GB_LDX; i += GB_NT) Xs[rows * GB_LDX + i] = 0.f;
     __syncthreads();
+    if (UP && t < GC_N) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < GB_NT / 64; ++k) tot += (double)bs_s[k][t >> 2][t & 3];
+        a.bias_parts[(size_t)b * H + ns0 + t] = tot;
+    }
     auto ident = [](float v) { return v; };
     gc_f32x16 acc[2], dzacc[2];
 #pragma unroll
