@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     __shared__ float dis_s[T];
     __shared__ int en[ECAP];
     __shared__ float ec[ECAP];
+    __shared__ signed char er[ECAP];
     __shared__ double red[4][2][32];
     __shared__ float pool_s[4][32];
     BLK_CLK(0);
@@ -224,6 +225,10 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     }
     RO_CLK(34);
     __syncthreads();                                     // BN tables
+    if (t < rows) {                                      // destination row of every CSR slot (stores only: no LDS latency chain)
+        const int s1 = ptr_s[t + 1];
+        for (int s = ptr_s[t]; s < s1; ++s) er[s] = (signed char)t;
+    }
     {
         int kc = 0, rr = 0;
 #pragma unroll
@@ -282,12 +287,14 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
         for (int idx = t; idx < nz4; idx += 256) z4[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    // one lane per destination row i: its incoming edges and its self loop (duplicate edges accumulate)
-    if (t < rows) {
-        const float di = dis_s[t];
-        for (int s = ptr_s[t]; s < ptr_s[t + 1]; ++s) At[en[s] * LDA + t] += di * ec[s];
-        At[t * LDA + t] += di * di * loop_w;
+    // one lane per CSR slot (then one per self loop): duplicate edges accumulate through the LDS atomic.  One lane per
+    // destination ROW walked a hub's 30 slots as 30 dependent LDS round trips (read source, read coefficient,
+    // read-modify-write the block) while the other lanes idled -- the slowest row was the phase.
+    for (int s = t; s < ne; s += 256) {
+        const int i = er[s];
+        atomicAdd(&At[en[s] * LDA + i], dis_s[i] * ec[s]);
     }
+    if (t < rows) atomicAdd(&At[t * LDA + t], dis_s[t] * dis_s[t] * loop_w);
     __syncthreads();
     RO_CLK(37);
     // ---- out tile = A z on the matrix cores (reduction over the graph's rowsP nodes) ---------------------------

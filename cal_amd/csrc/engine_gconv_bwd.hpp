@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     __shared__ __attribute__((aligned(16))) float Zr[MODE == 2 ? GB_T * GB_LDD : 4];       // POOL: z slice rows [j][n]
     __shared__ float gv_s[GC_N];                         // POOL: gradient of this graph's pooled row, slice columns
     __shared__ int ee[MODE == 2 ? GB_E : 1];             // POOL: edge id of CSR slot s
-    __shared__ short er[MODE == 2 ? GB_E : 1];           // POOL: destination row of CSR slot s
+    __shared__ short er[GB_E];                           // destination row of CSR slot s
     constexpr bool UP = MODE == 1, POOL = MODE == 2;
     BLK_CLK(0);
     const GconvBwdBranch& br = blockIdx.z ? b1 : b0;
@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     ro_issue<GB_NT>(bx, rows, K4, [&](int i, int k4) { return *reinterpret_cast<const float4*>(br.x + (size_t)(g0 + i) * K + 4 * k4); });
     ro_issue<GB_NT>(bw, K, 16, [&](int k, int n4) { return *reinterpret_cast<const float4*>(br.W + (size_t)k * H + ns0 + 4 * n4); });
     const int pv = g.ptr[g0 + min(t, rows)];
+    const int pn = g.ptr[g0 + min(t + 1, rows)];
     const float dv = br.dis[g0 + min(t, rows - 1)];
     const float rv = RS ? br.rs[(size_t)(g0 + min(t, rows - 1)) * br.rs_stride] : 1.f;
     int nv[2], ev[2];
@@ -209,7 +210,10 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     }
     // ---- stage everything in LDS -----------------------------------------------------------------------------------
     if (t <= rows) ptr_s[t] = pv - e0;
-    if (t < rows) { dis_s[t] = dv; rs_s[t] = rv; }
+    if (t < rows) {
+        dis_s[t] = dv; rs_s[t] = rv;
+        for (int s = pv - e0; s < pn - e0; ++s) er[s] = (short)t;      // destination row of every slot (stores only)
+    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int s = t + u * GB_NT;
@@ -301,11 +305,13 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     // rows rows .. rowsP of dOut / x_hat: zero (they are reduced over in the products below)
     for (int i = t; i < (rowsP - rows) * GB_LDD; i += GB_NT) Ds[rows * GB_LDD + i] = 0.f;
     for (int i = t; i < (rowsP - rows) * GB_LDX; i += GB_NT) Xs[rows * GB_LDX + i] = 0.f;
-    if (t < rows) {                                      // one lane per destination row j: its own row of the block
-        const float dj = dis_s[t];
-        for (int s = ptr_s[t]; s < ptr_s[t + 1]; ++s) { Ab[t * GB_LDJ + en[s]] += dj * ec[s]; if (POOL) er[s] = (short)t; }
-        Ab[t * GB_LDJ + t] += dj * dj * loop_w;
+    // one lane per CSR slot, then one per self loop (LDS atomics: duplicate edges share an entry) -- a lane per ROW walked
+    // a hub's slots as a chain of dependent LDS round trips while the rest of the workgroup waited
+    for (int s = t; s < ne; s += GB_NT) {
+        const int j = er[s];
+        atomicAdd(&Ab[j * GB_LDJ + en[s]], dis_s[j] * ec[s]);
     }
+    if (t < rows) atomicAdd(&Ab[t * GB_LDJ + t], dis_s[t] * dis_s[t] * loop_w);
     __syncthreads();
     if ((UP || POOL) && t < GC_N) {
         double tot = 0.0;
