@@ -777,7 +777,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     }
     const float* x = e->h + (size_t)L * NH;
     // 5+6 per graph: node attention, edge softmax and weighted degrees in one kernel (4 rows per lane group)
-    const bool att_graph = gc && e->max_nodes <= 4 * (512 / group_for(H, 4));
+    const bool att_graph = gc && e->max_nodes <= 4 * (512 / group_for(H, 4)) && e->max_edges <= GP_E;
     if (att_graph) {
         const Acc a0 = graph_acc(c, bn_stsum(c, L + 1), H), a1 = graph_acc(c, bn_stsq(c, L + 1), H);
         const Acc a2 = graph_acc(c, bn_stsum(c, L + 2), H), a3 = graph_acc(c, bn_stsq(c, L + 2), H);

@@ -215,30 +215,59 @@ __global__ void __launch_bounds__(512) k_att_fwd_graph(const int* __restrict__ g
         if (grp == 0 && cok) { stc_sum.add(c + j, o4[0]); stc_sq.add(c + j, o4[1]); sto_sum.add(c + j, o4[2]); sto_sq.add(c + j, o4[3]); }
     }
     if (rows <= 0 || rows > MAXR) return;
-    // edge softmax (model.py:102-104) + weighted degrees, 8 lanes per source node over its out-edges
+    // edge softmax (model.py:102-104) + weighted degrees.  The graph's by-source CSR rows (pointers, targets, edge ids) are
+    // fetched in ONE round of loads and staged in LDS; then one lane per slot computes the two attention weights (no
+    // dependent global round trips per out-edge, hubs do not serialise), and one lane per node adds its slots in order.
     const float e_b0 = be[0], e_b1 = be[1];
-    for (int i = t >> 3; i < rows; i += 64) {
-        const int l8 = t & 7, v = g0 + i;
-        const float4 pv = pq_s[i];
-        float dc = 0.f, dq = 0.f;
-        for (int s = gs.ptr[v] + l8; s < gs.ptr[v + 1]; s += 8) {
-            const int d = gs.nbr[s] - g0, e = gs.eid[s];
-            const float4 qd = pq_s[min(max(d, 0), rows - 1)];
-            const float l0 = pv.x + qd.z + e_b0, l1 = pv.y + qd.w + e_b1;
+    __shared__ int sp_s[MAXR + 1];
+    __shared__ short sd_s[GP_E], sr_s[GP_E];
+    __shared__ float a0_s[GP_E], a1_s[GP_E];
+    const int pv = gs.ptr[g0 + min(t, rows)], pn = gs.ptr[g0 + min(t + 1, rows)];
+    const int e0 = gs.ptr[g0], ne = gs.ptr[g0 + rows] - e0;
+    if (ne > GP_E || ne < 0) { if (t == 0) atomicOr(status, 8); return; }
+    int nd[2], ed[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int s = e0 + max(min(t + u * 512, ne - 1), 0);
+        nd[u] = ne > 0 ? gs.nbr[s] : g0;
+        ed[u] = ne > 0 ? gs.eid[s] : 0;
+    }
+    if (t <= rows) sp_s[t] = pv - e0;
+    if (t < rows) for (int s = pv - e0; s < pn - e0; ++s) sr_s[s] = (short)t;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int s = t + u * 512;
+        if (s < ne) sd_s[s] = (short)min(max(nd[u] - g0, 0), rows - 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int s = t + u * 512;
+        if (s < ne) {
+            const float4 pvv = pq_s[sr_s[s]], qd = pq_s[sd_s[s]];
+            const float l0 = pvv.x + qd.z + e_b0, l1 = pvv.y + qd.w + e_b1;
             const float m = fmaxf(l0, l1);
-            const float e0 = expf(l0 - m), e1 = expf(l1 - m);
-            const float inv = 1.f / (e0 + e1);
-            const float a0 = e0 * inv, a1 = e1 * inv;
-            att[e] = a0;
-            att[E + e] = a1;
-            dc += a0; dq += a1;
+            const float x0 = expf(l0 - m), x1 = expf(l1 - m);
+            const float inv = 1.f / (x0 + x1);
+            const float a0 = x0 * inv, a1 = x1 * inv;
+            att[ed[u]] = a0;
+            att[E + ed[u]] = a1;
+            a0_s[s] = a0; a1_s[s] = a1;
         }
-        dc = group_sum<8>(dc); dq = group_sum<8>(dq);
-        if (l8 == 0) {
-            dc += loop_w; dq += loop_w;
-            dis_c[v] = dc == 0.f ? 0.f : 1.0f / sqrtf(dc);
-            dis_o[v] = dq == 0.f ? 0.f : 1.0f / sqrtf(dq);
+    }
+    __syncthreads();
+    if (t < rows) {
+        float dc = loop_w, dq = loop_w;
+        const int s1 = sp_s[t + 1];
+        for (int s = sp_s[t]; s < s1; s += 8) {
+            float x[8], y[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int sq = min(s + q, s1 - 1); x[q] = a0_s[sq]; y[q] = a1_s[sq]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { dc += s + q < s1 ? x[q] : 0.f; dq += s + q < s1 ? y[q] : 0.f; }
         }
+        dis_c[g0 + t] = dc == 0.f ? 0.f : 1.0f / sqrtf(dc);
+        dis_o[g0 + t] = dq == 0.f ? 0.f : 1.0f / sqrtf(dq);
     }
 }
 
