@@ -257,7 +257,7 @@ def engine_roofline(trainer, batches, workload, iters=20):
     # GATConv layers (CausalGAT): scores + edge softmax + aggregation (forward), the five backward kernels
     # algorithmic bytes: z and the output once each, CSR slot + 3 logits-sized [E',K] passes (+3*E'*K*4)
     for key, label in (("gat_fwd", "GATConv forward: k_gat_scores + k_gat_fwd (edge softmax, dropout, aggregation, bias, ReLU)"),
-                       ("gat_bwd", "GATConv backward: k_gat_bwd_dst / _dasrc / _src / datt (alpha recomputed)")):
+                       ("gat_bwd", "GATConv backward: k_gat_bwd_dst / _src / datt_part (alpha recomputed)")):
         if key in out:
             dur, work, per_step = out[key]
             ach = work / dur / 1e9

@@ -1,8 +1,8 @@
-"""Compare every intermediate of the native engine with the CPU oracle (debug aid)."""
+"""Compare every intermediate of the native engine with the CPU oracle (debug aid; lives under tests/ because only tests may use oracle/)."""
 import argparse, os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cal_amd import model as M
 from cal_amd.engine import StepEngine
 from oracle import cal_oracle as O
