@@ -156,6 +156,32 @@ def test_gat_step_counter_keys_the_masks_and_replays_draw_fresh_ones():
     assert l0[0] == l0[1] == l0[2]
 
 
+def test_dense_small_graphs_mix_fused_forward_with_unfused_backward():
+    """Graphs of <= 64 nodes with 512 < edges <= 1024: k_ggat_fwd runs (GG_E = 1024) but k_ggat_bwd does not (GGB_E = 512),
+    so the fused forward's saved z / scores feed the unfused GAT backward kernels.  One train step vs the oracle."""
+    from tests.helpers import random_graph_batch
+    b = random_graph_batch(num_graphs=6, n_lo=36, n_hi=44, p=0.25, feat=10, seed=3)
+    bd = random_graph_batch(num_graphs=6, n_lo=36, n_hi=44, p=0.25, feat=10, seed=3).to(DEV)
+    assert bd.max_nodes <= 64 and 512 < bd.max_edges <= 1024, (bd.max_nodes, bd.max_edges)
+    torch.manual_seed(12)
+    sd = O.init_state("CausalGAT", 10, 4, hidden=128, layers=2, heads=4)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(layers=2), dropout=0.0)
+    perm = torch.randperm(6)
+    tr = O.CpuTrainer("CausalGAT", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=2, heads=4, gat_dropout=0.0)
+    loss, lc, lo, lco, logits = tr.step(b.x, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
+    lp = eng.buffer("logp", 3 * 6 * 4).view(3, 6, 4).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    assert int(eng.buffer("status", 1, torch.int32)[0].item()) == 0
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is not None:
+            scale = max(1.0, gref.abs().max().item())
+            assert (p.grad.cpu() - gref).abs().max().item() <= 5e-4 * scale, k
+
+
 @pytest.mark.parametrize("name,kind,nfeat,batch", [("CausalGAT", "mutag", 109, 64), ("CausalGCN", "nci1", 139, 512)])
 def test_config3_config4_standin_shapes_match_oracle(name, kind, nfeat, batch):
     """SURVEY.md 8d configs 3 (CausalGAT, MUTAG-like, F = 109, B = 64) and 4 (CausalGCN, NCI1-like, F = 139,
