@@ -156,6 +156,38 @@ def test_gat_step_counter_keys_the_masks_and_replays_draw_fresh_ones():
     assert l0[0] == l0[1] == l0[2]
 
 
+def test_fused_gat_layers_with_one_head_per_column_slice():
+    """hidden 128 / 2 heads: head dim 64 = one head per 64-column slice of k_ggat_fwd / k_ggat_bwd (the other tests run
+    two heads of 32 per slice).  One train step with dropout vs the oracle."""
+    from cal_amd import model as M
+    from cal_amd.engine import StepEngine
+    ids = list(range(20))
+    b, bd = ref_batch(ids), ref_batch(ids).to(DEV)
+    torch.manual_seed(13)
+    sd = O.init_state("CausalGAT", 10, 4, hidden=128, layers=2, heads=2)
+    m = M.CausalGAT(10, 4, _args(layers=2), head=2)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m = m.to(DEV).train()
+    for i, c in enumerate(m.convs):
+        c.dropout, c.seed = 0.2, 900 + i
+    eng = StepEngine(m)
+    assert eng.heads == 2
+    tr = O.CpuTrainer("CausalGAT", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=2, heads=2, gat_dropout=0.2,
+                      gat_masks=_masks([c.seed for c in m.convs], bd, b, 2, 0.2))
+    perm = torch.randperm(len(ids))
+    loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
+    lp = eng.buffer("logp", 3 * len(ids) * 4).view(3, len(ids), 4).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    assert int(eng.buffer("status", 1, torch.int32)[0].item()) == 0
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is not None:
+            assert torch.allclose(p.grad.cpu(), gref, atol=5e-5, rtol=2e-3), k
+
+
 def test_dense_small_graphs_mix_fused_forward_with_unfused_backward():
     """Graphs of <= 64 nodes with 512 < edges <= 1024: k_ggat_fwd runs (GG_E = 1024) but k_ggat_bwd does not (GGB_E = 512),
     so the fused forward's saved z / scores feed the unfused GAT backward kernels.  One train step vs the oracle."""
