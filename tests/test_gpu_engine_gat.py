@@ -188,6 +188,37 @@ def test_fused_gat_layers_with_one_head_per_column_slice():
             assert torch.allclose(p.grad.cpu(), gref, atol=5e-5, rtol=2e-3), k
 
 
+@pytest.mark.parametrize("self_loops,directed,seed", [(False, False, 1), (True, True, 2), (False, True, 3)])
+def test_fused_gat_layers_on_ragged_graphs(self_loops, directed, seed):
+    """Edge cases of the per-graph GAT kernels: one-node graphs, isolated nodes, asymmetric edge lists, explicit self
+    loops in the input (dropped by GATConv, and they switch the engine to its generic CSR build).  One train step with
+    dropout (fixed seeds, masks fed to the oracle) vs the oracle."""
+    from tests.helpers import random_graph_batch
+    kw = dict(num_graphs=9, n_lo=1, n_hi=24, p=0.15, feat=10, seed=seed, self_loops=self_loops, directed=directed)
+    b, bd = random_graph_batch(**kw), random_graph_batch(**kw).to(DEV)
+    assert bd.max_nodes <= 64
+    torch.manual_seed(20 + seed)
+    sd = O.init_state("CausalGAT", 10, 4, hidden=128, layers=2, heads=4)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(layers=2))
+    for i, c in enumerate(m.convs):
+        c.seed = 700 + i
+    tr = O.CpuTrainer("CausalGAT", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=2, heads=4, gat_dropout=0.2,
+                      gat_masks=_masks([c.seed for c in m.convs], bd, b, 4, 0.2))
+    perm = torch.randperm(9)
+    loss, lc, lo, lco, logits = tr.step(b.x, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
+    lp = eng.buffer("logp", 3 * 9 * 4).view(3, 9, 4).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    assert int(eng.buffer("status", 1, torch.int32)[0].item()) == 0
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is not None:
+            scale = max(1.0, gref.abs().max().item())
+            assert (p.grad.cpu() - gref).abs().max().item() <= 2e-4 * scale, k
+
+
 def test_dense_small_graphs_mix_fused_forward_with_unfused_backward():
     """Graphs of <= 64 nodes with 512 < edges <= 1024: k_ggat_fwd runs (GG_E = 1024) but k_ggat_bwd does not (GGB_E = 512),
     so the fused forward's saved z / scores feed the unfused GAT backward kernels.  One train step vs the oracle."""
