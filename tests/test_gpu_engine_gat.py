@@ -188,15 +188,16 @@ def test_fused_gat_layers_with_one_head_per_column_slice():
             assert torch.allclose(p.grad.cpu(), gref, atol=5e-5, rtol=2e-3), k
 
 
-@pytest.mark.parametrize("self_loops,directed,seed", [(False, False, 1), (True, True, 2), (False, True, 3)])
-def test_fused_gat_layers_on_ragged_graphs(self_loops, directed, seed):
+@pytest.mark.parametrize("self_loops,directed,seed,n_lo,n_hi,p", [(False, False, 1, 1, 24, 0.15), (True, True, 2, 1, 24, 0.15),
+                                                                  (False, True, 3, 1, 24, 0.15), (False, False, 4, 64, 64, 0.055)])
+def test_fused_gat_layers_on_ragged_graphs(self_loops, directed, seed, n_lo, n_hi, p):
     """Edge cases of the per-graph GAT kernels: one-node graphs, isolated nodes, asymmetric edge lists, explicit self
     loops in the input (dropped by GATConv, and they switch the engine to its generic CSR build).  One train step with
     dropout (fixed seeds, masks fed to the oracle) vs the oracle."""
     from tests.helpers import random_graph_batch
-    kw = dict(num_graphs=9, n_lo=1, n_hi=24, p=0.15, feat=10, seed=seed, self_loops=self_loops, directed=directed)
+    kw = dict(num_graphs=9, n_lo=n_lo, n_hi=n_hi, p=p, feat=10, seed=seed, self_loops=self_loops, directed=directed)
     b, bd = random_graph_batch(**kw), random_graph_batch(**kw).to(DEV)
-    assert bd.max_nodes <= 64
+    assert bd.max_nodes <= 64 and bd.max_edges <= 512, (bd.max_nodes, bd.max_edges)     # the last case sits at the 64-node bound
     torch.manual_seed(20 + seed)
     sd = O.init_state("CausalGAT", 10, 4, hidden=128, layers=2, heads=4)
     m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(layers=2))
