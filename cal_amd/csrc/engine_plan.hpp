@@ -136,7 +136,13 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
         const int* off = d ? off_in : off_out;
         const int s0 = off[v], s1 = off[v + 1];
         int rank = 0;
-        for (int k = s0; k < s1; ++k) rank += te[k] < s;
+        for (int k = s0; k < s1; k += 8) {               // eight independent LDS reads per round (hub rows: 30+ slots)
+            int x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = te[min(k + u, s1 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += (k + u < s1 && x[u] < s) ? 1 : 0;
+        }
         const int64_t slot = e0 + s0 + rank;
         if (d) { nbr_dst[slot] = g0 + tn[q]; eid_dst[slot] = (int)(e0 + s); }
         else { nbr_src[slot] = g0 + tn[q]; eid_src[slot] = (int)(e0 + s); }
