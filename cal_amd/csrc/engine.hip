@@ -1,6 +1,6 @@
 // Native CausalGCN step engine: the whole training step of train_causal.py:173-192 on
 // model.py:85-164 -- forward (3 heads), 3-term loss, backward, Adam -- as ONE C call that enqueues
-// ~55 hand-written kernels on a stream (hipGraph-capturable: no allocation, no sync, no memset
+// a few dozen hand-written kernels on a stream (hipGraph-capturable: no allocation, no sync, no memset
 // nodes).  What is fused, relative to the op sequence of the reference:
 //   * every BatchNorm is folded into its consumer: batch statistics are accumulated (fp64) by the
 //     producer's epilogue, the normalised tensor is never written -- the consumer GEMM applies
@@ -120,6 +120,7 @@ struct Engine {
     float *P, *G, *M1, *M2, *step, *lr;
     int64_t nparam;
     float beta1, beta2, eps, wd;
+    float grad_scale;           // gradient factor inside Adam (1 / world_size after a sum all-reduce)
     // parameter offsets (floats into P / G)
     int o_feat_w;
     int o_conv_w[MAX_LAYERS], o_conv_b[MAX_LAYERS];
@@ -189,6 +190,7 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     memset(e, 0, sizeof(Engine));
     e->F = (int)F; e->H = (int)H; e->C = (int)C; e->L = (int)L;
     e->loop_w = 1.f;
+    e->grad_scale = 1.f;
     e->nbn = (int)L + 9;
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { set_error("cal_engine_create: side stream"); delete e; return nullptr; }
     for (int i = 0; i < 24; ++i) {
@@ -658,7 +660,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         const int64_t ni = fast_plan ? 0 : 4 * ((int64_t)N + 1);
         hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256)), dim3(256), 0, st, e->arena,
                            (int64_t)e->arena_n, e->work, ni, e->status,
-                           (e->K > 0 && c.training && want_grad) ? e->gat_ctr : nullptr);
+                           (e->K > 0 && c.training) ? e->gat_ctr : nullptr);
         CAL_CHECK_LAUNCH("k_zero_f64"); STAGE();
     }
     // 1. GraphPlan
@@ -1409,7 +1411,8 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     c.nfork = 0;
     const int want_grad = (mode & 2) ? 1 : 0;
     c.y = y; c.perm = perm; c.wc = wc; c.wo = wo; c.wco = wco; c.want_grad = want_grad;
-    c.tick_in_finish = (mode & 4) ? 1 : 0;
+    c.tick_in_finish = (mode & (4 | 8)) ? 1 : 0;
+    CAL_REQUIRE(!(mode & 8) || want_grad, "mode bit 8 (Adam follows a gradient exchange) needs the backward pass");
     CAL_REQUIRE(!want_grad || c.training, "backward needs a training-mode forward");
     CAL_REQUIRE(!(mode & 4) || want_grad, "the Adam update needs the backward pass in the same step");
     g_stage = 0;
@@ -1427,7 +1430,7 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     }
     if (mode & 4) {          // k_finish has already advanced the step counter (c.tick_in_finish)
         hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, c.st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
-                           e->beta2, e->eps, e->wd, e->nparam, 1);
+                           e->beta2, e->eps, e->wd, e->nparam, 1, e->grad_scale);
         CAL_CHECK_LAUNCH("k_adam");
     }
     return 0;
@@ -1522,9 +1525,27 @@ CAL_EXPORT int cal_engine_adam(void* h, void* stream_) {
     Engine* e = (Engine*)h;
     hipStream_t st = (hipStream_t)stream_;
     hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
-                       e->beta2, e->eps, e->wd, e->nparam, 0);
+                       e->beta2, e->eps, e->wd, e->nparam, 0, e->grad_scale);
     CAL_CHECK_LAUNCH("k_adam");
     hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, e->step);
     CAL_CHECK_LAUNCH("k_adam_tick");
+    return 0;
+}
+// Adam after a gradient exchange when the step ran with mode bit 8 (its k_finish already advanced the step counter):
+// ONE launch -- [graph: forward + backward] -> all-reduce(sum) -> this, with the 1/world mean folded into grad_scale
+CAL_EXPORT int cal_engine_adam_ticked(void* h, void* stream_) {
+    Engine* e = (Engine*)h;
+    hipStream_t st = (hipStream_t)stream_;
+    hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
+                       e->beta2, e->eps, e->wd, e->nparam, 1, e->grad_scale);
+    CAL_CHECK_LAUNCH("k_adam");
+    return 0;
+}
+// Factor applied to the bound gradient buffer inside the Adam update (1/world_size turns the all-reduced SUM of the
+// replicas' gradients into the mean, train_causal.py:187-192 semantics per replica); default 1
+CAL_EXPORT int cal_engine_set_grad_scale(void* h, float scale) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e != nullptr && scale > 0.f, "bad arguments");
+    e->grad_scale = scale;
     return 0;
 }

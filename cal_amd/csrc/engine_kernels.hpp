@@ -114,14 +114,15 @@ __global__ void __launch_bounds__(256) k_stats_final(const FinalArgs fa) {
     }
 }
 
-// zero the fp64 arena, the GraphPlan degree counters / cursors and the status word in one launch
+// zero the fp64 arena, the GraphPlan degree counters / cursors and the status word in one launch; the previous
+// step's status bits are folded into the sticky word status[1] first (read by StepEngine.check_status once per epoch)
 // (and, for a GAT backbone in training, advance the attention-dropout step counter: one fresh mask per step)
 __global__ void k_zero_f64(double* __restrict__ a, int64_t n, int* __restrict__ ints, int64_t ni, int* __restrict__ status,
                            unsigned long long* __restrict__ tick) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = 0.0;
     if (i < ni) ints[i] = 0;
-    if (i == 0 && status) *status = 0;
+    if (i == 0 && status) { status[1] |= status[0]; status[0] = 0; }
     if (i == 0 && tick) *tick += 1;
 }
 
@@ -991,14 +992,14 @@ struct CommitTask { const double* src; int P; int stride; int dst; int n; float 
 
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        float* __restrict__ step, const float* __restrict__ lr_ptr, float beta1, float beta2, float eps,
-                       float wd, int64_t n, int ticked) {
+                       float wd, int64_t n, int ticked, float gscale) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // every thread reads the step counter, so it cannot be advanced in this launch: either the step's
     // k_finish has already done it (ticked = 1) or a separate tiny launch follows (k_adam_tick)
     if (i >= n) return;
     const float t = step[0] + (ticked ? 0.f : 1.f);
     const float lr = lr_ptr[0];
-    float gi = g[i];
+    float gi = g[i] * gscale;
     if (wd != 0.f) gi = fmaf(wd, p[i], gi);
     const float mi = beta1 * m[i] + (1.f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;

@@ -129,39 +129,71 @@ class Batch(Data):
         return int(self.batch.size(0))
 
 
+def shard_indices(n: int, shuffle: bool, rank: int, world_size: int, drop_last: bool,
+                  generator: Optional[torch.Generator], seed: int, epoch: int) -> List[int]:
+    """Indices of one epoch for replica ``rank`` of ``world_size``.
+
+    Single replica: ``torch.randperm(n, generator)`` (``torch.utils.data.RandomSampler``) or ``range(n)``.
+    Several replicas: every rank must see the SAME permutation and the SAME number of
+    samples -- unequal shard lengths give ranks different step counts and the per-step gradient all-reduce
+    hangs.  The permutation therefore comes from a generator seeded with ``seed + epoch`` on every rank (an
+    explicit ``generator`` must then be seeded identically on all ranks), is padded by wrapping around to
+    ``world_size * ceil(n / world_size)`` entries (``drop_last``: truncated to ``world_size * (n // world_size)``)
+    as ``torch.utils.data.DistributedSampler`` does, and rank r takes entries r, r + world, ...
+    """
+    if world_size > 1 and shuffle and generator is None:
+        generator = torch.Generator().manual_seed(int(seed) + int(epoch))
+    idx = torch.randperm(n, generator=generator).tolist() if shuffle else list(range(n))
+    if world_size > 1:
+        if drop_last:
+            idx = idx[:(n // world_size) * world_size]
+        else:
+            total = -(-n // world_size) * world_size
+            while n and len(idx) < total:
+                idx += idx[:total - len(idx)]
+        idx = idx[rank::world_size]
+    return idx
+
+
 class DataLoader:
     """``DataLoader(dataset, batch_size, shuffle)`` (train_causal.py:13-15).
 
     Shuffling uses ``torch.randperm`` (as ``torch.utils.data.RandomSampler``
-    does); ``rank``/``world_size`` give each data-parallel replica a disjoint
-    strided shard of every epoch's permutation.
+    does); ``rank``/``world_size`` give each data-parallel replica an equally
+    long strided shard of every epoch's (shared) permutation (``shard_indices``).
     """
 
     def __init__(self, dataset, batch_size: int = 1, shuffle: bool = False,
                  rank: int = 0, world_size: int = 1, drop_last: bool = False,
-                 generator: Optional[torch.Generator] = None):
+                 generator: Optional[torch.Generator] = None, seed: int = 0):
         self.dataset = dataset
         self.batch_size = int(batch_size)
         self.shuffle = shuffle
         self.rank, self.world_size = rank, world_size
         self.drop_last = drop_last
         self.generator = generator
+        self.seed, self.epoch = int(seed), 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
 
     def _indices(self) -> List[int]:
-        n = len(self.dataset)
-        idx = (torch.randperm(n, generator=self.generator).tolist()
-               if self.shuffle else list(range(n)))
-        if self.world_size > 1:
-            per = n // self.world_size if self.drop_last else -(-n // self.world_size)
-            idx = idx[self.rank::self.world_size][:per]
-        return idx
+        return shard_indices(len(self.dataset), self.shuffle, self.rank, self.world_size, self.drop_last,
+                             self.generator, self.seed, self.epoch)
+
+    def _shard_len(self) -> int:
+        n, w = len(self.dataset), self.world_size
+        if w <= 1:
+            return n
+        return n // w if self.drop_last else -(-n // w)
 
     def __len__(self) -> int:
-        n = len(self._indices()) if self.world_size > 1 else len(self.dataset)
+        n = self._shard_len()
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
     def __iter__(self) -> Iterable[Batch]:
         idx = self._indices()
+        self.epoch += 1
         for s in range(0, len(idx), self.batch_size):
             chunk = idx[s:s + self.batch_size]
             if self.drop_last and len(chunk) < self.batch_size:

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .data import Batch
+from .data import Batch, shard_indices
 from .plan import _p, _stream
 
 
@@ -94,24 +94,28 @@ class DeviceLoader:
     DeviceDataset; ``rank``/``world_size`` shard every epoch's permutation for data parallelism."""
 
     def __init__(self, dataset: DeviceDataset, batch_size: int, shuffle: bool = False, rank: int = 0,
-                 world_size: int = 1, drop_last: bool = False, generator: Optional[torch.Generator] = None):
+                 world_size: int = 1, drop_last: bool = False, generator: Optional[torch.Generator] = None,
+                 seed: int = 0):
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
         self.rank, self.world_size, self.drop_last, self.generator = rank, world_size, drop_last, generator
+        self.seed, self.epoch = int(seed), 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
 
     def _indices(self):
-        n = len(self.dataset)
-        idx = torch.randperm(n, generator=self.generator).numpy() if self.shuffle else np.arange(n)
-        if self.world_size > 1:
-            per = n // self.world_size if self.drop_last else -(-n // self.world_size)
-            idx = idx[self.rank::self.world_size][:per]
-        return idx
+        return np.asarray(shard_indices(len(self.dataset), self.shuffle, self.rank, self.world_size, self.drop_last,
+                                        self.generator, self.seed, self.epoch), dtype=np.int64)
 
     def __len__(self):
-        n = len(self._indices()) if self.world_size > 1 else len(self.dataset)
+        n, w = len(self.dataset), self.world_size
+        if w > 1:
+            n = n // w if self.drop_last else -(-n // w)
         return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
 
     def __iter__(self) -> Iterable[Batch]:
         idx = self._indices()
+        self.epoch += 1
         for s in range(0, len(idx), self.batch_size):
             chunk = idx[s:s + self.batch_size]
             if self.drop_last and len(chunk) < self.batch_size:

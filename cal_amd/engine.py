@@ -1,4 +1,4 @@
-"""Python handle of the native CausalGCN step engine (cal_amd/csrc/engine.hip).
+"""Python handle of the native CausalGCN / CausalGAT step engine (cal_amd/csrc/engine.hip).
 
 ``StepEngine(model)`` re-homes the module's parameters into one flat buffer
 (so the module, its state_dict and any torch optimizer keep working on the same
@@ -8,9 +8,9 @@ memory), binds gradients / Adam state, owns the device workspace and exposes
 * ``train_step(batch, perm)``       -> forward + 3-term loss + backward (+ Adam),
 
 each as ONE C call that enqueues the fused kernels on torch's current stream
-(hipGraph-capturable).  Only ``CausalGCN`` with ``cat_or_add == "add"`` and both
-attentions enabled is covered; everything else stays on the operator-level
-path (``cal_amd.model``).
+(hipGraph-capturable).  ``supported(model)`` says what is covered (CausalGCN and
+CausalGAT with ``cat_or_add == "add"`` and both attentions enabled); everything
+else stays on the operator-level path (``cal_amd.model``).
 """
 from __future__ import annotations
 
@@ -34,18 +34,26 @@ def _gat_heads(model) -> int:
 
 def supported(model) -> bool:
     from .model import CausalGCN, CausalGAT
+    from .gcn_conv import GCNConv
     a = model.args
     h = a.hidden
     if not (isinstance(model, (CausalGCN, CausalGAT)) and a.cat_or_add == "add"
             and not getattr(model, "without_node_attention", False) and not getattr(model, "without_edge_attention", False)
             and h % 4 == 0 and h <= 256 and a.layers <= 6 and model.num_classes <= 64):
         return False
+    # the engine hard-wires the normalised, non-improved GCNConv with a bias (gcn_conv.py:72-92 defaults): a model
+    # built with gfn=True / edge_norm=False / improved=True keeps the operator-level path
+    gcn_like = [model.context_convs, model.objects_convs] + [c for c in model.convs if isinstance(c, GCNConv)]
+    if any(c.gfn or not c.edge_norm or c.improved or c.bias is None for c in gcn_like):
+        return False
+    if not (model.conv_feat.gfn and model.conv_feat.bias is not None):
+        return False
     if isinstance(model, CausalGAT):
         k = _gat_heads(model)
         d = h // k if k else 0
         return (k > 0 and h % k == 0 and d % 4 == 0 and (d // 4) & (d // 4 - 1) == 0
                 and all(c.heads == k and c.bias is not None for c in model.convs))
-    return not any(c.improved for c in model.convs)
+    return True
 
 
 def _slot_names(layers: int):
@@ -59,6 +67,43 @@ def _slot_names(layers: int):
         names += [f"fc1_bn_{h}.weight", f"fc1_bn_{h}.bias", f"fc1_{h}.weight", f"fc1_{h}.bias",
                   f"fc2_bn_{h}.weight", f"fc2_bn_{h}.bias", f"fc2_{h}.weight", f"fc2_{h}.bias"]
     return names
+
+
+def _layout_of(batch, B: int) -> dict:
+    """Layout facts the per-graph kernels need -- node / edge ranges per graph, the largest graph, no self loops.
+    ``cal_amd.data.Batch`` and ``DeviceDataset.collate`` record them while collating; a foreign batch exposing only
+    the reference's protocol (``x``/``feat``, ``edge_index``, sorted ``batch``, ``num_graphs`` -- SURVEY.md 8b; PyG >= 2
+    adds ``ptr``) gets them derived here once on the device (one host read-back for the two bounds) and cached on the
+    object, instead of silently falling to the unfused kernels."""
+    have = all(hasattr(batch, k) for k in ("max_nodes", "max_edges", "edge_ptr", "no_self_loops")) and hasattr(batch, "ptr")
+    if have and (int(batch.max_nodes or 0) > 0 or B == 0):
+        return dict(ptr=batch.ptr, edge_ptr=batch.edge_ptr, no_self_loops=bool(batch.no_self_loops),
+                    max_nodes=int(batch.max_nodes or 0), max_edges=int(batch.max_edges or 0))
+    ei, bvec = batch.edge_index, batch.batch
+    key = (ei.data_ptr(), bvec.data_ptr(), int(ei.size(1)), int(bvec.numel()), B)
+    lay = getattr(batch, "_cal_layout", None)
+    if lay is not None and lay["key"] == key:
+        return lay
+    dev = bvec.device
+    counts = torch.bincount(bvec, minlength=B)[:B] if bvec.numel() else torch.zeros(B, dtype=torch.long, device=dev)
+    ptr = torch.zeros(B + 1, dtype=torch.long, device=dev)
+    ptr[1:] = torch.cumsum(counts, 0)
+    lay = dict(key=key, ptr=ptr, edge_ptr=None, no_self_loops=False, max_nodes=0, max_edges=0)
+    if ei.size(1) > 0 and B > 0:
+        gid = bvec[ei[0]]
+        grouped = bool((gid[1:] >= gid[:-1]).all().item()) and bool((bvec[ei[1]] == gid).all().item())
+        if grouped:                                       # graph b owns a contiguous run of edge columns
+            eptr = torch.searchsorted(gid, torch.arange(B + 1, device=dev, dtype=torch.long)).contiguous()
+            sizes = torch.stack([counts.max(), (eptr[1:] - eptr[:-1]).max(), (ei[0] == ei[1]).any().long()]).tolist()
+            lay.update(edge_ptr=eptr, max_nodes=int(sizes[0]), max_edges=int(sizes[1]), no_self_loops=not sizes[2])
+    elif B > 0:
+        lay.update(edge_ptr=torch.zeros(B + 1, dtype=torch.long, device=dev), no_self_loops=True,
+                   max_nodes=int(counts.max().item()), max_edges=0)
+    try:
+        batch._cal_layout = lay
+    except Exception:
+        pass
+    return lay
 
 
 class StepEngine:
@@ -116,6 +161,9 @@ class StepEngine:
                 att.append(off)
             self._att_offs = (ctypes.c_int64 * len(att))(*att)
             self._sync_gat()
+        #: False withholds the batch layout from the engine: generic CSR build + unfused GEMM / aggregation kernels
+        #: (what a batch too large for the per-graph kernels runs anyway); tests compare the two paths with it
+        self.fused = True
         self._ws: Optional[torch.Tensor] = None
         self._cap = (0, 0, 0)
         self._bounds = (0, 0)
@@ -160,6 +208,28 @@ class StepEngine:
         assert self._ws.data_ptr() % 256 == 0
         _lib.call("cal_engine_set_workspace", self._h, _p(self._ws), nbytes, N, E, B)
         self._cap = (N, E, B)
+        self.buffer("status", 4, torch.int32).zero_()       # [0] = latest step, [1] = sticky OR of the earlier steps
+
+    _STATUS_BITS = ((1, "edge_index has entries outside [0, num_nodes)"),
+                    (2, "batch vector is not sorted / has ids outside [0, num_graphs), or ptr / edge_ptr do not match it"),
+                    (8, "a graph exceeds the per-graph bounds (max_nodes / max_edges) the batch declared"),
+                    (16, "an edge leaves its graph's node range (edge_ptr / ptr are stale)"),
+                    (32, "edge_index has self loops although the batch declared no_self_loops"))
+
+    def check_status(self, reset: bool = True):
+        """Synchronising check of the device status word over every step since the last check: the per-graph kernels
+        skip graphs that violate the layout facts the batch declared (``max_nodes``, ``max_edges``, ``ptr``,
+        ``edge_ptr``, ``no_self_loops``) and flag it there, so a stale attribute would otherwise train on garbage
+        silently.  Called where the loops already synchronise (per-epoch statistics read-back, evaluation)."""
+        if self._ws is None:
+            return
+        st = self.buffer("status", 4, torch.int32)
+        word = int((st[0] | st[1]).item())
+        if reset:
+            st[:2].zero_()
+        if word:
+            msgs = [m for bit, m in self._STATUS_BITS if word & bit] or ["unknown status bits"]
+            raise _lib.CalError("cal_amd engine: invalid batch (status 0x%x): %s" % (word, "; ".join(msgs)))
 
     def buffer(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
         off = _lib.query("cal_engine_buffer_offset", self._h, name.encode())
@@ -185,15 +255,16 @@ class StepEngine:
         self.reserve(N, E, B)
         self._last_B = B
         # layout facts of a collated batch -> one-kernel per-graph CSR build (the tensors stay referenced by the batch)
-        nptr, eptr = getattr(batch, "ptr", None), getattr(batch, "edge_ptr", None)
-        ok = (getattr(batch, "no_self_loops", False) and torch.is_tensor(nptr) and torch.is_tensor(eptr)
+        lay = _layout_of(batch, B) if self.fused else dict(ptr=None, edge_ptr=None, no_self_loops=False, max_nodes=0, max_edges=0)
+        nptr, eptr = lay["ptr"], lay["edge_ptr"]
+        ok = (lay["no_self_loops"] and torch.is_tensor(nptr) and torch.is_tensor(eptr)
               and nptr.is_cuda and eptr.is_cuda and nptr.dtype == torch.long and eptr.dtype == torch.long
               and nptr.numel() == B + 1 and eptr.numel() == B + 1 and nptr.is_contiguous() and eptr.is_contiguous())
         ptrs = (nptr.data_ptr(), eptr.data_ptr()) if ok else (0, 0)
         if ptrs != self._ptrs:
             _lib.call("cal_engine_set_graph_ptrs", self._h, ptrs[0] or None, ptrs[1] or None)
             self._ptrs = ptrs
-        bounds = (int(getattr(batch, "max_nodes", 0) or 0), int(getattr(batch, "max_edges", 0) or 0))
+        bounds = (lay["max_nodes"], lay["max_edges"])
         if bounds != self._bounds:
             _lib.call("cal_engine_set_graph_bounds", self._h, bounds[0], bounds[1])
             self._bounds = bounds
@@ -210,14 +281,23 @@ class StepEngine:
         lp = self.buffer("logp", 3 * B * self.C).view(3, B, self.C)
         return lp[0], lp[1], lp[2]
 
-    def train_step(self, batch, perm=None, adam: bool = True):
+    def train_step(self, batch, perm=None, adam: bool = True, tick: bool = False):
         """forward + loss + backward (+ Adam); returns the device stats tensor
-        [loss, c_loss, o_loss, co_loss, correct_o] (a view into the workspace)."""
-        self._run(batch, perm, 3 | (4 if adam else 0))
+        [loss, c_loss, o_loss, co_loss, correct_o] (a view into the workspace).  ``tick`` (with ``adam=False``):
+        the update follows a gradient exchange as ``adam_ticked()``; the step advances the Adam step counter."""
+        self._run(batch, perm, 3 | (4 if adam else (8 if tick else 0)))
         return self.buffer("stats", 5)
 
     def adam(self):
         _lib.call("cal_engine_adam", self._h, _stream())
+
+    def adam_ticked(self):
+        """The Adam update of a ``train_step(adam=False, tick=True)``, one launch (after the gradient all-reduce)."""
+        _lib.call("cal_engine_adam_ticked", self._h, _stream())
+
+    def set_grad_scale(self, scale: float):
+        """Factor on the gradient inside Adam: 1 / world_size turns the all-reduced sum into the replicas' mean."""
+        _lib.call("cal_engine_set_grad_scale", self._h, float(scale))
 
     def backward_from(self, batch, dlogp: torch.Tensor):
         """Backward of the LAST training-mode ``forward`` of ``batch`` from an external
@@ -252,15 +332,26 @@ class _EngineAutograd(torch.autograd.Function):
         B, C = eng._last_B, eng.C
         z = torch.zeros(B, C, dtype=torch.float32, device=eng.device)
         g = torch.stack([t if t is not None else z for t in (gc, go, gco)]).to(torch.float32)
+        # p.grad tensors that already alias the flat buffer hold the gradients of an earlier backward (accumulation)
+        # or in-place zeros (zero_grad(set_to_none=False)): backward_from overwrites the buffer, so keep them and add
+        params = list(eng.model.parameters())
+        views, off = [], 0
+        for p in params:
+            views.append(eng.flat_g[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        alias = [p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, views)]
+        old = eng.flat_g.clone() if any(alias) else None
         eng.backward_from(ctx.batch, g)
         eng._fwd_token += 1                                   # a second backward would double-count
         off = 0
-        for p in eng.model.parameters():                      # hand the gradients to autograd's owners
-            n = p.numel()
-            view = eng.flat_g[off:off + n].view(p.shape)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                p.grad = view if p.grad is None else p.grad.add_(view)
-            off += n
+        for p, view, al in zip(params, views, alias):          # hand the gradients to autograd's owners
+            if al:
+                view.add_(old[off:off + p.numel()].view(p.shape))
+            elif p.grad is None:
+                p.grad = view
+            else:
+                p.grad.add_(view)
+            off += p.numel()
         return None, None, None, None
 
 

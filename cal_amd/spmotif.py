@@ -24,7 +24,7 @@ Follows the *distribution* of the reference generator chain
 and the b-biased train mix of ``utils.dataset_bias_split`` (utils.py:123-159).
 It uses numpy's Generator instead of networkx's RNG stream, so individual
 graphs differ from the reference's; sizes and degree statistics match
-(tests/test_spmotif.py compares against reference-generated fixtures).
+(tests/test_data.py compares against reference-generated fixtures).
 """
 from __future__ import annotations
 

@@ -24,6 +24,13 @@ def _device():
     return torch.device("cuda")
 
 
+def _check_engine(model):
+    """Raise if any step since the last check flagged its batch as invalid (the read-back above already synchronised)."""
+    eng = getattr(model, "_engine", None)
+    if eng is not None:
+        eng.check_status()
+
+
 def num_graphs(data):
     """utils.py:12-16."""
     if data.batch is not None:
@@ -64,6 +71,7 @@ def train_causal_epoch(model, optimizer, loader, device, args, grad_sync=None):
         optimizer.step()
     num = len(loader.dataset)
     total_loss, total_loss_c, total_loss_o, total_loss_co, correct_o = (acc / num).tolist()
+    _check_engine(model)
     return total_loss, total_loss_c, total_loss_o, total_loss_co, correct_o
 
 
@@ -81,6 +89,7 @@ def eval_acc_causal(model, loader, device, args):
                                 o_logs.max(1)[1].eq(y).sum()]).to(torch.float64)
     n = len(loader.dataset)
     acc_co, acc_c, acc_o = (acc / n).tolist()
+    _check_engine(model)
     return acc_co, acc_c, acc_o
 
 

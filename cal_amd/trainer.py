@@ -7,20 +7,28 @@ MI355X-first choices (DESIGN.md section "step engine"):
   ONE flat gradient buffer -> Adam is a single fused update over one tensor and
   the data-parallel exchange is a single RCCL all-reduce of ~0.5 MB
   (latency-bound on xGMI, so: one bucket, one call);
-* CausalGCN runs on the native step engine (cal_amd/csrc/engine.hip): forward +
-  3-term loss + backward + Adam are ~55 fused kernels enqueued by ONE C call;
-  other models run the operator-level autograd path (cal_amd.ops) with torch's
-  loss / Adam;
+* CausalGCN / CausalGAT run on the native step engine (cal_amd/csrc/engine.hip):
+  forward + 3-term loss + backward + Adam are a few dozen fused kernels enqueued
+  by ONE C call; other models run the operator-level autograd path
+  (cal_amd.ops) with torch's loss / Adam;
 * either way the step for one resident, pre-collated batch is captured once
-  into a hipGraph and replayed -- no per-kernel host launch cost;
+  into a hipGraph and replayed -- no per-kernel host launch cost; a pass over
+  several resident batches can share one graph launch (``step_sequence``);
+* with more than one rank the RCCL all-reduce is captured inside the same graph
+  (between the backward's last kernel and Adam, which applies the 1/world mean),
+  so N > 1 differs from N = 1 only by the collective node;
 * the GraphPlan (CSR build) is rebuilt inside every step: it is part of the
   work the reference does per step (GCNConv.norm, gcn_conv.py:79-89);
-* the random-intervention permutation (model.py:147-152) stays a host-side
-  ``random.shuffle`` and is uploaded into a static device buffer before replay.
+* the random-intervention permutation (model.py:147-152) is drawn on the device
+  inside the captured step (``cal_randperm``, keyed by a seed taken from Python's
+  RNG); ``step(perm=...)`` / ``device_perm=False`` keep the host-side
+  ``random.shuffle`` stream of the reference.
 """
 from __future__ import annotations
 
+import os
 import random
+import warnings
 from typing import Dict, Optional, Sequence
 
 import torch
@@ -48,10 +56,21 @@ def flatten_parameters(model: torch.nn.Module):
     return flat_p, flat_g
 
 
+def _batch_ptrs(batch):
+    x = batch.x if getattr(batch, "x", None) is not None else batch.feat
+    return (x.data_ptr(), batch.edge_index.data_ptr(), batch.batch.data_ptr(), batch.y.data_ptr(),
+            int(x.size(0)), int(batch.edge_index.size(1)), int(batch.num_graphs))
+
+
+#: captured single-step graphs kept per trainer; batches beyond it (a loader yielding fresh batches every step)
+#: evict the oldest entry instead of growing without bound
+MAX_CAPTURED = 256
+
+
 class _Captured:
     """Captured step(s) of one resident batch: `graphs[True]` draws the intervention permutation on the
     device inside the graph (cal_randperm), `graphs[False]` reads it from `perm` (uploaded by the host)."""
-    __slots__ = ("graphs", "perm", "stats")
+    __slots__ = ("graphs", "perm", "stats", "batch", "ptrs")
 
 
 class _PinnedRing:
@@ -79,7 +98,8 @@ class _PinnedRing:
 class CausalTrainer:
     def __init__(self, model, args, lr: float = 1e-3, weight_decay: float = 0.0,
                  use_graph: bool = True, world_size: int = 1, rebuild_plan: bool = True,
-                 use_engine: Optional[bool] = None, device_perm: bool = True):
+                 use_engine: Optional[bool] = None, device_perm: bool = True,
+                 force_exchange: bool = False, graph_exchange: Optional[bool] = None):
         from . import engine as eng_mod
         self.model, self.args = model, args
         self.use_graph = use_graph
@@ -114,11 +134,31 @@ class CausalTrainer:
         self.device_perm = bool(device_perm)
         self._perm_seed = random.getrandbits(63)
         self._perm_counter = torch.zeros(1, dtype=torch.int64, device=self.flat_p.device)
-        # with one GPU the optimizer update rides in the same graph as forward/backward
-        self.fused_opt = self.engine is not None and world_size == 1
+        # Data parallel: one all-reduce (sum) of the flat gradient bucket per step, the 1/world mean
+        # folded into the engine's Adam kernel.  `exchange_in_graph`: the collective is captured INSIDE the step's
+        # hipGraph (RCCL collectives are capturable; gloo is not), so N > 1 keeps one graph launch per step -- and
+        # the multi-step sequence graph -- and differs from N = 1 only by the collective node.  Otherwise the step is
+        # graph(forward + backward) -> eager all-reduce -> graph(Adam).  `force_exchange` runs the exchange on a
+        # one-rank group too (tests the captured-collective path on a single GPU).
+        self.exchange = bool((world_size > 1 or force_exchange) and dist.is_available() and dist.is_initialized())
+        if world_size > 1 and not self.exchange:
+            raise RuntimeError("CausalTrainer(world_size > 1) needs an initialised torch.distributed process group")
+        if graph_exchange is None:
+            graph_exchange = os.environ.get("CAL_AMD_GRAPH_EXCHANGE", "1") != "0"
+        self.exchange_in_graph = bool(self.exchange and self.engine is not None and use_graph and graph_exchange
+                                      and dist.get_backend() == "nccl")
+        if self.exchange and self.engine is not None:
+            self.engine.set_grad_scale(1.0 / max(1, dist.get_world_size()))
+        # the optimizer update rides in the same graph as forward/backward (always on one GPU)
+        self.fused_opt = self.engine is not None and (not self.exchange or self.exchange_in_graph or not use_graph)
         self.model.train()
 
     # ------------------------------------------------------------------ pieces
+    def check_status(self):
+        """Synchronising check that no step since the last call flagged its batch as invalid (StepEngine.check_status)."""
+        if self.engine is not None:
+            self.engine.check_status()
+
     def set_lr(self, lr: float):
         if torch.is_tensor(self.lr):
             self.lr.fill_(lr)
@@ -160,7 +200,13 @@ class CausalTrainer:
         """One forward + backward (+ fused Adam); returns the device stats tensor.  On the engine path that is a
         view of the engine's own stats buffer (no copy node in the graph): it holds the LATEST step's values."""
         if self.engine is not None:
-            return self.engine.train_step(batch, perm, adam=self.fused_opt)
+            if not self.exchange:
+                return self.engine.train_step(batch, perm, adam=True)
+            stats = self.engine.train_step(batch, perm, adam=False, tick=True)      # k_finish advances the Adam step
+            if self.fused_opt:                        # collective + update in stream order (captured with the step)
+                dist.all_reduce(self.flat_g)
+                self.engine.adam_ticked()
+            return stats
         self.flat_g.zero_()
         if self.rebuild_plan:
             batch._plan = None
@@ -173,9 +219,11 @@ class CausalTrainer:
         return stats
 
     def _allreduce(self):
-        if self.world_size > 1:
+        """Gradient exchange outside the step graph (operator-level path, gloo, CAL_AMD_GRAPH_EXCHANGE=0)."""
+        if self.exchange and not self.fused_opt:
             dist.all_reduce(self.flat_g)
-            self.flat_g.mul_(1.0 / self.world_size)
+            if self.engine is None:                   # torch Adam has no gradient factor; the engine's k_adam does
+                self.flat_g.mul_(1.0 / dist.get_world_size())
 
     def _snapshot(self):
         state = {k: v.clone() for k, v in self.model.state_dict().items()}
@@ -199,6 +247,10 @@ class CausalTrainer:
         if cap is None:
             cap = _Captured()
             cap.graphs = {}
+            # the graph bakes in the batch's device pointers: keep the batch alive (its id() is the cache key and
+            # must not be recycled by a later batch) and remember the pointers to detect in-place replacement
+            cap.batch = batch
+            cap.ptrs = _batch_ptrs(batch)
             cap.perm = torch.arange(nb, dtype=torch.long, device=self.flat_p.device)
             cap.stats = torch.zeros(5, dtype=torch.float32, device=self.flat_p.device)
         draws = dev_perm and self._shuffles()
@@ -222,10 +274,23 @@ class CausalTrainer:
         torch.cuda.current_stream().wait_stream(s)
         self._restore(snap)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._pool):
-            if draws:
-                self._device_perm_into(cap.perm, nb)
-            cap.stats = self._fwd_bwd(batch, cap.perm, cap.stats)
+        try:
+            with torch.cuda.graph(g, pool=self._pool):
+                if draws:
+                    self._device_perm_into(cap.perm, nb)
+                cap.stats = self._fwd_bwd(batch, cap.perm, cap.stats)
+        except Exception as exc:
+            if not (self.exchange_in_graph and not self._graphs):
+                raise
+            # the collective refused stream capture: keep it between two graphs instead (every rank runs the same
+            # software, so every rank takes this branch)
+            warnings.warn("cal_amd: gradient all-reduce could not be captured into the step graph (%r); "
+                          "running it between the forward/backward graph and the Adam graph" % (exc,))
+            self.exchange_in_graph = False
+            self.fused_opt = False
+            torch.cuda.synchronize()
+            self._restore(snap)
+            return self._capture(batch, dev_perm, cap)
         self._restore(snap)
         cap.graphs[dev_perm] = g
         return cap
@@ -255,7 +320,7 @@ class CausalTrainer:
             if self.opt is not None:
                 self.opt.step()
             else:
-                self.engine.adam()
+                self.engine.adam_ticked()            # the step graph (mode bit 8) has advanced the counter
         if self.opt is not None:
             if saved_state is None:
                 self._reset_opt_state()
@@ -272,7 +337,7 @@ class CausalTrainer:
             if self.opt is not None:
                 self.opt.step()
             else:
-                self.engine.adam()
+                self.engine.adam_ticked()
             return
         if self._opt_graph is None:
             self._build_opt_graph()
@@ -321,10 +386,21 @@ class CausalTrainer:
 
     def _captured(self, batch, dev_perm: bool) -> _Captured:
         cap = self._graphs.get(id(batch))
+        if cap is not None and (cap.batch is not batch or cap.ptrs != _batch_ptrs(batch)):
+            # same id() but another object, or the batch's tensors were replaced: the baked-in pointers are stale
+            self._evict(id(batch))
+            cap = None
         if cap is None or dev_perm not in cap.graphs:
+            if cap is None and len(self._graphs) >= MAX_CAPTURED:
+                self._evict(next(iter(self._graphs)))
             cap = self._capture(batch, dev_perm, cap)
             self._graphs[id(batch)] = cap
         return cap
+
+    def _evict(self, key):
+        self._graphs.pop(key, None)
+        for k in [k for k in self._seqs if key in k]:
+            del self._seqs[k]
 
     def _upload_perm(self, perm: torch.Tensor, dst: torch.Tensor):
         if perm.is_cuda:
@@ -342,9 +418,9 @@ class CausalTrainer:
         if perm is None and not dev:
             perm = self.draw_perm(nb)
         if self.use_graph:
-            if id(batch) not in self._graphs:
-                self.prepare(batch)
             cap = self._captured(batch, dev)
+            if self._opt_graph is None and not self.fused_opt:
+                self._build_opt_graph()
             if not dev:
                 self._upload_perm(perm, cap.perm)
             cap.graphs[dev].replay()

@@ -163,19 +163,19 @@ def get_dataset(name: str, feat_str: str = "deg+odeg100", root: Optional[str] = 
 
 
 def k_fold(dataset, folds: int, epoch_select: str):
-    """utils.py:18-36."""
+    """Stratified k-fold index sets with the contract of utils.py:18-36: returns (train, test, val) lists of ``folds``
+    LongTensors.  Fold i's test set is the i-th stratified split (sklearn StratifiedKFold, shuffle, random_state 12345 --
+    the reference's seed, so the folds are the same partition); its validation set is the test set itself for
+    ``epoch_select == "test_max"``, otherwise the previous fold's test set (cyclically); the training set is every
+    remaining graph, ascending."""
     from sklearn.model_selection import StratifiedKFold
-    skf = StratifiedKFold(folds, shuffle=True, random_state=12345)
-    test_indices, train_indices = [], []
-    for _, idx in skf.split(torch.zeros(len(dataset)), dataset.y):
-        test_indices.append(torch.from_numpy(idx))
-    if epoch_select == "test_max":
-        val_indices = [test_indices[i] for i in range(folds)]
-    else:
-        val_indices = [test_indices[i - 1] for i in range(folds)]
-    for i in range(folds):
-        train_mask = torch.ones(len(dataset), dtype=torch.bool)
-        train_mask[test_indices[i].long()] = False
-        train_mask[val_indices[i].long()] = False
-        train_indices.append(train_mask.nonzero().view(-1))
-    return train_indices, test_indices, val_indices
+    n = len(dataset)
+    labels = dataset.y.view(-1).cpu().numpy()
+    splitter = StratifiedKFold(folds, shuffle=True, random_state=12345)
+    tests = [np.sort(held_out) for _, held_out in splitter.split(np.zeros(n), labels)]
+    shift = 0 if epoch_select == "test_max" else 1
+    vals = [tests[(i - shift) % folds] for i in range(folds)]
+    everything = np.arange(n)
+    trains = [np.setdiff1d(everything, np.union1d(tests[i], vals[i])) for i in range(folds)]
+    as_t = lambda arrs: [torch.from_numpy(np.asarray(a, dtype=np.int64)) for a in arrs]
+    return as_t(trains), as_t(tests), as_t(vals)

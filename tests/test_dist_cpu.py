@@ -88,3 +88,26 @@ def test_loader_shards_are_disjoint_and_cover():
         assert sum(b.num_graphs for b in dl) == len(shards[-1])
     assert not set(shards[0]) & set(shards[1])
     assert sorted(shards[0] + shards[1]) == list(range(len(gs)))
+
+
+def test_loader_shards_have_equal_length_for_any_dataset_size():
+    """n % world != 0 must not give ranks different step counts (mismatched all-reduce counts hang), and
+    without an explicit generator every rank must draw the SAME permutation (seed + epoch), like DistributedSampler."""
+    from cal_amd.data import DataLoader, shard_indices
+    from tests.helpers import ref_graphs
+    gs = ref_graphs(list(range(10)))
+    for world in (2, 3, 4):
+        for drop_last in (False, True):
+            loaders = [DataLoader(gs, 2, shuffle=True, rank=r, world_size=world, drop_last=drop_last, seed=5) for r in range(world)]
+            for epoch in range(2):
+                shards = [dl._indices() for dl in loaders]
+                assert len({len(s) for s in shards}) == 1, (world, drop_last, shards)
+                assert len({len(dl) for dl in loaders}) == 1
+                flat = sum(shards, [])
+                if drop_last:
+                    assert len(set(flat)) == len(flat) == (10 // world) * world
+                else:
+                    assert set(flat) == set(range(10)) and len(flat) == -(-10 // world) * world
+                steps = [sum(1 for _ in dl) for dl in loaders]          # iterating advances the epoch on every rank
+                assert len(set(steps)) == 1 and steps[0] == len(loaders[0])
+            assert loaders[0]._indices() != shard_indices(10, True, 0, world, drop_last, None, 5, 0)   # epoch 2 != epoch 0

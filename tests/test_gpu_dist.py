@@ -1,0 +1,163 @@
+"""The N > 1 trainer path on ONE GPU: `CausalTrainer(world_size > 1)` itself --
+not a toy net -- executed by
+
+* two ranks sharing device 0 over gloo (graph(forward + backward) -> all-reduce -> graph(Adam), the path taken when the
+  collective cannot be captured): replicas stay bit-identical, and the first step equals Adam on the MEAN of the two
+  oracle gradients (train_causal.py:187-192 per replica, `conv_feat.bias` never receiving a gradient tolerated);
+* a one-rank RCCL group with `force_exchange=True`: the all-reduce is captured INSIDE the step's hipGraph (the path
+  bench.py --gpus N takes), single-step graphs and the 8-step sequence graph, results equal to the exchange-free run.
+Each case runs in spawned processes so this pytest process never owns a process group."""
+import argparse
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _margs(**kw):
+    d = dict(layers=2, hidden=64, with_random=True, without_node_attention=False, without_edge_attention=False,
+             fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def _gloo_worker(rank, world, port, sd, q):
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from cal_amd import model as M
+        from cal_amd.trainer import CausalTrainer
+        from tests.helpers import ref_batch
+        m = M.CausalGCN(10, 4, _margs())
+        m.load_state_dict(sd)
+        m = m.cuda()
+        trn = CausalTrainer(m, _margs(), lr=1e-2, use_graph=True, world_size=world)
+        assert trn.exchange and not trn.exchange_in_graph and not trn.fused_opt
+        batches = [ref_batch(list(range(12 * rank + 4 * s, 12 * rank + 4 * s + 4)) * 2).to("cuda") for s in range(3)]
+        trn.reserve_for(batches)
+        out = []
+        for s, b in enumerate(batches):
+            perm = torch.arange(b.num_graphs - 1, -1, -1, device="cuda")
+            trn.step(b, perm=perm)
+            torch.cuda.synchronize()
+            out.append((trn.flat_g.cpu().numpy().copy(), trn.flat_p.detach().cpu().numpy().copy()))
+        assert int(trn.engine.step_count.item()) == 3
+        trn.check_status()
+        q.put((rank, out, None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as exc:      # surface the failure in the parent instead of a timeout
+        import traceback
+        q.put((rank, None, traceback.format_exc() + repr(exc)))
+
+
+def test_two_ranks_on_one_gpu_over_gloo_match_the_mean_gradient_oracle():
+    from oracle import cal_oracle as O
+    from tests.helpers import ref_batch
+    torch.manual_seed(12)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, {k: v.clone() for k, v in sd.items()}, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out, err = q.get(timeout=600)
+        assert err is None, err
+        res[rank] = out
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for s in range(3):                                    # replicas stay bit-identical after every step
+        assert np.array_equal(res[0][s][0], res[1][s][0]) and np.array_equal(res[0][s][1], res[1][s][1]), s
+    # step 1 == Adam on the mean of the two oracle gradients
+    grads = []
+    for rank in range(2):
+        b = ref_batch(list(range(12 * rank, 12 * rank + 4)) * 2)
+        tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-2, layers=2)
+        tr.step(b.feat, b.edge_index, b.batch, b.y, perm=torch.arange(b.num_graphs - 1, -1, -1))
+        grads.append({k: tr.sd[k].grad.clone() for k in tr.names if tr.sd[k].grad is not None})
+    from cal_amd import model as M
+    m = M.CausalGCN(10, 4, _margs())
+    off = 0
+    flat_g, flat_p = torch.from_numpy(res[0][0][0]), torch.from_numpy(res[0][0][1])
+    for k, p in m.named_parameters():
+        n = p.numel()
+        g_sum = flat_g[off:off + n].view(p.shape)             # the bucket holds the all-reduced SUM; Adam applies 1/world
+        if k in grads[0]:
+            mean = 0.5 * (grads[0][k] + grads[1][k])
+            assert torch.allclose(0.5 * g_sum, mean, atol=5e-5, rtol=2e-3), k
+            mask = mean.abs() > 1e-5
+            ref_p = sd[k] - 1e-2 * mean / (mean.abs() + 1e-8)           # Adam step 1: m_hat / (sqrt(v_hat) + eps)
+            assert torch.allclose(flat_p[off:off + n].view(p.shape)[mask], ref_p[mask], atol=2e-5, rtol=1e-4), k
+        else:
+            assert k == "conv_feat.bias" and float(g_sum.abs().max()) == 0.0
+        off += n
+
+
+def _nccl_worker(port, sd, q):
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from cal_amd import model as M
+        from cal_amd.trainer import CausalTrainer
+        from tests.helpers import ref_batch
+        res = {}
+        for tag, force in (("plain", False), ("exchange", True)):
+            import random
+            random.seed(3)
+            m = M.CausalGCN(10, 4, _margs())
+            m.load_state_dict(sd)
+            m = m.cuda()
+            trn = CausalTrainer(m, _margs(), lr=1e-2, use_graph=True, world_size=1, force_exchange=force)
+            batches = [ref_batch(list(range(4 * s, 4 * s + 8))).to("cuda") for s in range(4)]
+            trn.reserve_for(batches)
+            for b in batches:
+                trn.prepare(b)
+            if force:
+                assert trn.exchange and trn.exchange_in_graph and trn.fused_opt and trn.can_sequence(), "all-reduce was not captured"
+            for b in batches:                         # single-step graphs
+                trn.step(b)
+            trn.step_sequence(batches)                # and the multi-step sequence graph
+            trn.step_sequence(batches)
+            torch.cuda.synchronize()
+            res[tag] = (trn.flat_p.detach().cpu().clone(), int(trn.engine.step_count.item()))
+        q.put((res, None))
+        dist.destroy_process_group()
+    except Exception as exc:
+        import traceback
+        q.put((None, traceback.format_exc() + repr(exc)))
+
+
+def test_allreduce_is_captured_inside_the_step_graph_on_a_one_rank_rccl_group():
+    from oracle import cal_oracle as O
+    torch.manual_seed(13)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), sd, q))
+    p.start()
+    res, err = q.get(timeout=600)
+    p.join(120)
+    assert err is None, err
+    assert res["plain"][1] == res["exchange"][1] == 12
+    assert torch.equal(res["plain"][0], res["exchange"][0])        # mean over one rank: identical trajectory

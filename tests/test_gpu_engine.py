@@ -377,11 +377,8 @@ def test_fused_conv_matches_unfused_and_flags_bad_bounds():
     res = []
     for fused in (True, False):
         m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(hidden=128, layers=2), 10, 4)
-        if not fused:
-            bd.max_nodes, keep = 0, bd.max_nodes            # unknown bounds -> unfused kernels
+        eng.fused = fused                                   # False: layout withheld -> unfused kernels
         stats = eng.train_step(bd, perm, adam=False).cpu().clone()
-        if not fused:
-            bd.max_nodes = keep
         res.append((stats, eng.flat_g.clone(), eng.buffer("logp", 3 * len(sizes) * 4).clone()))
     assert torch.allclose(res[0][0], res[1][0], atol=1e-5)
     assert torch.allclose(res[0][2], res[1][2], atol=2e-5)

@@ -328,8 +328,8 @@ def test_fused_per_graph_gat_forward_with_dropout_matches_oracle():
     # the status word stays clean and the unfused path (no per-graph bounds) gives the same logits
     assert int(eng.buffer("status", 1, torch.int32)[0].item()) == 0
     bd2 = ref_batch(ids).to(DEV)
-    bd2.max_nodes = bd2.max_edges = 0
     m2, eng2 = _engine({k: v.clone() for k, v in sd.items()}, _args())
+    eng2.fused = False
     for i, c in enumerate(m2.convs):
         c.seed = 500 + i
     eng2.train_step(bd2, perm.to(DEV), adam=False)
