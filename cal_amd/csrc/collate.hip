@@ -36,48 +36,13 @@ __global__ void __launch_bounds__(256) k_collate(const float* __restrict__ X, co
     if (threadIdx.x == 0) yo[b] = Y[g];
 }
 
-// Random-intervention permutation (model.py:147-152: `random.shuffle(list(range(num)))`) drawn ON the
-// device inside the captured step, so that a step needs no host RNG, no pinned staging and no H2D
-// copy in front of its hipGraph: graph b gets the key splitmix64(seed, *counter, b) and the
-// permutation is the argsort of the keys (bitonic network in LDS, one workgroup, B <= 4096).
-// *counter is advanced by the kernel itself, so replaying the same graph draws a fresh permutation.
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
+// Stand-alone draw of the random-intervention permutation (randperm_block in engine_kernels.hpp): one workgroup, B <= 4096.
 constexpr int PERM_MAX = 4096;
 __global__ void __launch_bounds__(1024) k_randperm(int64_t* __restrict__ perm, int B, unsigned long long seed,
                                                     unsigned long long* __restrict__ counter) {
     __shared__ unsigned long long key[PERM_MAX];
     __shared__ int idx[PERM_MAX];
-    int n = 1;
-    while (n < B) n <<= 1;
-    const unsigned long long cnt = *counter;
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        // padding keys sort to the end; real keys keep 63 random bits
-        key[i] = i < B ? (splitmix64(splitmix64(seed ^ (cnt * 0xD1342543DE82EF95ull)) + (unsigned long long)i) >> 1)
-                       : 0xFFFFFFFFFFFFFFFFull;
-        idx[i] = i;
-    }
-    __syncthreads();
-    for (int k = 2; k <= n; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n; i += 1024) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const bool up = (i & k) == 0;
-                    const unsigned long long a = key[i], b = key[p];
-                    // ties (probability ~B^2 / 2^64) broken by index so the result is always a permutation
-                    const bool gt = a > b || (a == b && idx[i] > idx[p]);
-                    if (gt == up) { key[i] = b; key[p] = a; const int t = idx[i]; idx[i] = idx[p]; idx[p] = t; }
-                }
-            }
-            __syncthreads();
-        }
-    for (int i = threadIdx.x; i < B; i += 1024) perm[i] = idx[i];
-    if (threadIdx.x == 0) *counter = cnt + 1;
+    randperm_block<1024>(perm, B, seed, counter, key, idx);
 }
 
 }  // namespace cal

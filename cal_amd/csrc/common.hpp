@@ -105,6 +105,47 @@ template <> struct Vec<1> {
     __device__ __forceinline__ void pin() { asm volatile("" : "+v"(v)); }
 };
 
+// Random-intervention permutation (model.py:147-152, `random.shuffle(range(num))`) drawn on the device: graph b gets
+// the key splitmix64(seed, *counter, b), the permutation is the argsort of the keys (bitonic network in LDS, one
+// workgroup of NT threads, B <= CAP); *counter is advanced, so a replayed hipGraph draws a fresh permutation every
+// step.  Shared by cal_randperm (collate.hip, stand-alone) and the step engine's first kernel.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+template <int NT>
+__device__ __forceinline__ void randperm_block(int64_t* __restrict__ perm, int B, unsigned long long seed,
+                                               unsigned long long* __restrict__ counter, unsigned long long* key, int* idx) {
+    int n = 1;
+    while (n < B) n <<= 1;
+    const unsigned long long cnt = *counter;
+    for (int i = threadIdx.x; i < n; i += NT) {
+        // padding keys sort to the end; real keys keep 63 random bits
+        key[i] = i < B ? (splitmix64(splitmix64(seed ^ (cnt * 0xD1342543DE82EF95ull)) + (unsigned long long)i) >> 1)
+                       : 0xFFFFFFFFFFFFFFFFull;
+        idx[i] = i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += NT) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = key[i], b = key[p];
+                    // ties (probability ~B^2 / 2^64) broken by index so the result is always a permutation
+                    const bool gt = a > b || (a == b && idx[i] > idx[p]);
+                    if (gt == up) { key[i] = b; key[p] = a; const int t = idx[i]; idx[i] = idx[p]; idx[p] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < B; i += NT) perm[i] = idx[i];
+    if (threadIdx.x == 0) *counter = cnt + 1;
+}
+
 }  // namespace cal
 
 namespace cal { inline const char* g_last_launch = ""; }     // name of the latest launch site (profiling aid)

@@ -25,6 +25,7 @@
 #include "engine_gconv_bwd.hpp"
 #include "engine_ggat.hpp"
 #include "engine_plan.hpp"
+#include "engine_attbwd.hpp"
 
 namespace cal {
 
@@ -120,6 +121,8 @@ struct Engine {
     float *P, *G, *M1, *M2, *step, *lr;
     int64_t nparam;
     float beta1, beta2, eps, wd;
+    unsigned long long perm_seed; unsigned long long* perm_ctr;   // device draw of the random-intervention permutation (mode bit 16)
+    int64_t* perm_dev;          // [capB] the permutation drawn by the step itself
     float grad_scale;           // gradient factor inside Adam (1 / world_size after a sum all-reduce)
     // parameter offsets (floats into P / G)
     int o_feat_w;
@@ -144,6 +147,7 @@ struct Engine {
     // side stream for the weight-gradient GEMMs (off the critical path until the final commit)
     hipStream_t side; hipEvent_t ev_fork[24], ev_join[24];
     int *rowptr_dst, *nbr_dst, *eid_dst, *rowptr_src, *nbr_src, *eid_src, *row32, *col32, *work, *status, *gptr, *iperm, *eptr;
+    float* wslot;               // [2][E] attention edge weights (context, objects) in CSR-by-destination slot order
     float* coef;                // [3][E] edge coefficients dis_j * w_e in CSR-by-destination slot order: unit, context, objects
     int max_nodes, max_edges;   // per-graph bounds of the coming batches (0 = unknown): cal_engine_set_graph_bounds
     const int64_t *node_ptr, *edge_ptr;   // [B+1] device arrays of the coming batch (null = unknown): cal_engine_set_graph_ptrs
@@ -309,8 +313,10 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     I32(e->rowptr_src, N + 1); I32(e->nbr_src, E); I32(e->eid_src, E);
     I32(e->row32, E); I32(e->col32, E); I32(e->work, 4 * (N + 1) + 4 * E); I32(e->status, 4); I32(e->gptr, B + 1);
     I32(e->iperm, B);
+    { int* tmp = nullptr; I32(tmp, 2 * B + 2); if (assign) e->perm_dev = (int64_t*)tmp; }
     I32(e->eptr, B + 1);
     F32(e->coef, 3 * E);
+    F32(e->wslot, 2 * E);
     if (e->K > 0) {
         const size_t K = e->K;
         F32(e->gz, (L > 0 ? L : 1) * N * H); F32(e->gsc, (L > 0 ? L : 1) * 4 * al(N * K));
@@ -361,7 +367,7 @@ CAL_EXPORT int64_t cal_engine_buffer_offset(void* h, const char* name) {
         {"dl", e->dl}, {"dzco", e->dzco}, {"dXhco", e->dXhco}, {"dZ", e->dZ}, {"dzi", e->dzi}, {"dXh", e->dXh},
         {"arena", e->arena}, {"gptr", e->gptr}, {"status", e->status}, {"eptr", e->eptr},
         {"rowptr_dst", e->rowptr_dst}, {"nbr_dst", e->nbr_dst}, {"eid_dst", e->eid_dst},
-        {"rowptr_src", e->rowptr_src}, {"nbr_src", e->nbr_src}, {"eid_src", e->eid_src},
+        {"rowptr_src", e->rowptr_src}, {"nbr_src", e->nbr_src}, {"eid_src", e->eid_src}, {"perm", e->perm_dev},
     };
     for (auto& t : tab)
         if (!strcmp(t.n, name)) return ((char*)t.p - e->ws) / 4;
@@ -379,6 +385,7 @@ struct Ctx {
     int rpb_n, rpb_b;   // rows per block for node-level / graph-level row walkers
     int nfork;          // weight-gradient GEMMs forked to the side stream so far
     const int64_t* y; const int64_t* perm; float wc, wo, wco; int want_grad;
+    int draw_perm;      // the step draws its own intervention permutation (first kernel) into Engine::perm_dev
     int tick_in_finish; // the step ends with the Adam update: k_finish advances the step counter
     size_t parts_off;   // bump allocator over Engine::parts
     FinalArgs fin;      // pending k_stats_final tasks
@@ -658,9 +665,9 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     // 0. zero the fp64 arena and the GraphPlan counters (one kernel, not memset nodes)
     {
         const int64_t ni = fast_plan ? 0 : 4 * ((int64_t)N + 1);
-        hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256)), dim3(256), 0, st, e->arena,
-                           (int64_t)e->arena_n, e->work, ni, e->status,
-                           (e->K > 0 && c.training) ? e->gat_ctr : nullptr);
+        hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256) + (c.draw_perm ? 1 : 0)), dim3(256), 0, st,
+                           e->arena, (int64_t)e->arena_n, e->work, ni, e->status, (e->K > 0 && c.training) ? e->gat_ctr : nullptr,
+                           c.draw_perm ? e->perm_dev : nullptr, B, e->perm_seed, e->perm_ctr);
         CAL_CHECK_LAUNCH("k_zero_f64"); STAGE();
     }
     // 1. GraphPlan
@@ -822,6 +829,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             gb[k].rs = e->anode + k; gb[k].rs_stride = 2; gb[k].bn = bnref(c, L + 1 + k, N, 1);
             gb[k].out = e->hco + (size_t)k * NH; gb[k].z = e->zco + (size_t)k * NH; gb[k].pooled = e->pooled + (size_t)k * B * H;
             gb[k].coef_out = e->coef + (size_t)(1 + k) * E;
+            gb[k].w_out = e->wslot + (size_t)k * E;
         }
         if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<true, 64>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, gb[0], gb[1], 1,
                                             e->loop_w, H, H, e->status);
@@ -935,6 +943,10 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     struct Deferred { double* p; int P; int stride; };
     auto deferred = [&](int cols, Deferred& d) -> Acc {
         d.p = parts_alloc(c, (size_t)PN * cols); d.P = PN; d.stride = cols;
+        return d.p ? Acc(nullptr, d.p, cols) : Acc();
+    };
+    auto deferred_g = [&](int cols, Deferred& d) -> Acc {          // two partial rows per graph (k_att_bwd_graph, grid (2 B))
+        d.p = parts_alloc(c, (size_t)2 * B * cols); d.P = 2 * B; d.stride = cols;
         return d.p ? Acc(nullptr, d.p, cols) : Acc();
     };
     Deferred d_convb[MAX_LAYERS], d_cb, d_ob, d_dwn, d_dwe, d_bn0;
@@ -1084,12 +1096,13 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             gb[k].rs = e->anode + k; gb[k].rs_stride = 2; gb[k].bn = bnref(c, L + 1 + k, N, 0);
             gb[k].dxp0 = e->dXhco + (size_t)k * NH; gb[k].dxp1 = e->dzco + (size_t)k * NH;
             gb[k].coef_in = e->coef + (size_t)(1 + k) * E;
+            gb[k].gn_slot = 1;                  // consumed by k_att_bwd_graph in slot order
             dst[k] = e->G + (k ? e->o_ow : e->o_cw); dsum[k] = bn_dsum(c, L + 1 + k); dprod[k] = bn_dprod(c, L + 1 + k);
         }
         RC(gconv_bwd(c, gd, gb, 2, dst, dsum, dprod, fa, slab_off, true)); STAGE();
         RC(flush_finals(c)); STAGE();
-        const bool two = H > GC_N;
-        RC(norm_bwd(two ? e->gn + 2 * (size_t)E : nullptr, two ? e->gself + 2 * (size_t)N : nullptr));
+        // (the edge-weight gradients through the normalisation -- k_normbwd_node2 / k_normbwd_edge of the unfused path --
+        //  are part of the per-graph attention backward below)
     }
     // P6. dW_k = BN_k(a_k x)^T @ dz_k
     if (!gcb) {
@@ -1123,6 +1136,22 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         aa.dsc = bn_dsum(c, L + 1); aa.dpc = bn_dprod(c, L + 1); aa.dso = bn_dsum(c, L + 2); aa.dpo = bn_dprod(c, L + 2);
         aa.Wn = e->P + e->o_natt_w; aa.We = e->P + e->o_eatt_w; aa.dl = e->dl;
         aa.gs = gs; aa.gd = gd; aa.dZ = e->dZ;
+        if (gcb) {       // per graph: d deg, d edge logits and the row pass in one kernel (engine_attbwd.hpp)
+            aa.dbias = L > 0 ? deferred_g(H, d_convb[L - 1]) : Acc();
+            aa.dWn = deferred_g(H + 4, d_dwn); aa.dWe = deferred_g(2 * H + 4, d_dwe);
+            if (!aa.dWn.on() || !aa.dWe.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
+            AttBwdGraphArgs ag;
+            ag.a = aa; ag.gptr = e->gptr; ag.eptr = e->eptr; ag.att = e->wslot; ag.dis = e->dis_co;
+            ag.gn = e->gn; ag.gn2 = two ? e->gn + 2 * (size_t)E : nullptr;
+            ag.gself = e->gself; ag.gself2 = two ? e->gself + 2 * (size_t)N : nullptr;
+            ag.loop_w = e->loop_w; ag.E = E; ag.N = N; ag.status = e->status;
+            RC(with_g(H, [&](auto g) {
+                constexpr int G = decltype(g)::value;
+                hipLaunchKernelGGL((k_att_bwd_graph<4, G>), dim3(2 * B), dim3(512), 0, st, ag, 1, H);
+                return 0;
+            }));
+            CAL_CHECK_LAUNCH("k_att_bwd_graph"); STAGE();
+        } else {
         aa.dbias = L > 0 ? deferred(H, d_convb[L - 1]) : Acc();
         aa.dWn = deferred(H + 4, d_dwn); aa.dWe = deferred(2 * H + 4, d_dwe);
         if (!aa.dWn.on() || !aa.dWe.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
@@ -1132,6 +1161,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             return 0;
         }));
         CAL_CHECK_LAUNCH("k_att_bwd"); STAGE();
+        }
     }
     bool feat_done = false;     // the per-graph feature-layer backward (k_feat_bwd) has run
     // Q. backbone layers, last to first
@@ -1410,6 +1440,10 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     c.fin.nt = 0;
     c.nfork = 0;
     const int want_grad = (mode & 2) ? 1 : 0;
+    c.draw_perm = (mode & 16) ? 1 : 0;
+    CAL_REQUIRE(!c.draw_perm || (e->perm_ctr && B <= ZP_CAP), "mode bit 16 needs cal_engine_set_perm_rng and at most 1024 graphs per batch");
+    CAL_REQUIRE(c.draw_perm || perm, "perm is null and the step does not draw its own (mode bit 16)");
+    if (c.draw_perm) perm = e->perm_dev;
     c.y = y; c.perm = perm; c.wc = wc; c.wo = wo; c.wco = wco; c.want_grad = want_grad;
     c.tick_in_finish = (mode & (4 | 8)) ? 1 : 0;
     CAL_REQUIRE(!(mode & 8) || want_grad, "mode bit 8 (Adam follows a gradient exchange) needs the backward pass");
@@ -1452,7 +1486,7 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
     c.rpb_b = std::max(32, cdiv(B, 64));
     c.parts_off = 0; c.fin.nt = 0; c.nfork = 0;
     c.y = nullptr; c.perm = nullptr; c.wc = c.wo = c.wco = 0.f; c.want_grad = 1;
-    c.tick_in_finish = 0;
+    c.tick_in_finish = 0; c.draw_perm = 0;
     hipLaunchKernelGGL(k_logsoftmax_bwd, dim3(1), dim3(256), 0, c.st, e->logp, dlogp, e->dzl, e->arena + e->a_db2, (int)B, e->C);
     CAL_CHECK_LAUNCH("k_logsoftmax_bwd");
     g_stage = 0;
@@ -1539,6 +1573,14 @@ CAL_EXPORT int cal_engine_adam_ticked(void* h, void* stream_) {
     hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
                        e->beta2, e->eps, e->wd, e->nparam, 1, e->grad_scale);
     CAL_CHECK_LAUNCH("k_adam");
+    return 0;
+}
+// Random-intervention permutation drawn by the step itself (mode bit 16; model.py:147-152): keyed by (seed, *counter), the
+// device counter advancing once per drawing step.  The drawn permutation is the workspace buffer "perm" (int64 [B]).
+CAL_EXPORT int cal_engine_set_perm_rng(void* h, uint64_t seed, uint64_t* counter) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e != nullptr, "bad arguments");
+    e->perm_seed = seed; e->perm_ctr = (unsigned long long*)counter;
     return 0;
 }
 // Factor applied to the bound gradient buffer inside the Adam update (1/world_size turns the all-reduced SUM of the

@@ -51,6 +51,7 @@ struct GconvBranch {
     // instead of chasing nbr -> dis / eid -> w in a second one
     const float* coef_in;
     float* coef_out;
+    float* w_out;            // with coef_out: the raw edge weights w_e in CSR-slot order (read by the per-graph attention backward), or null
 };
 
 typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
@@ -191,16 +192,16 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
 #pragma unroll
     for (int u = 0; u < 8; ++u) ro_pin(vb[u]);
     // second round: edge coefficients dis_j * w_e (needs the neighbour / edge ids)
-    float cv[8];
+    float cv[8], wv[8];
     if (br.coef_in) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cv[u] = cin[u];
+        for (int u = 0; u < 8; ++u) { cv[u] = cin[u]; wv[u] = 1.f; }
     } else {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            float c = br.dis[nv[u]];
-            if (hasw) c *= br.ew[ev[u]];
-            cv[u] = c;
+            const float c = br.dis[nv[u]];
+            wv[u] = hasw ? br.ew[ev[u]] : 1.f;
+            cv[u] = c * wv[u];
         }
     }
     RO_CLK(33);
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
             const int loc = nv[u] - g0;
             const bool inb = loc >= 0 && loc < rows;        // an edge that leaves its graph is not a mini-batch: flag it
             en[s] = inb ? loc : 0; ec[s] = inb ? cv[u] : 0.f;
-            if (br.coef_out && blockIdx.y == 0) br.coef_out[e0 + s] = cv[u];
+            if (br.coef_out && blockIdx.y == 0) { br.coef_out[e0 + s] = cv[u]; if (br.w_out) br.w_out[e0 + s] = wv[u]; }
             if (!inb) atomicOr(status, 16);
         }
     }

@@ -59,6 +59,7 @@ struct GconvBwdBranch {
     const float* z;          // [N,H] x' W of the forward
     float* gn; float* gself; // this branch's [E] / [N] partials of slice 0; slice 1 is gn_stride / gself_stride further
     size_t gn_stride, gself_stride;
+    int gn_slot;             // gn is written in CSR-slot order (gn[eptr[b] + s], for the per-graph attention backward) instead of edge-id order
 };
 
 // acc[0] (+acc[1]) += A B over kred (multiple of 32) with k-major LDS operands A[k*LDA + row], B[k*LDB + col];
@@ -345,7 +346,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
                 p += __shfl_xor(p, 1, 64);
                 p += __shfl_xor(p, 2, 64);
                 if (ok && q4 == 0) {
-                    if (isedge) gn[ee[itc]] = p; else gs[g0 + itc - ne] = p;
+                    if (isedge) gn[br.gn_slot ? e0 + itc : ee[itc]] = p; else gs[g0 + itc - ne] = p;
                 }
             }
         }

@@ -239,9 +239,22 @@ class StepEngine:
             return self._ws[off:off + 2 * numel].view(torch.float64)
         if dtype == torch.int32:
             return self._ws[off:off + numel].view(torch.int32)
+        if dtype == torch.int64:
+            return self._ws[off:off + 2 * numel].view(torch.int64)
         return self._ws[off:off + numel]
 
     # --------------------------------------------------------------------- run
+    def set_perm_rng(self, seed: int, counter: torch.Tensor):
+        """Key of the random-intervention permutations the step draws itself (``train_step(draw_perm=True)``): ``seed`` and
+        a device int64 counter that the drawing kernel advances (same stream of permutations as ``cal_randperm``)."""
+        assert counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1
+        self._perm_counter = counter
+        _lib.call("cal_engine_set_perm_rng", self._h, int(seed) & ((1 << 64) - 1), _p(counter))
+
+    def drawn_perm(self, B: int) -> torch.Tensor:
+        """The permutation the latest ``draw_perm`` step drew (device int64 [B], a view into the workspace)."""
+        return self.buffer("perm", B, torch.int64)
+
     def _run(self, batch, perm, mode: int):
         x = batch.x if getattr(batch, "x", None) is not None else batch.feat
         ei, bvec, y = batch.edge_index, batch.batch, batch.y
@@ -268,12 +281,15 @@ class StepEngine:
         if bounds != self._bounds:
             _lib.call("cal_engine_set_graph_bounds", self._h, bounds[0], bounds[1])
             self._bounds = bounds
-        if perm is None:
+        if mode & 16:
+            perm = None                                   # drawn by the step's first kernel
+        elif perm is None:
             perm = torch.arange(B, device=self.device)
         if y is None:
             y = torch.zeros(B, dtype=torch.long, device=self.device)
         _lib.call("cal_engine_step", self._h, _p(x.contiguous()), _p(ei.contiguous()), _p(bvec.contiguous()),
-                  _p(y.view(-1).contiguous()), _p(perm.contiguous()), N, E, B, self.wc, self.wo, self.wco, mode, _stream())
+                  _p(y.view(-1).contiguous()), _p(perm.contiguous()) if perm is not None else None, N, E, B,
+                  self.wc, self.wo, self.wco, mode, _stream())
         return B
 
     def forward(self, batch, perm=None, training: bool = False):
@@ -281,11 +297,12 @@ class StepEngine:
         lp = self.buffer("logp", 3 * B * self.C).view(3, B, self.C)
         return lp[0], lp[1], lp[2]
 
-    def train_step(self, batch, perm=None, adam: bool = True, tick: bool = False):
+    def train_step(self, batch, perm=None, adam: bool = True, tick: bool = False, draw_perm: bool = False):
         """forward + loss + backward (+ Adam); returns the device stats tensor
         [loss, c_loss, o_loss, co_loss, correct_o] (a view into the workspace).  ``tick`` (with ``adam=False``):
-        the update follows a gradient exchange as ``adam_ticked()``; the step advances the Adam step counter."""
-        self._run(batch, perm, 3 | (4 if adam else (8 if tick else 0)))
+        the update follows a gradient exchange as ``adam_ticked()``; the step advances the Adam step counter.
+        ``draw_perm``: the step draws the random-intervention permutation itself (``set_perm_rng``), in its first kernel."""
+        self._run(batch, perm, 3 | (4 if adam else (8 if tick else 0)) | (16 if draw_perm else 0))
         return self.buffer("stats", 5)
 
     def adam(self):

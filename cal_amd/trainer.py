@@ -134,6 +134,8 @@ class CausalTrainer:
         self.device_perm = bool(device_perm)
         self._perm_seed = random.getrandbits(63)
         self._perm_counter = torch.zeros(1, dtype=torch.int64, device=self.flat_p.device)
+        if self.engine is not None:       # the engine draws inside its first kernel: no launch of its own for the permutation
+            self.engine.set_perm_rng(self._perm_seed, self._perm_counter)
         # Data parallel: one all-reduce (sum) of the flat gradient bucket per step, the 1/world mean
         # folded into the engine's Adam kernel.  `exchange_in_graph`: the collective is captured INSIDE the step's
         # hipGraph (RCCL collectives are capturable; gloo is not), so N > 1 keeps one graph launch per step -- and
@@ -196,13 +198,22 @@ class CausalTrainer:
             g = max(int(b.num_graphs) for b in batches)
             self.engine.reserve(n, e, g)
 
-    def _fwd_bwd(self, batch, perm, stats):
+    def _in_engine_draw(self, num: int) -> bool:
+        """The engine draws the permutation in its own first kernel (up to 1024 graphs; beyond that cal_randperm)."""
+        return self.engine is not None and num <= 1024 and self._shuffles()
+
+    def _fwd_bwd(self, batch, perm, stats, draw: bool = False):
         """One forward + backward (+ fused Adam); returns the device stats tensor.  On the engine path that is a
-        view of the engine's own stats buffer (no copy node in the graph): it holds the LATEST step's values."""
+        view of the engine's own stats buffer (no copy node in the graph): it holds the LATEST step's values.
+        ``draw``: the intervention permutation is drawn on the device for this step (inside the engine's first kernel
+        when it can, else by cal_randperm into ``perm`` first)."""
+        if draw and not self._in_engine_draw(batch.num_graphs):
+            self._device_perm_into(perm, batch.num_graphs)
+            draw = False
         if self.engine is not None:
             if not self.exchange:
-                return self.engine.train_step(batch, perm, adam=True)
-            stats = self.engine.train_step(batch, perm, adam=False, tick=True)      # k_finish advances the Adam step
+                return self.engine.train_step(batch, perm, adam=True, draw_perm=draw)
+            stats = self.engine.train_step(batch, perm, adam=False, tick=True, draw_perm=draw)  # k_finish advances the Adam step
             if self.fused_opt:                        # collective + update in stream order (captured with the step)
                 dist.all_reduce(self.flat_g)
                 self.engine.adam_ticked()
@@ -268,17 +279,13 @@ class CausalTrainer:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(2):
-                if draws:
-                    self._device_perm_into(cap.perm, nb)
-                self._fwd_bwd(batch, cap.perm, cap.stats)
+                self._fwd_bwd(batch, cap.perm, cap.stats, draw=draws)
         torch.cuda.current_stream().wait_stream(s)
         self._restore(snap)
         g = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(g, pool=self._pool):
-                if draws:
-                    self._device_perm_into(cap.perm, nb)
-                cap.stats = self._fwd_bwd(batch, cap.perm, cap.stats)
+                cap.stats = self._fwd_bwd(batch, cap.perm, cap.stats, draw=draws)
         except Exception as exc:
             if not (self.exchange_in_graph and not self._graphs):
                 raise
@@ -376,9 +383,7 @@ class CausalTrainer:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._pool):
                 for b, cap in zip(batches, caps):
-                    if self._shuffles():
-                        self._device_perm_into(cap.perm, b.num_graphs)
-                    stats = self._fwd_bwd(b, cap.perm, cap.stats)
+                    stats = self._fwd_bwd(b, cap.perm, cap.stats, draw=self._shuffles())
             self._restore(snap)
             seq = self._seqs[key] = (g, stats, list(batches))
         seq[0].replay()
@@ -432,11 +437,11 @@ class CausalTrainer:
                 if self._eager_perm is None or self._eager_perm.numel() < nb:
                     self._eager_perm = torch.empty(max(nb, 1), dtype=torch.long, device=self.flat_p.device)
                 dperm = self._eager_perm[:nb]
-                if dev:
-                    self._device_perm_into(dperm, nb)
-                else:
+                if not dev:
                     self._upload_perm(perm, dperm)
-            stats = self._fwd_bwd(batch, dperm, self.stats)
+                elif not self._shuffles():
+                    self._device_perm_into(dperm, nb)           # identity
+            stats = self._fwd_bwd(batch, dperm, self.stats, draw=dev and self._shuffles())
         self._allreduce()
         self._opt_step()
         return stats

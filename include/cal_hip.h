@@ -146,7 +146,8 @@ CAL_API int cal_engine_set_gat(void* engine, int64_t heads, float p, float slope
  * The whole train step of train_causal.py:173-192 on model.py:85-164 (forward, 3-term loss,
  * backward, Adam) as one call enqueuing a few dozen fused kernels (32 at BASELINE config 2); see cal_amd/csrc/engine.hip for the
  * slot order of `offs` / `bn_ptrs`.  mode bits: 1 = training-mode forward, 2 = loss gradient +
- * backward into the flat gradient buffer, 4 = Adam, 8 = Adam follows separately (cal_engine_adam_ticked).  Outputs ("logp" [3,B,C], "stats" [5] =
+ * backward into the flat gradient buffer, 4 = Adam, 8 = Adam follows separately (cal_engine_adam_ticked),
+ * 16 = draw the random-intervention permutation on the device inside the step's first kernel (`perm` ignored; cal_engine_set_perm_rng).  Outputs ("logp" [3,B,C], "stats" [5] =
  * loss, c_loss, o_loss, co_loss, correct_o) live in the caller-owned workspace at
  * cal_engine_buffer_offset(name) floats from its base. */
 CAL_API void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L);
@@ -165,6 +166,9 @@ CAL_API int cal_engine_step(void* engine, const float* x0, const int64_t* edge_i
                             int64_t E, int64_t B, float wc, float wo, float wco, int mode,
                             void* stream);
 CAL_API int cal_engine_adam(void* engine, void* stream);
+/* model.py:147-152 on the device, inside the step (mode bit 16): permutation keyed by (seed, *counter), as cal_randperm draws it;
+ * the device counter advances once per drawing step, so a replayed hipGraph draws a fresh permutation.  B <= 1024. */
+CAL_API int cal_engine_set_perm_rng(void* engine, uint64_t seed, uint64_t* counter);
 /* data parallel (train_causal.py:187-192 per replica): cal_engine_step(mode = 1|2|8) runs forward + backward
  * and advances the Adam step counter, the caller all-reduces (sum) the bound gradient buffer, cal_engine_adam_ticked applies
  * the update in ONE launch with the gradient multiplied by cal_engine_set_grad_scale's factor (1 / world_size = mean) */

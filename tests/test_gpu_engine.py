@@ -329,6 +329,29 @@ def test_device_randperm_is_a_fresh_uniform_permutation():
     assert (counts - trials / B).abs().max() < 6 * (trials / B) ** 0.5      # ~6 sigma of a binomial cell
 
 
+def test_engine_draws_the_same_permutations_as_cal_randperm():
+    """Mode bit 16: the step's first kernel draws the intervention permutation (no launch of its own); for the same
+    (seed, counter) it is cal_randperm's permutation, the counter advances once per step, and the step equals one that
+    was handed that permutation explicitly."""
+    from cal_amd import _lib
+    from cal_amd.plan import _p, _stream
+    _, bd = _config2_batch(24, seed=2)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=32, layers=2)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(layers=2, hidden=32))
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    eng.set_perm_rng(777, cnt)
+    ref_cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ref = torch.empty(24, dtype=torch.long, device=DEV)
+    for k in range(3):
+        stats = eng.train_step(bd, None, adam=False, draw_perm=True).clone()
+        g = eng.flat_g.clone()
+        _lib.call("cal_randperm", _p(ref), 24, 777, _p(ref_cnt), _stream())
+        assert torch.equal(eng.drawn_perm(24), ref) and int(cnt.item()) == k + 1
+        m2, eng2 = _engine({k_: v.clone() for k_, v in sd.items()}, _args(layers=2, hidden=32))
+        stats2 = eng2.train_step(bd, ref.clone(), adam=False)
+        assert torch.equal(stats, stats2) and torch.equal(g, eng2.flat_g)
+
+
 def test_trainer_device_perm_graph_trains_and_redraws():
     """Default trainer path: the permutation is drawn inside the captured graph (no host upload); an explicit
     host permutation still works on the same trainer and matches the eager engine bit for bit."""
@@ -344,7 +367,7 @@ def test_trainer_device_perm_graph_trains_and_redraws():
     losses, perms = [], []
     for i in range(8):
         losses.append(tr.step(b1)[0].item())
-        perms.append(tr._graphs[id(b1)].perm.cpu().clone())
+        perms.append(tr.engine.drawn_perm(32).cpu().clone())     # drawn by the step's first kernel
         assert torch.equal(perms[-1].sort().values, torch.arange(32))
     assert len({tuple(p.tolist()) for p in perms}) == 8          # a fresh draw on every replay
     assert losses[-1] < losses[0]
