@@ -91,6 +91,43 @@ __device__ __forceinline__ void bn_update_running(const BNRef& bn, int c) {
     if (c == 0 && bn.nbt) *bn.nbt += 1;
 }
 
+// Branch-free access to a BatchNorm's constants for kernel prologues.  bn_scale_shift / bn_mean_rstd select between
+// running and batch statistics (and test gamma / beta for null) with BRANCHES; hipcc then waits for every load in
+// flight at each join and requests the next operand only afterwards -- a prologue with two BatchNorms became 4-10
+// serial round trips behind the tile loads (1.5-2 us each when the statistics were just written by another XCD).
+// bn_raw_load issues all six loads unconditionally (every pointer of a BNRef built by the engine is valid; `c` must be
+// a valid column), bn_raw_pin keeps them from sinking, bn_raw_* turn the values into the constants with selects.
+struct BNRaw { double s, q; float rm, rv, g, b; };
+__device__ __forceinline__ BNRaw bn_raw_load(const BNRef& bn, int c) {
+    BNRaw r;
+    r.s = bn.sum[c]; r.q = bn.sq[c]; r.rm = bn.run_mean[c]; r.rv = bn.run_var[c]; r.g = bn.gamma[c]; r.b = bn.beta[c];
+    return r;
+}
+__device__ __forceinline__ void bn_raw_pin(BNRaw& r) {
+    asm volatile("" : "+v"(r.s), "+v"(r.q), "+v"(r.rm), "+v"(r.rv), "+v"(r.g), "+v"(r.b));
+}
+__device__ __forceinline__ void bn_raw_mean_rstd(const BNRef& bn, const BNRaw& r, float& mean, float& rstd) {
+    const double m = r.s * (double)bn.inv_n, v = r.q * (double)bn.inv_n - m * m;
+    mean = bn.use_running ? r.rm : (float)m;
+    const float var = bn.use_running ? r.rv : (float)(v > 0.0 ? v : 0.0);
+    rstd = 1.0f / sqrtf(var + bn.eps);
+}
+__device__ __forceinline__ void bn_raw_scale_shift(const BNRef& bn, const BNRaw& r, float& sc, float& sh) {
+    float mean, rstd;
+    bn_raw_mean_rstd(bn, r, mean, rstd);
+    sc = r.g * rstd;
+    sh = r.b - mean * sc;
+}
+// running-statistics update from the raw values (stores only; call under the one-block-per-BatchNorm condition)
+__device__ __forceinline__ void bn_raw_update_running(const BNRef& bn, const BNRaw& r, int c) {
+    const double m = r.s * (double)bn.inv_n;
+    double v = r.q * (double)bn.inv_n - m * m;
+    if (v < 0.0) v = 0.0;
+    bn.run_mean[c] = 0.9f * r.rm + 0.1f * (float)m;
+    bn.run_var[c] = 0.9f * r.rv + 0.1f * (float)(v * (double)bn.unbias);
+    if (c == 0 && bn.nbt) *bn.nbt += 1;
+}
+
 // Optional transform applied to a GEMM operand while it is staged, in STORAGE coordinates
 // (storage row = node / sample index, storage column = feature index):
 //     v' = (rs[row] * v) * sc[col] + sh[col]        (sc, sh from `bn`; rs may be null)

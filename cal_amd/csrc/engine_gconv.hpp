@@ -162,45 +162,58 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
 #pragma unroll
         for (int q = 0; q < 4; ++q) rsv[q] = br.rs[(size_t)(g0 + min((q << 5) + (t >> 3), rows - 1)) * br.rs_stride];
     }
+    // CSR slots, BatchNorm constants, bias, coefficients: all unconditional on clamped indices / substituted pointers
+    // (see BNRaw in engine.hpp: guarded loads here cost four serial round trips behind the tile loads)
     int nv[8], ev[8];
-    if (ne > 0) {
+    const int slot_hi = max(g.nnz - 1, 0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int s = e0 + min(t + u * 256, ne - 1);
-            nv[u] = g.nbr[s];
-            ev[u] = hasw ? g.eid[s] : 0;
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { nv[u] = g0; ev[u] = 0; }
+    for (int u = 0; u < 8; ++u) {
+        const int s = min(e0 + max(min(t + u * 256, ne - 1), 0), slot_hi);
+        nv[u] = g.nbr[s];
+        ev[u] = g.eid[s];
     }
     const int lane = t & 63, li = lane & 31, lk = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ct = w & 1, r0 = w >> 1;
-    const float bias = br.bias ? br.bias[n0 + ct * 32 + li] : 0.f;
-    if (t < K) {
-        bn_scale_shift(br.bn, t, sc_s[t], sh_s[t]);
-        if (br.bn.update && blockIdx.x == 0 && blockIdx.y == 0) bn_update_running(br.bn, t);
-    }
+    const float* biasp = br.bias ? br.bias : br.W;       // W: any valid [>= H] float array; the value is masked below
+    float bias = biasp[n0 + ct * 32 + li];
+    BNRaw braw = bn_raw_load(br.bn, min(t, K - 1));
+    const float* coefp = br.coef_in ? br.coef_in : br.dis;
+    const int coef_hi = br.coef_in ? slot_hi : 0;
     float cin[8];                                        // coefficients of an earlier kernel of this step, if any
 #pragma unroll
-    for (int u = 0; u < 8; ++u) cin[u] = br.coef_in ? br.coef_in[e0 + max(min(t + u * 256, ne - 1), 0)] : 0.f;
+    for (int u = 0; u < 8; ++u) cin[u] = coefp[min(e0 + max(min(t + u * 256, ne - 1), 0), coef_hi)];
     // all of the above stay in flight together: without the pins hipcc pairs every W load with its LDS store
     // ("load, s_waitcnt vmcnt(0), ds_write" x 8: eight serial round trips, 5-30 us under 256-way contention)
 #pragma unroll
     for (int u = 0; u < UA; ++u) ro_pin(va[u]);
 #pragma unroll
     for (int u = 0; u < 8; ++u) ro_pin(vb[u]);
+    bn_raw_pin(braw);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]), "+v"(cin[u]));
+    asm volatile("" : "+v"(bias));
+    if (!br.bias) bias = 0.f;
+    if (ne <= 0) {                                       // no slot of this graph exists: what the clamped loads fetched is not an index
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { nv[u] = g0; ev[u] = 0; }
+    }
+    if (t < K) {
+        bn_raw_scale_shift(br.bn, braw, sc_s[t], sh_s[t]);
+        if (br.bn.update && blockIdx.x == 0 && blockIdx.y == 0) bn_raw_update_running(br.bn, braw, t);
+    }
     // second round: edge coefficients dis_j * w_e (needs the neighbour / edge ids)
     float cv[8], wv[8];
     if (br.coef_in) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) { cv[u] = cin[u]; wv[u] = 1.f; }
     } else {
+        const float* ewp = hasw ? br.ew : br.dis;        // (masked when there are no edge weights)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const float c = br.dis[nv[u]];
-            wv[u] = hasw ? br.ew[ev[u]] : 1.f;
+            const float wl = ewp[hasw ? ev[u] : 0];
+            wv[u] = hasw ? wl : 1.f;
             cv[u] = c * wv[u];
         }
     }

@@ -129,6 +129,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     const GconvBwdBranch& br = blockIdx.z ? b1 : b0;
     const int b = blockIdx.x, sl = blockIdx.y, ns0 = sl * GC_N, t = threadIdx.x;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
+    const int pb = (MODE == 2 && br.iperm) ? br.iperm[b] : b;         // row of the second pooled-gradient partial (scalar load, with the extents)
     const int lane = t & 63, li = lane & 31, lk = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     double* parts = br.dot_parts + ((size_t)sl * gridDim.x + b) * (2 * K);
@@ -147,13 +148,14 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     RoBatch<float4, 2> bd, bd1, by;                      // dOut[g0 + j][ns0 + 4 n4 ..]: rows x 16 float4 (UP: dy0, dy1, y)
     RoBatch<float4, 4> bx, bw;                           // x[g0 + i][4 k4 ..]: rows x K/4;  W[k_in][ns0 + 4 n4 ..]: K x 16
     RoBatch<float4, 2> bz;                               // POOL: z[g0 + j][ns0 + 4 n4 ..]
-    float gv = 0.f;
+    float gv = 0.f, gv1 = 0.f;
     if (POOL) {
         ro_issue<GB_NT>(by, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(br.y + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
         ro_issue<GB_NT>(bz, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(br.z + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
-        if (t < GC_N) {
-            gv = br.gp0[(size_t)b * H + ns0 + t];
-            if (br.gp1) gv += br.gp1[(size_t)(br.iperm ? br.iperm[b] : b) * H + ns0 + t];
+        {   // gradient of this graph's pooled row, slice columns: both partials unconditionally (gp1 absent: gp0 twice, weight 0)
+            const float* gp1 = br.gp1 ? br.gp1 : br.gp0;
+            gv = br.gp0[(size_t)b * H + ns0 + (t & (GC_N - 1))];
+            gv1 = gp1[(size_t)pb * H + ns0 + (t & (GC_N - 1))];
         }
     } else {
         const float* d0 = UP ? br.dy0 : br.dout;
@@ -170,31 +172,48 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     const int pn = g.ptr[g0 + min(t + 1, rows)];
     const float dv = br.dis[g0 + min(t, rows - 1)];
     const float rv = RS ? br.rs[(size_t)(g0 + min(t, rows - 1)) * br.rs_stride] : 1.f;
+    // CSR slots, coefficients and the BatchNorm constants: unconditional loads on clamped indices / substituted pointers,
+    // pinned below (BNRaw in engine.hpp: as guarded blocks these were up to ten serial round trips behind the tile loads)
     int nv[2], ev[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int s = e0 + max(min(t + u * GB_NT, ne - 1), 0);
-        nv[u] = ne > 0 ? g.nbr[s] : g0;
-        ev[u] = (ne > 0 && hasw) ? g.eid[s] : 0;
-    }
+    const int slot_hi = max(g.nnz - 1, 0);
+    const float* coefp = br.coef_in ? br.coef_in : br.dis;
+    const int coef_hi = br.coef_in ? slot_hi : 0;
     float cin[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) cin[u] = br.coef_in ? br.coef_in[e0 + max(min(t + u * GB_NT, ne - 1), 0)] : 0.f;
-    if (UP && t >= 256 && t < 256 + GC_N) {              // upper BatchNorm constants of this slice's 64 columns
-        const int c = ns0 + t - 256;
-        float m1[1], r1[1];
-        bn_mean_rstd_v<1>(br.ubn, c, m1, r1);
-        um_s[t - 256] = m1[0]; ur_s[t - 256] = r1[0];
-        ug_s[t - 256] = (br.ubn.gamma ? br.ubn.gamma[c] : 1.f) * r1[0];
-        u1_s[t - 256] = (float)(br.udot_sum[c] * (double)br.ubn.inv_n);
-        u2_s[t - 256] = (float)(br.udot_prod[c] * (double)br.ubn.inv_n);
+    for (int u = 0; u < 2; ++u) {
+        const int s = min(e0 + max(min(t + u * GB_NT, ne - 1), 0), slot_hi);
+        nv[u] = g.nbr[s];
+        ev[u] = g.eid[s];
+        cin[u] = coefp[min(s, coef_hi)];
+    }
+    BNRaw braw = bn_raw_load(br.bn, min(t, K - 1));
+    BNRaw uraw;
+    double ud1 = 0.0, ud2 = 0.0;
+    if (UP) {                                            // upper BatchNorm constants of this slice's 64 columns
+        const int c = ns0 + (t & (GC_N - 1));
+        uraw = bn_raw_load(br.ubn, c);
+        ud1 = br.udot_sum[c]; ud2 = br.udot_prod[c];
+    }
+    bn_raw_pin(braw);
+    if (UP) { bn_raw_pin(uraw); asm volatile("" : "+v"(ud1), "+v"(ud2)); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]), "+v"(cin[u]));
+    if (POOL) { asm volatile("" : "+v"(gv), "+v"(gv1)); gv += br.gp1 ? gv1 : 0.f; }
+    if (ne <= 0) { nv[0] = g0; nv[1] = g0; ev[0] = 0; ev[1] = 0; }   // no slot of this graph exists: the clamped loads fetched no index
+    if (UP && t >= 256 && t < 256 + GC_N) {
+        float m1, r1;
+        bn_raw_mean_rstd(br.ubn, uraw, m1, r1);
+        um_s[t - 256] = m1; ur_s[t - 256] = r1;
+        ug_s[t - 256] = uraw.g * r1;
+        u1_s[t - 256] = (float)(ud1 * (double)br.ubn.inv_n);
+        u2_s[t - 256] = (float)(ud2 * (double)br.ubn.inv_n);
     }
     if (t < K) {
-        float m1[1], r1[1];
-        bn_mean_rstd_v<1>(br.bn, t, m1, r1);
-        mean_s[t] = m1[0]; rstd_s[t] = r1[0];
-        gam_s[t] = br.bn.gamma ? br.bn.gamma[t] : 1.f;
-        bet_s[t] = br.bn.beta ? br.bn.beta[t] : 0.f;
+        float m1, r1;
+        bn_raw_mean_rstd(br.bn, braw, m1, r1);
+        mean_s[t] = m1; rstd_s[t] = r1;
+        gam_s[t] = braw.g;
+        bet_s[t] = braw.b;
     }
     for (int i = t; i < (rowsP * GB_LDJ + 3) / 4; i += GB_NT) reinterpret_cast<float4*>(Ab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     float cv[2];
@@ -202,11 +221,12 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
 #pragma unroll
         for (int u = 0; u < 2; ++u) cv[u] = cin[u];
     } else {
+        const float* ewp = hasw ? br.ew : br.dis;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            float c = br.dis[nv[u]];
-            if (hasw) c *= br.ew[ev[u]];
-            cv[u] = c;
+            const float c = br.dis[nv[u]];
+            const float wl = ewp[hasw ? ev[u] : 0];
+            cv[u] = hasw ? c * wl : c;
         }
     }
     // ---- stage everything in LDS -----------------------------------------------------------------------------------
