@@ -14,6 +14,7 @@
 #include "common.hpp"
 #include "gat_common.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace cal {
 
@@ -25,6 +26,26 @@ __device__ __forceinline__ int xcd_block() {
 }
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
+constexpr float GAT_LOG2E = 1.4426950408889634f;      // softmax weights as base-2 exponentials (v_exp_f32) of log2(e)-scaled logits
+
+// sum over the 16 lanes of a DPP row (every lane gets the total): four v_add_f32 with row_ror modifiers instead of four
+// ds_bpermute round trips -- a head of 64 columns is exactly one row of 16 lanes x 4 columns
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+template <int LH>
+__device__ __forceinline__ float head_sum(float v) {
+    if constexpr (LH == 16) return row16_sum(v);
+    else {
+#pragma unroll
+        for (int o = LH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+}
 
 // thread per (node, head)
 __global__ void k_gat_scores(const float* __restrict__ z, const float* __restrict__ att,
@@ -134,6 +155,92 @@ __global__ void __launch_bounds__(256) k_gat_fwd(const int* __restrict__ rowptr,
     }
 }
 
+// Single-pass forward with the attention scores fused (vectorised layout: a head's D/4 lanes sit side by side in the row
+// group).  k_gat_scores + k_gat_fwd cost the latency of five dependent load rounds per destination row
+// (rowptr -> nbr -> a_src (max pass) -> nbr again -> a_src + z rows) with every wave holding one row: 241 + 33 us per layer at
+// config 5 = 17 % of the HBM roofline.  Here a row costs three rounds (rowptr | nbr, eid, own z row | neighbour z rows):
+//   * a_src[j,k] is recomputed from the z row of j that the aggregation fetches anyway (a dot with att[k,D:] and log2(D/4)
+//     shuffles), a_dst[i,k] / a_src[i,k] of the row's own node come from its own z row and are STORED for the backward,
+//     so the separate scores kernel (a full extra read of z) and the a_src gather are gone;
+//   * the edge softmax is computed online (running max m, accumulator and denominator rescaled by exp(m - m')): no max pass;
+//     the final m and the denominator are what the two-pass version stored;
+//   * neighbours go eight at a time (hub rows of the BA graphs: 150 slots were 38 dependent batches of four).
+template <int VEC, int G, int LH>
+__global__ void __launch_bounds__(256) k_gat_fwd_fused(const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                       const int* __restrict__ eid, const float* __restrict__ z,
+                                                       const float* __restrict__ att, const float* __restrict__ bias, int relu,
+                                                       float slope, float p, uint64_t seed, int64_t E, float* __restrict__ out,
+                                                       float* __restrict__ adst, float* __restrict__ asrc,
+                                                       float* __restrict__ mx, float* __restrict__ den, int N, int K,
+                                                       const uint64_t* __restrict__ ctr) {
+    constexpr int RPB = 256 / G, NB = 4, D = LH * VEC;
+    seed = step_seed(seed, ctr);
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    const int i = xcd_block() * RPB + g;
+    if (i >= N) return;
+    const int H = K * D;
+    const int s0 = rowptr[i], s1 = rowptr[i + 1];
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+    using V = Vec<VEC>;
+    for (int c = l * VEC; c < H; c += G * VEC) {
+        const int k = c / D, d = c % D, hl = (threadIdx.x & 63) & ~(LH - 1);      // first lane of this head in the wave
+        const V att_d = V::ld(att + (size_t)k * 2 * D + d), att_s = V::ld(att + (size_t)k * 2 * D + D + d);
+        const V zi = V::ld(z + (size_t)i * H + c);
+        const float ad = head_sum<LH>(zi.dot(att_d)), as_i = head_sum<LH>(zi.dot(att_s));
+        if (d == 0) { adst[(size_t)i * K + k] = ad; asrc[(size_t)i * K + k] = as_i; }
+        // the node's own loop starts the running softmax (base-2 exponentials of log2(e)-scaled logits)
+        float m = lrelu(ad + as_i, slope) * LOG2E, lsum = 1.f;
+        V acc = zi;
+        acc.scale(keep_scale(seed, E + i, k, K, p, inv_keep));
+        for (int s = s0; s < s1; s += NB) {
+            int j[NB], id[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) { const int sq = min(s + q, s1 - 1); j[q] = nbr[sq]; id[q] = eid[sq]; }
+            V zv[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) zv[q] = V::ld(z + (size_t)j[q] * H + c);
+            // dropout keep factors: lane (d / VEC) % NB of a head hashes slot q = that index, the others read it by shuffle --
+            // one hash per batch instead of one per slot (every lane of a wave executes every hash)
+            float kq[NB];
+            if (p > 0.f) {
+                const int myq = (d / VEC) % NB;
+                const int myid = myq == 0 ? id[0] : (myq == 1 ? id[1] : (myq == 2 ? id[2] : id[3]));
+                const float mine = keep_scale(seed, myid, k, K, p, inv_keep);
+#pragma unroll
+                for (int q = 0; q < NB; ++q) kq[q] = LH >= NB ? __shfl(mine, hl + q, 64) : keep_scale(seed, id[q], k, K, p, inv_keep);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) kq[q] = 1.f;
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) zv[q].pin();
+            float e[NB], mn = m;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                e[q] = lrelu(ad + head_sum<LH>(zv[q].dot(att_s)), slope) * LOG2E;
+                if (s + q < s1) mn = fmaxf(mn, e[q]);
+            }
+            const float sc = exp2f(m - mn);                 // one rescale per batch
+            lsum *= sc;
+            acc.scale(sc);
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const float pe = s + q < s1 ? exp2f(e[q] - mn) : 0.f;
+                lsum += pe;
+                acc.fma(pe * kq[q], zv[q]);
+            }
+            m = mn;
+        }
+        const float dn = lsum + 1e-16f;
+        acc.scale(1.f / dn);
+        if (bias) acc.add(V::ld(bias + c));
+        if (relu) acc.relu();
+        acc.st(out + (size_t)i * H + c);
+        if (d == 0) { mx[(size_t)i * K + k] = m * (1.f / LOG2E); den[(size_t)i * K + k] = dn; }
+    }
+}
+
 // Backward pass 1+2 over the by-destination CSR.  Lanes of one head (LH = D/VEC of them, a power
 // of two) reduce their partial dots with shuffles.  draw[id*K + k] (id = edge id, or E + i for the
 // loop of node i) receives d(raw logit); dadst[i,k] the row sum.
@@ -182,7 +289,8 @@ __global__ void __launch_bounds__(256) k_gat_bwd_dst(const int* __restrict__ row
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float dot = gi.dot(zv[q]);
-                for (int o = LH / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+                if (LH == 16) dot = row16_sum(dot);
+                else for (int o = LH / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
                 const float alpha = expf(lrelu(ad + as[q], slope) - m) / dn;
                 const float dalpha = dot * keep_scale(seed, id[q], k, K, p, inv_keep);
                 if (s + q <= s1) {
@@ -211,6 +319,159 @@ __global__ void __launch_bounds__(256) k_gat_bwd_dst(const int* __restrict__ row
                 const float dalpha = __shfl(da[q], (threadIdx.x & 63) & ~(LH - 1), 64);
                 const float de = alpha * (dalpha - S);
                 const float dr = de * (raw > 0.f ? 1.f : slope);
+                if (s + q <= s1) {
+                    rowsum += dr;
+                    if (head_lead) draw[id[q] * K + k] = dr;
+                }
+            }
+        }
+        if (head_lead) dadst[(size_t)i * K + k] = rowsum;
+    }
+}
+
+// The same with the first NC slots of a row kept in registers between the two passes.  The softmax backward needs
+// S = sum_s alpha_s dalpha_s over the whole row before any d(raw logit) can be formed, so k_gat_bwd_dst walks the row twice
+// and parks dalpha in `draw` in between: rowptr -> nbr/eid -> z rows + a_src -> (write dalpha) -> nbr/eid -> a_src + dalpha
+// read-back -> write: six dependent rounds per row, 459 us per layer at config 5 (12 % of the HBM roofline with the
+// source-side kernel).  BA(m = 2) rows have ~5 slots: with (raw logit, dalpha, slot id) of the first NC = 8 slots held in
+// registers a typical row is rowptr -> nbr/eid -> z rows + a_src -> write, and only a hub's slots beyond the eighth take the
+// read-back path.
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_gat_bwd_dst_c(const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                       const int* __restrict__ eid, const float* __restrict__ z,
+                                                       const float* __restrict__ adst, const float* __restrict__ asrc,
+                                                       const float* __restrict__ mx, const float* __restrict__ den,
+                                                       const float* __restrict__ gout, float slope, float p,
+                                                       uint64_t seed, int64_t E, float* __restrict__ draw,
+                                                       float* __restrict__ dadst, int N, int K, int D,
+                                                       const uint64_t* __restrict__ ctr) {
+    constexpr int RPB = 256 / G, NC = 8;
+    seed = step_seed(seed, ctr);
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    const int i = xcd_block() * RPB + g;
+    if (i >= N) return;
+    const int H = K * D;
+    const int LH = D / VEC;
+    const int s0 = rowptr[i], s1 = rowptr[i + 1];          // slots s0 .. s1 - 1 are edges, "slot" s1 is the node's own loop
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    using V = Vec<VEC>;
+    for (int c = l * VEC; c < H; c += G * VEC) {
+        const int k = c / D;
+        const bool head_lead = (c % D) == 0;
+        const float ad = adst[(size_t)i * K + k];
+        const float m = mx[(size_t)i * K + k], dn = den[(size_t)i * K + k];
+        const V gi = V::ld(gout + (size_t)i * H + c);
+        const float rdn = 1.f / dn;
+        // ---- cached slots: s0 .. s0 + NC - 1 (clamped to the loop slot s1), gathered in two halves of four (registers) -------
+        int cid[NC];                                           // slot id (edge id, or E + i for the loop): < 2^31
+        float craw[NC], cda[NC], cal[NC];
+        float S = 0.f;
+        {
+            int j[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int sq = min(s0 + q, s1);
+                const int se = max(min(min(sq, s1 - 1), (int)E - 1), 0);   // a valid slot to read, unconditionally (masked for the loop)
+                const int jn = nbr[se], en = eid[se];
+                j[q] = sq < s1 ? jn : i;
+                cid[q] = sq < s1 ? en : (int)E + i;
+            }
+            float as[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) as[q] = asrc[(size_t)j[q] * K + k];
+            // dropout keep factors: lane q of a head hashes cached slot q, the others read it by shuffle (one hash per row
+            // instead of eight: every lane of a wave executes every hash)
+            float ckeep[NC];
+            if (p > 0.f && LH >= NC) {
+                const int myq = (c % D) / VEC % NC;
+                int myid = cid[0];
+#pragma unroll
+                for (int q = 1; q < NC; ++q) myid = myq == q ? cid[q] : myid;
+                const float mine = keep_scale(seed, myid, k, K, p, inv_keep);
+                const int hl = (threadIdx.x & 63) & ~(LH - 1);
+#pragma unroll
+                for (int q = 0; q < NC; ++q) ckeep[q] = __shfl(mine, hl + q, 64);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NC; ++q) ckeep[q] = keep_scale(seed, cid[q], k, K, p, inv_keep);
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < NC; h2 += 4) {
+                if (h2 > 0 && s0 + h2 > s1) break;             // the second half holds no slot of this row
+                V zv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zv[q] = V::ld(z + (size_t)j[h2 + q] * H + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zv[q].pin();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float dot = gi.dot(zv[q]);
+                    if (LH == 16) dot = row16_sum(dot);
+                    else for (int o = LH / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+                    craw[h2 + q] = ad + as[h2 + q];
+                    cda[h2 + q] = dot * ckeep[h2 + q];
+                    cal[h2 + q] = exp2f((lrelu(craw[h2 + q], slope) - m) * GAT_LOG2E) * rdn;
+                    if (s0 + h2 + q <= s1) S = fmaf(cal[h2 + q], cda[h2 + q], S);
+                }
+            }
+        }
+        // ---- slots beyond the cache (hub rows): dalpha parked in `draw`, as in k_gat_bwd_dst -------------------------------
+        for (int s = s0 + NC; s <= s1; s += 4) {
+            int j[4];
+            int64_t id[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sq = min(s + q, s1);
+                j[q] = sq < s1 ? nbr[min(sq, max(s1 - 1, 0))] : i;
+                id[q] = sq < s1 ? (int64_t)eid[min(sq, max(s1 - 1, 0))] : E + i;
+            }
+            V zv[4];
+            float as[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { zv[q] = V::ld(z + (size_t)j[q] * H + c); as[q] = asrc[(size_t)j[q] * K + k]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) zv[q].pin();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float dot = gi.dot(zv[q]);
+                if (LH == 16) dot = row16_sum(dot);
+                else for (int o = LH / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+                const float alpha = exp2f((lrelu(ad + as[q], slope) - m) * GAT_LOG2E) * rdn;
+                const float dalpha = dot * keep_scale(seed, id[q], k, K, p, inv_keep);
+                if (s + q <= s1) {
+                    S = fmaf(alpha, dalpha, S);
+                    if (head_lead) draw[id[q] * K + k] = dalpha;
+                }
+            }
+        }
+        // ---- d(raw logit) = alpha (dalpha - S) lrelu'(raw) ------------------------------------------------------------------
+        float rowsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            if (s0 + q <= s1) {
+                const float dr = cal[q] * (cda[q] - S) * (craw[q] > 0.f ? 1.f : slope);
+                rowsum += dr;
+                if (head_lead) draw[(int64_t)cid[q] * K + k] = dr;
+            }
+        }
+        for (int s = s0 + NC; s <= s1; s += 4) {
+            int j[4];
+            int64_t id[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int sq = min(s + q, s1);
+                j[q] = sq < s1 ? nbr[min(sq, max(s1 - 1, 0))] : i;
+                id[q] = sq < s1 ? (int64_t)eid[min(sq, max(s1 - 1, 0))] : E + i;
+            }
+            float as[4], da[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { as[q] = asrc[(size_t)j[q] * K + k]; da[q] = draw[id[q] * K + k]; }   // written by this head's lead lane above
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float raw = ad + as[q];
+                const float alpha = exp2f((lrelu(raw, slope) - m) * GAT_LOG2E) * rdn;
+                const float dalpha = __shfl(da[q], (threadIdx.x & 63) & ~(LH - 1), 64);
+                const float dr = alpha * (dalpha - S) * (raw > 0.f ? 1.f : slope);
                 if (s + q <= s1) {
                     rowsum += dr;
                     if (head_lead) draw[id[q] * K + k] = dr;
@@ -268,7 +529,7 @@ __global__ void __launch_bounds__(256) k_gat_bwd_src(const int* __restrict__ row
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool ok = s + q <= s1;
-                const float alpha = expf(lrelu(ad4[q] + as, slope) - mx4[q]) / dn4[q];
+                const float alpha = exp2f((lrelu(ad4[q] + as, slope) - mx4[q]) * GAT_LOG2E) / dn4[q];
                 acc.fma(ok ? alpha * keep_scale(seed, id[q], k, K, p, inv_keep) : 0.f, gv[q]);
                 das += ok ? dr4[q] : 0.f;
             }
@@ -341,6 +602,29 @@ static inline int gat_rows_per_block(int64_t N) {
 // p > 0 applies attention dropout with the counter-based mask of `seed` (cal_gat_dropout_mask
 // materialises the same mask for tests).
 namespace cal {
+template <int G, int LH>
+static void gat_fused_one(hipStream_t stream, const int32_t* rowptr, const int32_t* nbr, const int32_t* eid, const float* z, const float* att,
+                          const float* bias, int relu, float slope, float p, uint64_t seed, int64_t E, float* out, float* adst,
+                          float* asrc, float* mx, float* den, int N, int K, const uint64_t* ctr) {
+    if constexpr (LH <= G)
+        hipLaunchKernelGGL((k_gat_fwd_fused<4, G, LH>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr, nbr, eid, z, att, bias, relu,
+                           slope, p, seed, E, out, adst, asrc, mx, den, N, K, ctr);
+}
+template <int G, class... A>
+static void gat_fused_launch(int lh, hipStream_t stream, A... a) {
+    switch (lh) {
+        case 1: gat_fused_one<G, 1>(stream, a...); break;
+        case 2: gat_fused_one<G, 2>(stream, a...); break;
+        case 4: gat_fused_one<G, 4>(stream, a...); break;
+        case 8: gat_fused_one<G, 8>(stream, a...); break;
+        case 16: gat_fused_one<G, 16>(stream, a...); break;
+        case 32: gat_fused_one<G, 32>(stream, a...); break;
+        default: gat_fused_one<G, 64>(stream, a...); break;
+    }
+}
+}  // namespace cal
+
+namespace cal {
 int gat_forward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst, const float* z,
                 const float* att, const float* bias, int relu, float slope, float p, uint64_t seed, const uint64_t* ctr,
                 float* out, float* adst, float* asrc, float* mx, float* den, int64_t N, int64_t E,
@@ -350,6 +634,17 @@ int gat_forward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t
     CAL_REQUIRE(p >= 0.f && p < 1.f, "dropout p must be in [0,1)");
     int64_t H = K * D;
     bool vec_ok = (D % 4 == 0) && aligned16(z) && aligned16(out) && (!bias || aligned16(bias));
+    if (vec_ok && pow2(D / 4) && aligned16(att) && D / 4 <= 64) {
+        // scores + online edge softmax + aggregation in one pass (a head's lanes sit inside one row group)
+        CAL_DISPATCH_VG((int)H, true, {
+            if (G >= D / 4) {
+                gat_fused_launch<G>((int)D / 4, stream, rowptr_dst, nbr_dst, eid_dst, z, att, bias, relu, slope, p, seed, E, out, adst, asrc,
+                                    mx, den, (int)N, (int)K, ctr);
+                CAL_CHECK_LAUNCH("k_gat_fwd_fused");
+                return 0;
+            }
+        });
+    }
     if (vec_ok && pow2(D / 4) && aligned16(att) && D / 4 <= 64) {
         const int G = std::max(group_for((int)H, 4), (int)(D / 4));      // a head's lanes must sit inside one row group
         const int blocks = (int)std::min<int64_t>(cdiv(N, 256 / G), 4096);
@@ -405,7 +700,7 @@ int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_
         bool vec_ok = (D % 4 == 0) && pow2(D / 4) && aligned16(z) && aligned16(gout) && aligned16(dz) && aligned16(att);
         CAL_REQUIRE(vec_ok || pow2(D), "head dim must be a power of two (or 4 * a power of two)");
         CAL_DISPATCH_VG((int)H, vec_ok, {
-            hipLaunchKernelGGL((k_gat_bwd_dst<VEC, G>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr_dst, nbr_dst,
+            hipLaunchKernelGGL((k_gat_bwd_dst_c<VEC, G>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr_dst, nbr_dst,
                                eid_dst, z, adst, asrc, mx, den, gout, slope, p, seed, E, draw, dadst, (int)N, (int)K, (int)D, ctr);
         });
         CAL_CHECK_LAUNCH("k_gat_bwd_dst");
