@@ -116,6 +116,8 @@ struct BNSlot { int gamma, beta; int width; float* rm; float* rv; int64_t* nbt; 
 
 struct Engine {
     int F, H, C, L;
+    int cat;                    // cat_or_add == "cat": the co readout takes cat(xc[perm], xo) [B, 2H] (model.py:65-69,153-154)
+    int no_node_att, no_edge_att;   // without_node_attention / without_edge_attention: constant 0.5 masks (model.py:99-107)
     float loop_w;
     // bound buffers
     float *P, *G, *M1, *M2, *step, *lr;
@@ -249,7 +251,7 @@ CAL_EXPORT int cal_engine_bind(void* h, float* P, float* G, float* M1, float* M2
     e->o_cw = (int)offs[s++]; e->o_cb = (int)offs[s++];
     e->o_ow = (int)offs[s++]; e->o_ob = (int)offs[s++];
     for (int hd = 0; hd < 3; ++hd) {
-        bn_g[k] = (int)offs[s++]; bn_b[k] = (int)offs[s++]; bn_w[k] = H; ++k;
+        bn_g[k] = (int)offs[s++]; bn_b[k] = (int)offs[s++]; bn_w[k] = (hd == 2 && e->cat) ? 2 * H : H; ++k;
         e->o_fc1_w[hd] = (int)offs[s++]; e->o_fc1_b[hd] = (int)offs[s++];
         bn_g[k] = (int)offs[s++]; bn_b[k] = (int)offs[s++]; bn_w[k] = H; ++k;
         e->o_fc2_w[hd] = (int)offs[s++]; e->o_fc2_b[hd] = (int)offs[s++];
@@ -281,9 +283,9 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     auto I32 = [&](int*& p, size_t n) { if (assign) p = (int*)(e->ws) + off; off += al(n); };
     F32(e->h, (L + 1) * N * H); F32(e->z, N * H); F32(e->zco, 2 * N * H); F32(e->hco, 2 * N * H);
     F32(e->anode, 2 * N); F32(e->pq, 4 * N); F32(e->att, 2 * E); F32(e->dis_unit, N); F32(e->dis_co, 2 * N);
-    F32(e->pooled, 2 * B * H); F32(e->xco, B * H); F32(e->y1, 3 * B * H); F32(e->zl, 3 * B * C); F32(e->logp, 3 * B * C);
+    F32(e->pooled, 2 * B * H); F32(e->xco, 2 * B * H); F32(e->y1, 3 * B * H); F32(e->zl, 3 * B * C); F32(e->logp, 3 * B * C);
     F32(e->stats, 8);
-    F32(e->dzl, 3 * B * C); F32(e->dyh1, 3 * B * H); F32(e->dy1, 3 * B * H); F32(e->dxh, 3 * B * H); F32(e->dpool, 2 * B * H);
+    F32(e->dzl, 3 * B * C); F32(e->dyh1, 3 * B * H); F32(e->dy1, 3 * B * H); F32(e->dxh, 4 * B * H); F32(e->dpool, 2 * B * H);
     F32(e->dZco, 2 * N * H); F32(e->gn, 4 * E); F32(e->gself, 4 * N); F32(e->ddeg, 2 * N); F32(e->dl, E);
     F32(e->dzco, 2 * N * H); F32(e->dXhco, 2 * N * H); F32(e->dZ, N * H); F32(e->dzi, (L > 0 ? L : 1) * N * H); F32(e->dXh, N * H);
     // split-K slabs: worst case per weight gradient (S <= 256, but S*tiles ~ 512 => S*M*N <= ~512*64*64 + M*N)
@@ -294,7 +296,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
         const size_t big = gemm_big_grad((int)M, (int)Nn, (int)N) ? (size_t)gemm_big_grad_splits((int)N) * M * Nn : 0;
         return std::max<size_t>(std::max<size_t>(512 * 64 * 64, (size_t)B * M * Nn), big) + 2 * M * Nn;
     };
-    slab += slab_of(F, H) + (L + 2) * slab_of(H, H) + 3 * slab_of(H, H) + 3 * slab_of(C, H);
+    slab += slab_of(F, H) + (L + 2) * slab_of(H, H) + 2 * slab_of(H, H) + slab_of(H, 2 * H) + 3 * slab_of(C, H);
     if (e->K > 0) slab += L * (size_t)1024 * H;      // GATConv: <= 512 partial rows of d att [2H] per layer
     if (assign) e->slab_floats = slab;
     F32(e->slabs, slab);
@@ -598,6 +600,7 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
 bool use_ro(const Ctx& c) {
     const int B = c.B, H = c.e->H, C = c.e->C;
     const int B4 = (B + 15) & ~15;
+    if (c.e->cat) return false;                     // the 2H-wide co head takes the GEMM path
     return (size_t)B4 * (H + 4) <= (size_t)RO_LDS && B * H <= 16384 && H % RO_CW == 0 && B4 <= 256 && H <= 256 &&
            B * C <= 2048 && C <= 64;
 }
@@ -794,7 +797,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             constexpr int G = decltype(g)::value;
             hipLaunchKernelGGL((k_att_fwd_graph<4, G>), dim3(B), dim3(512), 0, st, e->gptr, gs, x, e->P + e->o_natt_w, e->P + e->o_natt_b,
                                e->P + e->o_eatt_w, e->P + e->o_eatt_b, e->anode, e->pq, e->att, e->dis_co, e->dis_co + N, a0, a1, a2, a3,
-                               e->loop_w, H, E, e->status);
+                               e->loop_w, H, E, e->status, e->no_node_att ? 0.f : 1.f, e->no_edge_att ? 0.f : 1.f);
             return 0;
         }));
         CAL_CHECK_LAUNCH("k_att_fwd_graph"); STAGE();
@@ -807,7 +810,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
             hipLaunchKernelGGL((k_node_att_fwd<4, G>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, x, e->P + e->o_natt_w,
-                               e->P + e->o_natt_b, e->P + e->o_eatt_w, e->anode, e->pq, a0, a1, a2, a3, N, H, c.rpb_n);
+                               e->P + e->o_natt_b, e->P + e->o_eatt_w, e->anode, e->pq, a0, a1, a2, a3, N, H, c.rpb_n, e->no_node_att ? 0.f : 1.f);
             return 0;
         }));
         CAL_CHECK_LAUNCH("k_node_att_fwd"); STAGE();
@@ -816,7 +819,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     // 6. edge softmax + weighted degrees (model.py:102-104, gcn_conv.py:63-68)
     if (!att_graph) {
         hipLaunchKernelGGL(k_edge_att_deg, dim3(cdiv(N, 32)), dim3(256), 0, st, gs, e->pq, e->P + e->o_eatt_b, e->att, e->dis_co,
-                           e->dis_co + N, e->loop_w, N, E);
+                           e->dis_co + N, e->loop_w, N, E, e->no_edge_att ? 0.f : 1.f);
         CAL_CHECK_LAUNCH("k_edge_att_deg"); STAGE();
     }
     // 7-9 fused: both weighted convolutions and the add-pool in one per-graph launch
@@ -890,19 +893,26 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         int tc = std::min(256, pow2ceil(H));
         hipLaunchKernelGGL(k_readout_prep, dim3(cdiv(B, c.rpb_b)), dim3(256), 0, st, e->pooled, perm, e->iperm, e->xco, B, H, tc,
                            c.rpb_b, bn_stsum(c, bn_fc1), bn_stsq(c, bn_fc1), bn_stsum(c, bn_fc1 + 2), bn_stsq(c, bn_fc1 + 2),
-                           bn_stsum(c, bn_fc1 + 4), bn_stsq(c, bn_fc1 + 4));
+                           bn_stsum(c, bn_fc1 + 4), bn_stsq(c, bn_fc1 + 4), e->cat);
         CAL_CHECK_LAUNCH("k_readout_prep"); STAGE();
     }
     const float* xin[3] = {e->pooled, e->pooled + (size_t)B * H, e->xco};
+    const int Wco = e->cat ? 2 * H : H;                 // input width of the co head
     {
-        GemmArgs a = gemm_args(B, H, H, false, true, 1);
-        for (int hd = 0; hd < 3; ++hd) {
-            a.p[hd].A = xin[hd]; a.p[hd].B = e->P + e->o_fc1_w[hd]; a.p[hd].bias = e->P + e->o_fc1_b[hd];
-            a.p[hd].C = e->y1 + (size_t)hd * B * H;
-            a.p[hd].xa.has_bn = 1; a.p[hd].xa.bn = bnref(c, bn_fc1 + 2 * hd, B, 1);
-            if (c.training) gemm_stats(c, a.p[hd], B, H, bn_stsum(c, bn_fc2 + 2 * hd), bn_stsq(c, bn_fc2 + 2 * hd), false);
-        }
-        RC(fwd_gemm(c, true, a, 3)); STAGE();
+        // fc1 of the three heads: one batched launch, or (cat: the co head reduces over 2H) heads c / o batched + co alone
+        auto fc1 = [&](int hd0, int nh, int Kin) -> int {
+            GemmArgs a = gemm_args(B, H, Kin, false, true, 1);
+            for (int q = 0; q < nh; ++q) {
+                const int hd = hd0 + q;
+                a.p[q].A = xin[hd]; a.p[q].B = e->P + e->o_fc1_w[hd]; a.p[q].bias = e->P + e->o_fc1_b[hd];
+                a.p[q].C = e->y1 + (size_t)hd * B * H;
+                a.p[q].xa.has_bn = 1; a.p[q].xa.bn = bnref(c, bn_fc1 + 2 * hd, B, 1);
+                if (c.training) gemm_stats(c, a.p[q], B, H, bn_stsum(c, bn_fc2 + 2 * hd), bn_stsq(c, bn_fc2 + 2 * hd), false);
+            }
+            return fwd_gemm(c, true, a, nh);
+        };
+        if (e->cat) { RC(fc1(0, 2, H)); STAGE(); RC(fc1(2, 1, Wco)); STAGE(); }
+        else { RC(fc1(0, 3, H)); STAGE(); }
         RC(flush_finals(c)); STAGE();
     }
     {
@@ -997,34 +1007,46 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         }));
         CAL_CHECK_LAUNCH("k_bn_bwd(readout)"); STAGE();
     }
+    const int Wco = e->cat ? 2 * H : H;                 // input width of the co head (cat: [xc[perm] | xo])
+    float* const dxh_hd[3] = {e->dxh, e->dxh + BH, e->dxh + 2 * BH};
     // R4. dW1_h = dy1_h^T @ BN1(xin_h)
     if (!ro) {
-        GemmArgs a = gemm_args(H, H, B, true, false, 0);
-        float* dst[3];
-        for (int hd = 0; hd < 3; ++hd) {
-            a.p[hd].A = e->dy1 + hd * BH; a.p[hd].B = xin[hd];
-            a.p[hd].xb.has_bn = 1; a.p[hd].xb.bn = bnref(c, bn_fc1 + 2 * hd, B, 0);
-            dst[hd] = e->G + e->o_fc1_w[hd];
-        }
-        RC(grad_gemm(c, a, 3, dst, fa, slab_off)); STAGE();
+        auto r4 = [&](int hd0, int nh, int Kin) -> int {
+            GemmArgs a = gemm_args(H, Kin, B, true, false, 0);
+            float* dst[3];
+            for (int q = 0; q < nh; ++q) {
+                const int hd = hd0 + q;
+                a.p[q].A = e->dy1 + hd * BH; a.p[q].B = xin[hd];
+                a.p[q].xb.has_bn = 1; a.p[q].xb.bn = bnref(c, bn_fc1 + 2 * hd, B, 0);
+                dst[q] = e->G + e->o_fc1_w[hd];
+            }
+            return grad_gemm(c, a, nh, dst, fa, slab_off);
+        };
+        if (e->cat) { RC(r4(0, 2, H)); STAGE(); RC(r4(2, 1, Wco)); STAGE(); }
+        else { RC(r4(0, 3, H)); STAGE(); }
     }
     // R5. d(BN1 out)_h = dy1_h @ W1_h with the BN1-backward sums
     if (!ro) {
-        GemmArgs a = gemm_args(B, H, H, false, false, 0);
-        for (int hd = 0; hd < 3; ++hd) {
-            a.p[hd].A = e->dy1 + hd * BH; a.p[hd].B = e->P + e->o_fc1_w[hd]; a.p[hd].C = e->dxh + hd * BH;
-            a.p[hd].aux = xin[hd]; a.p[hd].has_aux = 1; a.p[hd].aux_bn = bnref(c, bn_fc1 + 2 * hd, B, 0);
-            gemm_stats(c, a.p[hd], B, H, bn_dsum(c, bn_fc1 + 2 * hd), bn_dprod(c, bn_fc1 + 2 * hd), true);
-        }
-        RC(fwd_gemm(c, false, a, 3)); STAGE();
+        auto r5 = [&](int hd0, int nh, int Kin) -> int {
+            GemmArgs a = gemm_args(B, Kin, H, false, false, 0);
+            for (int q = 0; q < nh; ++q) {
+                const int hd = hd0 + q;
+                a.p[q].A = e->dy1 + hd * BH; a.p[q].B = e->P + e->o_fc1_w[hd]; a.p[q].C = dxh_hd[hd];
+                a.p[q].aux = xin[hd]; a.p[q].has_aux = 1; a.p[q].aux_bn = bnref(c, bn_fc1 + 2 * hd, B, 0);
+                gemm_stats(c, a.p[q], B, Kin, bn_dsum(c, bn_fc1 + 2 * hd), bn_dprod(c, bn_fc1 + 2 * hd), true);
+            }
+            return fwd_gemm(c, false, a, nh);
+        };
+        if (e->cat) { RC(r5(0, 2, H)); STAGE(); RC(r5(2, 1, Wco)); STAGE(); }
+        else { RC(r5(0, 3, H)); STAGE(); }
         RC(flush_finals(c)); STAGE();
     }
     // R6. BN1 backward + un-permute the random intervention -> d pooled
     if (!ro) {
         BnIn in[3];
         for (int hd = 0; hd < 3; ++hd)
-            in[hd] = BnIn{e->dxh + hd * BH, xin[hd], bnref(c, bn_fc1 + 2 * hd, B, 0), bn_dsum(c, bn_fc1 + 2 * hd), bn_dprod(c, bn_fc1 + 2 * hd)};
-        hipLaunchKernelGGL(k_readout_bwd_tail, dim3(cdiv((int64_t)BH, 256)), dim3(256), 0, st, in[0], in[1], in[2], e->iperm, e->dpool, B, H);
+            in[hd] = BnIn{dxh_hd[hd], xin[hd], bnref(c, bn_fc1 + 2 * hd, B, 0), bn_dsum(c, bn_fc1 + 2 * hd), bn_dprod(c, bn_fc1 + 2 * hd)};
+        hipLaunchKernelGGL(k_readout_bwd_tail, dim3(cdiv((int64_t)BH, 256)), dim3(256), 0, st, in[0], in[1], in[2], e->iperm, e->dpool, B, H, e->cat);
         CAL_CHECK_LAUNCH("k_readout_bwd_tail"); STAGE();
     }
     const bool gcb = use_gcb(c);
@@ -1052,7 +1074,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         CAL_CHECK_LAUNCH("k_normbwd_node2"); STAGE();
         if (E > 0) {
             hipLaunchKernelGGL(k_normbwd_edge, dim3(cdiv(E, 256)), dim3(256), 0, st, e->row32, e->col32, e->att, e->dis_co, e->gn, e->ddeg,
-                               e->dl, N, E, gn2);
+                               e->dl, N, E, gn2, e->no_edge_att ? 0.f : 1.f);
             CAL_CHECK_LAUNCH("k_normbwd_edge"); STAGE();
         }
         return 0;
@@ -1135,6 +1157,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         aa.bnc = bnref(c, L + 1, N, 0); aa.bno = bnref(c, L + 2, N, 0);
         aa.dsc = bn_dsum(c, L + 1); aa.dpc = bn_dprod(c, L + 1); aa.dso = bn_dsum(c, L + 2); aa.dpo = bn_dprod(c, L + 2);
         aa.Wn = e->P + e->o_natt_w; aa.We = e->P + e->o_eatt_w; aa.dl = e->dl;
+        aa.fnode = e->no_node_att ? 0.f : 1.f; aa.fedge = e->no_edge_att ? 0.f : 1.f;
         aa.gs = gs; aa.gd = gd; aa.dZ = e->dZ;
         if (gcb) {       // per graph: d deg, d edge logits and the row pass in one kernel (engine_attbwd.hpp)
             aa.dbias = L > 0 ? deferred_g(H, d_convb[L - 1]) : Acc();
@@ -1573,6 +1596,15 @@ CAL_EXPORT int cal_engine_adam_ticked(void* h, void* stream_) {
     hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
                        e->beta2, e->eps, e->wd, e->nparam, 1, e->grad_scale);
     CAL_CHECK_LAUNCH("k_adam");
+    return 0;
+}
+// Model variants (opts.py:96-103 / model.py:24-31): cat = the random-intervention readout concatenates xc[perm] and xo
+// (fc1_bn_co and fc1_co are 2H wide) instead of adding them; no_node_att / no_edge_att = the ablation flags (constant 0.5
+// node / edge masks, no gradient into the corresponding attention MLP).  Call before cal_engine_bind.
+CAL_EXPORT int cal_engine_set_options(void* h, int cat, int no_node_att, int no_edge_att) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e != nullptr, "bad arguments");
+    e->cat = cat ? 1 : 0; e->no_node_att = no_node_att ? 1 : 0; e->no_edge_att = no_edge_att ? 1 : 0;
     return 0;
 }
 // Random-intervention permutation drawn by the step itself (mode bit 16; model.py:147-152): keyed by (seed, *counter), the

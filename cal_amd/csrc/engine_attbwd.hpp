@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
                 const int r = d_oth[s], q = d_own[s];
                 const float xc = dgc[u] * dis_c_s[r] * dis_c_s[q] + dd_c_s[r];
                 const float xo = dgo[u] * dis_o_s[r] * dis_o_s[q] + dd_o_s[r];
-                if (r != q) atomicAdd(&Dm[r * AG_LD + q], dwc[u] * dwo[u] * (xc - xo));
+                if (r != q) atomicAdd(&Dm[r * AG_LD + q], a.fedge * dwc[u] * dwo[u] * (xc - xo));
             }
         }
         __syncthreads();
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
                     d1 = fmaf(dxo[j], xv[j], d1);
                 }
                 d0 = group_sum<G>(d0); d1 = group_sum<G>(d1);
-                const float dl0 = a0[u] * a1[u] * (d0 - d1);
+                const float dl0 = a.fnode * a0[u] * a1[u] * (d0 - d1);
                 if (i < rend) {
                     const float spv = spv_s[i], sqv = sqv_s[i];
                     if (l == 0) { sdl += (double)dl0; ssp += (double)spv; }

@@ -267,7 +267,8 @@ __global__ void __launch_bounds__(256) k_node_att_fwd(const float* __restrict__ 
                                                       const float* __restrict__ bn, const float* __restrict__ We,
                                                       float* __restrict__ anode, float* __restrict__ pq,
                                                       const Acc stc_sum, const Acc stc_sq, const Acc sto_sum,
-                                                      const Acc sto_sq, int N, int H, int rows_per_block) {
+                                                      const Acc sto_sq, int N, int H, int rows_per_block, float fnode) {
+    // fnode: 1, or 0 for without_node_attention (model.py:106-107): equal logits -> the constant 0.5 / 0.5 split
     __shared__ double lds[4 * 256 * (VEC == 4 ? 4 : 1)];
     constexpr int RPB = 256 / G;
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(256) k_node_att_fwd(const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int v = rbeg + grp + u * RPB;
-            const float l0 = group_sum<G>(xv[u].dot(w[0])) + b0, l1 = group_sum<G>(xv[u].dot(w[1])) + b1;
+            const float l0 = fnode * (group_sum<G>(xv[u].dot(w[0])) + b0), l1 = fnode * (group_sum<G>(xv[u].dot(w[1])) + b1);
             const float p0 = group_sum<G>(xv[u].dot(w[2])), p1 = group_sum<G>(xv[u].dot(w[3]));
             const float q0 = group_sum<G>(xv[u].dot(w[4])), q1 = group_sum<G>(xv[u].dot(w[5]));
             const float m = fmaxf(l0, l1);
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(256) k_node_att_fwd(const float* __restrict__ 
             q0 += xv.dot(V::ld(We + H + c));
             q1 += xv.dot(V::ld(We + 3 * H + c));
         }
-        l0 = group_sum<G>(l0) + bn[0]; l1 = group_sum<G>(l1) + bn[1];
+        l0 = fnode * (group_sum<G>(l0) + bn[0]); l1 = fnode * (group_sum<G>(l1) + bn[1]);
         p0 = group_sum<G>(p0); p1 = group_sum<G>(p1); q0 = group_sum<G>(q0); q1 = group_sum<G>(q1);
         if (l == 0) {
             float m = fmaxf(l0, l1);
@@ -382,7 +383,8 @@ __global__ void __launch_bounds__(256) k_node_att_fwd(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_edge_att_deg(const CSR gs, const float* __restrict__ pq, const float* __restrict__ be,
                                                       float* __restrict__ att, float* __restrict__ dis_c,
-                                                      float* __restrict__ dis_o, float loop_w, int N, int64_t E) {
+                                                      float* __restrict__ dis_o, float loop_w, int N, int64_t E, float fedge) {
+    // fedge: 1, or 0 for without_edge_attention (model.py:99-100): both edge weights are the constant 0.5
     const int v = blockIdx.x * 32 + threadIdx.x / 8, l = threadIdx.x % 8;
     if (v >= N) return;
     const float4 pv = *reinterpret_cast<const float4*>(pq + 4 * (size_t)v);
@@ -391,7 +393,7 @@ __global__ void __launch_bounds__(256) k_edge_att_deg(const CSR gs, const float*
     for (int s = gs.ptr[v] + l; s < gs.ptr[v + 1]; s += 8) {
         const int d = gs.nbr[s], e = gs.eid[s];
         const float4 qd = *reinterpret_cast<const float4*>(pq + 4 * (size_t)d);
-        const float l0 = pv.x + qd.z + b0, l1 = pv.y + qd.w + b1;
+        const float l0 = fedge * (pv.x + qd.z + b0), l1 = fedge * (pv.y + qd.w + b1);
         const float m = fmaxf(l0, l1);
         const float e0 = expf(l0 - m), e1 = expf(l1 - m);
         const float inv = 1.f / (e0 + e1);
@@ -472,12 +474,15 @@ __global__ void k_pool2_sum(const float* __restrict__ slices, int S, int64_t n, 
 __global__ void __launch_bounds__(256) k_readout_prep(const float* __restrict__ pooled, const int64_t* __restrict__ perm,
                                                       int* __restrict__ iperm, float* __restrict__ xco, int B, int H,
                                                       int tc, int rows_per_block, const Acc s_c, const Acc q_c,
-                                                      const Acc s_o, const Acc q_o, const Acc s_co, const Acc q_co) {
+                                                      const Acc s_o, const Acc q_o, const Acc s_co, const Acc q_co, int cat) {
+    // cat (model.py:153-154): x_co = [xc[perm] | xo], [B, 2H]; its batch statistics are those of xc[perm] (columns < H)
+    // and of xo (columns >= H)
     __shared__ double lds[256];
     const int nrl = 256 / tc, cl = threadIdx.x % tc, rl = threadIdx.x / tc;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(B, r0 + rows_per_block);
     const float* pc = pooled;
     const float* po = pooled + (size_t)B * H;
+    const int W = cat ? 2 * H : H;
     if (cl == 0)
         for (int r = r0 + rl; r < r1; r += nrl) iperm[perm[r]] = r;
     for (int c = cl; c - cl < H; c += tc) {
@@ -487,8 +492,10 @@ __global__ void __launch_bounds__(256) k_readout_prep(const float* __restrict__ 
 #pragma unroll 4
             for (int r = r0 + rl; r < r1; r += nrl) {
                 const float vc = pc[(size_t)r * H + c], vo = po[(size_t)r * H + c];
-                const float vco = pc[(size_t)perm[r] * H + c] + vo;
-                xco[(size_t)r * H + c] = vco;
+                const float vcp = pc[(size_t)perm[r] * H + c];
+                const float vco = cat ? vcp : vcp + vo;
+                xco[(size_t)r * W + c] = vco;
+                if (cat) xco[(size_t)r * W + H + c] = vo;
                 a1 += vc; a2 += (double)vc * vc; b1 += vo; b2 += (double)vo * vo; c1 += vco; c2 += (double)vco * vco;
             }
         block_col_atomic(a1, cl, rl, nrl, tc, cok, s_c, c, lds);
@@ -497,6 +504,10 @@ __global__ void __launch_bounds__(256) k_readout_prep(const float* __restrict__ 
         block_col_atomic(b2, cl, rl, nrl, tc, cok, q_o, c, lds);
         block_col_atomic(c1, cl, rl, nrl, tc, cok, s_co, c, lds);
         block_col_atomic(c2, cl, rl, nrl, tc, cok, q_co, c, lds);
+        if (cat) {
+            block_col_atomic(b1, cl, rl, nrl, tc, cok, s_co, H + c, lds);
+            block_col_atomic(b2, cl, rl, nrl, tc, cok, q_co, H + c, lds);
+        }
     }
 }
 
@@ -701,7 +712,7 @@ struct BnIn {
     const double* dot_sum;
     const double* dot_prod;
 };
-__device__ __forceinline__ float bn_bwd_elem(const BnIn& p, int r, int c, int H) {
+__device__ __forceinline__ float bn_bwd_elem(const BnIn& p, int r, int c, int H) {      // H = row stride of dyh / x
     float mean, rstd;
     bn_mean_rstd(p.bn, c, mean, rstd);
     const float gs = (p.bn.gamma ? p.bn.gamma[c] : 1.f) * rstd;
@@ -711,12 +722,14 @@ __device__ __forceinline__ float bn_bwd_elem(const BnIn& p, int r, int c, int H)
 }
 __global__ void __launch_bounds__(256) k_readout_bwd_tail(const BnIn hc, const BnIn ho, const BnIn hco,
                                                           const int* __restrict__ iperm, float* __restrict__ dpool,
-                                                          int B, int H) {
+                                                          int B, int H, int cat) {
+    // cat: the co input is [xc[perm] | xo] ([B, 2H]): its first H columns flow back to xc (un-permuted), the last H to xo
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)B * H) return;
     const int r = (int)(t / H), c = (int)(t % H);
-    dpool[t] = bn_bwd_elem(hc, r, c, H) + bn_bwd_elem(hco, iperm[r], c, H);
-    dpool[(size_t)B * H + t] = bn_bwd_elem(ho, r, c, H) + bn_bwd_elem(hco, r, c, H);
+    const int W = cat ? 2 * H : H;
+    dpool[t] = bn_bwd_elem(hc, r, c, H) + bn_bwd_elem(hco, iperm[r], c, W);
+    dpool[(size_t)B * H + t] = bn_bwd_elem(ho, r, c, H) + bn_bwd_elem(hco, r, cat ? H + c : c, W);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -815,7 +828,7 @@ __global__ void __launch_bounds__(256) k_normbwd_node2(const CSR gs, const CSR g
 // d edge_weight of both branches -> d(edge logit 0): dl[e] = a0 a1 (dw_c - dw_o)  (softmax2 backward)
 __global__ void k_normbwd_edge(const int* __restrict__ row32, const int* __restrict__ col32, const float* __restrict__ att,
                                const float* __restrict__ dis, const float* __restrict__ gn, const float* __restrict__ ddeg,
-                               float* __restrict__ dl, int N, int64_t E, const float* __restrict__ gn2) {
+                               float* __restrict__ dl, int N, int64_t E, const float* __restrict__ gn2, float fedge) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const int r = row32[e], c = col32[e];
@@ -823,7 +836,7 @@ __global__ void k_normbwd_edge(const int* __restrict__ row32, const int* __restr
     const float gc = gn[e] + (gn2 ? gn2[e] : 0.f), go = gn[E + e] + (gn2 ? gn2[E + e] : 0.f);
     const float dwc = gc * dis[r] * dis[c] + ddeg[r];
     const float dwo = go * dis[(size_t)N + r] * dis[(size_t)N + c] + ddeg[(size_t)N + r];
-    dl[e] = att[e] * att[E + e] * (dwc - dwo);
+    dl[e] = fedge * att[e] * att[E + e] * (dwc - dwo);       // fedge = 0: constant edge masks, nothing flows into the edge MLP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -847,6 +860,7 @@ struct AttBwdArgs {
     Acc dWn;           // [H] (+1: d bn0 at [H])
     Acc dWe;           // [2H] (+1: d be0 at [2H])
     const float* dxhc2; const float* dxho2;   // second partials of dxhc / dxho (per-graph fused backward) or null
+    float fnode, fedge;                       // 0 for without_node_attention / without_edge_attention (constant masks), else 1
 };
 
 template <int VEC, int G>
@@ -943,7 +957,7 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
                 d1 = fmaf(dxo[j], xv[j], d1);
             }
             d0 = group_sum<G>(d0); d1 = group_sum<G>(d1);
-            const float dl0 = a0[u] * a1[u] * (d0 - d1);
+            const float dl0 = a.fnode * a0[u] * a1[u] * (d0 - d1);
             float spv = sp[u], sqv = sq[u];
             for (int s = ps0[u] + l + G; s < ps1[u]; s += G) spv += a.dl[a.gs.eid[s]];      // rare: degree > G
             for (int s = pd0[u] + l + G; s < pd1[u]; s += G) sqv += a.dl[a.gd.eid[s]];

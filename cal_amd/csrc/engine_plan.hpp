@@ -163,7 +163,8 @@ __global__ void __launch_bounds__(512) k_att_fwd_graph(const int* __restrict__ g
                                                        float* __restrict__ anode, float* __restrict__ pq, float* __restrict__ att,
                                                        float* __restrict__ dis_c, float* __restrict__ dis_o, const Acc stc_sum,
                                                        const Acc stc_sq, const Acc sto_sum, const Acc sto_sq, float loop_w, int H,
-                                                       int64_t E, int* __restrict__ status) {
+                                                       int64_t E, int* __restrict__ status, float fnode, float fedge) {
+    // fnode / fedge: 1, or 0 for without_node_attention / without_edge_attention (equal logits -> constant 0.5 masks)
     constexpr int RPB = 512 / G, MAXR = 4 * RPB;
     __shared__ double lds[4 * 512 * (VEC == 4 ? 4 : 1)];
     __shared__ float4 pq_s[MAXR];
@@ -190,7 +191,7 @@ __global__ void __launch_bounds__(512) k_att_fwd_graph(const int* __restrict__ g
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = grp + u * RPB;
-            const float l0 = group_sum<G>(xv[u].dot(w[0])) + b0, l1 = group_sum<G>(xv[u].dot(w[1])) + b1;
+            const float l0 = fnode * (group_sum<G>(xv[u].dot(w[0])) + b0), l1 = fnode * (group_sum<G>(xv[u].dot(w[1])) + b1);
             const float p0 = group_sum<G>(xv[u].dot(w[2])), p1 = group_sum<G>(xv[u].dot(w[3]));
             const float q0 = group_sum<G>(xv[u].dot(w[4])), q1 = group_sum<G>(xv[u].dot(w[5]));
             const float m = fmaxf(l0, l1);
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(512) k_att_fwd_graph(const int* __restrict__ g
         const int s = t + u * 512;
         if (s < ne) {
             const float4 pvv = pq_s[sr_s[s]], qd = pq_s[sd_s[s]];
-            const float l0 = pvv.x + qd.z + e_b0, l1 = pvv.y + qd.w + e_b1;
+            const float l0 = fedge * (pvv.x + qd.z + e_b0), l1 = fedge * (pvv.y + qd.w + e_b1);
             const float m = fmaxf(l0, l1);
             const float x0 = expf(l0 - m), x1 = expf(l1 - m);
             const float inv = 1.f / (x0 + x1);

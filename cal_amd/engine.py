@@ -8,9 +8,10 @@ memory), binds gradients / Adam state, owns the device workspace and exposes
 * ``train_step(batch, perm)``       -> forward + 3-term loss + backward (+ Adam),
 
 each as ONE C call that enqueues the fused kernels on torch's current stream
-(hipGraph-capturable).  ``supported(model)`` says what is covered (CausalGCN and
-CausalGAT with ``cat_or_add == "add"`` and both attentions enabled); everything
-else stays on the operator-level path (``cal_amd.model``).
+(hipGraph-capturable).  ``supported(model)`` says what is covered: CausalGCN and
+CausalGAT, ``cat_or_add`` "add" or "cat", with or without the node / edge
+attention (``opts.get_model``'s causal variants except CausalGIN, which stays
+on the operator-level path of ``cal_amd.model``).
 """
 from __future__ import annotations
 
@@ -37,8 +38,7 @@ def supported(model) -> bool:
     from .gcn_conv import GCNConv
     a = model.args
     h = a.hidden
-    if not (isinstance(model, (CausalGCN, CausalGAT)) and a.cat_or_add == "add"
-            and not getattr(model, "without_node_attention", False) and not getattr(model, "without_edge_attention", False)
+    if not (isinstance(model, (CausalGCN, CausalGAT)) and a.cat_or_add in ("add", "cat")
             and h % 4 == 0 and h <= 256 and a.layers <= 6 and model.num_classes <= 64):
         return False
     # the engine hard-wires the normalised, non-improved GCNConv with a bias (gcn_conv.py:72-92 defaults): a model
@@ -110,7 +110,7 @@ class StepEngine:
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, flat=None):
         if not supported(model):
-            raise ValueError("StepEngine covers CausalGCN / CausalGAT (cat_or_add='add', attentions on, hidden % 4 == 0, <= 256)")
+            raise ValueError("StepEngine covers CausalGCN / CausalGAT (hidden % 4 == 0, <= 256, <= 6 layers, <= 64 classes)")
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise _lib.CalError("StepEngine needs the model on the GPU (no CPU fallback)")
@@ -129,6 +129,10 @@ class StepEngine:
         if not h:
             raise _lib.CalError("cal_engine_create failed: " + _lib.lib().cal_last_error().decode())
         self._h = ctypes.c_void_p(h)
+        # model variants: cat readout (2H-wide co head), the two ablation flags (model.py:65-69,99-107)
+        _lib.call("cal_engine_set_options", self._h, int(a.cat_or_add == "cat"),
+                  int(bool(getattr(model, "without_node_attention", False))),
+                  int(bool(getattr(model, "without_edge_attention", False))))
         # parameter offsets in slot order
         base = self.flat_p.data_ptr()
         params = dict(model.named_parameters())

@@ -152,6 +152,9 @@ CAL_API int cal_engine_set_gat(void* engine, int64_t heads, float p, float slope
  * cal_engine_buffer_offset(name) floats from its base. */
 CAL_API void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L);
 CAL_API void cal_engine_destroy(void* engine);
+/* model variants (model.py:24-31,65-69,99-107): cat = cat_or_add "cat" (fc1_bn_co / fc1_co are 2H wide), no_node_att / no_edge_att =
+ * without_node_attention / without_edge_attention (constant 0.5 masks).  Call before cal_engine_bind. */
+CAL_API int cal_engine_set_options(void* engine, int cat, int no_node_att, int no_edge_att);
 CAL_API int64_t cal_engine_num_param_slots(void* engine);
 CAL_API int64_t cal_engine_num_bn(void* engine);
 CAL_API int cal_engine_bind(void* engine, float* P, float* G, float* M1, float* M2, float* step,

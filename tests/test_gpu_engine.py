@@ -506,3 +506,55 @@ def test_step_sequence_equals_single_steps():
         outs.append((stats.clone(), tr.flat_p.clone()))
     assert torch.allclose(outs[0][0], outs[1][0], atol=1e-6)
     assert torch.allclose(outs[0][1], outs[1][1], atol=1e-6)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("CausalGCN", dict(cat_or_add="cat")), ("CausalGAT", dict(cat_or_add="cat")),
+    ("CausalGCN", dict(without_node_attention=True)), ("CausalGCN", dict(without_edge_attention=True)),
+    ("CausalGCN", dict(without_node_attention=True, without_edge_attention=True, cat_or_add="cat")),
+])
+@pytest.mark.parametrize("fused", [True, False])
+def test_model_variants_on_the_engine(name, kw, fused):
+    """Every causal variant `opts.get_model` can build from the CLI flags runs on the step engine:
+    `--cat_or_add cat` (fc1_bn_co / fc1_co 2H wide, model.py:65-69,153-154) and the two ablation flags (constant 0.5
+    node / edge masks, model.py:99-107, no gradient into the switched-off attention MLP) -- one train step against the
+    oracle, through the per-graph fused kernels and through the unfused chain."""
+    from cal_amd import model as M
+    from cal_amd.engine import StepEngine, supported
+    ids = list(range(20))
+    b, bd = ref_batch(ids), ref_batch(ids).to(DEV)
+    torch.manual_seed(23)
+    sd = O.init_state(name, 10, 4, hidden=64, layers=2, heads=4, cat_or_add=kw.get("cat_or_add", "add"))
+    args = _args(layers=2, hidden=64, **kw)
+    m = getattr(M, name)(10, 4, args)
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m = m.to(DEV).train()
+    if name == "CausalGAT":
+        for c in m.convs:
+            c.dropout = 0.0
+    assert supported(m)
+    eng = StepEngine(m, lr=1e-3)
+    eng.fused = fused
+    perm = torch.randperm(len(ids))
+    okw = {k: v for k, v in kw.items()}
+    tr = O.CpuTrainer(name, {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=2, heads=4, gat_dropout=0.0, **okw)
+    loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
+    lp = eng.buffer("logp", 3 * len(ids) * 4).view(3, len(ids), 4).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    eng.check_status()
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is None:                       # switched-off attention MLPs / conv_feat.bias: no gradient in the reference
+            assert float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert torch.allclose(p.grad.cpu(), gref, atol=5e-5, rtol=2e-3), k
+    # eval-mode forward of the same variant
+    m.eval()
+    sde = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    ref = O.causal_forward(name, sde, b.feat, b.edge_index, b.batch, perm=perm, training=False, layers=2, heads=4, **okw)
+    out = eng.forward(bd, perm.to(DEV), training=False)
+    for r, t in zip(ref, out):
+        assert (r - t.cpu()).abs().max().item() < LOGIT_TOL
