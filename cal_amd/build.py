@@ -41,8 +41,31 @@ def _needs(src: str, obj: str, deps) -> bool:
     return any(os.path.getmtime(p) > t for p in [src] + deps)
 
 
+HOST_SRC = os.path.join(HERE, "csrc_host", "calhost.cpp")
+HOST_LIB = os.path.join(LIBDIR, "libcalhost.so")
+
+
+def build_host(force: bool = False, verbose: bool = True) -> str:
+    """libcalhost.so: the plain-C++ HOST implementation of the operator-level entry points (same symbols; g++, no HIP)."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdr = os.path.join(os.path.dirname(HERE), "include", "cal_hip.h")
+    if force or _needs(HOST_SRC, HOST_LIB, [hdr]):
+        cxx = shutil.which("g++") or shutil.which("c++")
+        if not cxx:
+            raise RuntimeError("g++ not found: libcalhost.so cannot be built")
+        cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-fopenmp", "-Wall",
+               "-I", os.path.join(os.path.dirname(HERE), "include"), HOST_SRC, "-o", HOST_LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("host build failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("[cal_amd.build] built", HOST_LIB, flush=True)
+    return HOST_LIB
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
+    build_host(force, verbose)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "cal_hip.h"))

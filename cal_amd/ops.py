@@ -1,7 +1,9 @@
-"""autograd wrappers around the libcalhip entry points (operator-level boundary).
+"""autograd wrappers around the C-ABI entry points (operator-level boundary).
 
-Every Function checks that its tensors live on the GPU and calls straight into
-the C ABI on torch's current stream; there is no CPU implementation.
+Every Function hands its tensors to ``plan._c``, which calls straight into the
+C ABI: CUDA tensors -> libcalhip.so (HIP kernels, torch's current stream), CPU
+tensors -> libcalhost.so (the plain-C++ host implementation of the same
+symbols).  Tensors of one call must live on one device.
 """
 from __future__ import annotations
 
@@ -11,13 +13,10 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from .plan import GraphPlan, _p, _stream
+from .plan import GraphPlan, _c, _q
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
-    if not t.is_cuda:
-        raise _lib.CalError("%s: %s is on %s -- cal_amd kernels run on the GPU only (no CPU fallback)"
-                            % ("cal_amd.ops", name, t.device))
     if t.dtype != torch.float32:
         raise TypeError("%s must be float32 (got %s)" % (name, t.dtype))
     return t.contiguous()
@@ -43,13 +42,13 @@ class _GCNAggregate(Function):
             if w.numel() != plan.E:
                 raise AssertionError("edge_weight.size(0) != edge_index.size(1)")   # gcn_conv.py:54
             dis, norm = _empty(N, h.device), _empty(plan.E, h.device)
-            _lib.call("cal_gcn_norm_fwd", _p(plan.rowptr_src), _p(plan.eid_src), _p(plan.row32), _p(plan.col32),
-                      _p(w), loop_w, N, plan.E, _p(dis), _p(norm), _stream())
+            _c("cal_gcn_norm_fwd", plan.rowptr_src, plan.eid_src, plan.row32, plan.col32,
+                      w, loop_w, N, plan.E, dis, norm)
         if bias is not None:
             bias = _f32(bias, "bias")
         out = torch.empty_like(h)
-        _lib.call("cal_spmm_fwd", _p(plan.rowptr_dst), _p(plan.nbr_dst), _p(plan.eid_dst), _p(norm), _p(dis),
-                  loop_w, _p(h), _p(bias), int(relu), _p(out), N, H, _stream())
+        _c("cal_spmm_fwd", plan.rowptr_dst, plan.nbr_dst, plan.eid_dst, norm, dis,
+                  loop_w, h, bias, int(relu), out, N, H)
         ctx.plan, ctx.loop_w, ctx.relu, ctx.has_bias = plan, loop_w, relu, bias is not None
         ctx.has_w = w is not None
         need_h = ctx.has_w and ctx.needs_input_grad[1]
@@ -67,22 +66,22 @@ class _GCNAggregate(Function):
         dz = torch.empty_like(gout) if ctx.relu else gout
         dbias = torch.empty(H, dtype=torch.float32, device=dev) if need_bias else None
         if ctx.relu or need_bias:
-            part = _empty(_lib.query("cal_colsum_parts", N) * H, dev) if need_bias else None
-            _lib.call("cal_relu_bwd_colsum", _p(gout), _p(out) if ctx.relu else None,
-                      _p(dz) if ctx.relu else None, _p(dbias), _p(part), N, H, _stream())
+            part = _empty(_q(gout, "cal_colsum_parts", N) * H, dev) if need_bias else None
+            _c("cal_relu_bwd_colsum", gout, out if ctx.relu else None,
+                      dz if ctx.relu else None, dbias, part, N, H)
         dh = None
         if ctx.needs_input_grad[0]:
             dh = torch.empty_like(gout)
-            _lib.call("cal_spmm_fwd", _p(plan.rowptr_src), _p(plan.nbr_src), _p(plan.eid_src), _p(norm), _p(dis),
-                      loop_w, _p(dz), None, 0, _p(dh), N, H, _stream())
+            _c("cal_spmm_fwd", plan.rowptr_src, plan.nbr_src, plan.eid_src, norm, dis,
+                      loop_w, dz, None, 0, dh, N, H)
         dw = None
         if ctx.has_w and ctx.needs_input_grad[1]:
             dw = _empty(plan.E, dev)[:plan.E]
             gn, gself, ddeg = _empty(plan.E, dev), _empty(N, dev), _empty(N, dev)
-            _lib.call("cal_gcn_norm_bwd", _p(plan.rowptr_dst), _p(plan.nbr_dst), _p(plan.eid_dst),
-                      _p(plan.rowptr_src), _p(plan.nbr_src), _p(plan.eid_src), _p(plan.row32), _p(plan.col32),
-                      _p(w), _p(dis), loop_w, _p(h), _p(dz), _p(gn), _p(gself), _p(ddeg), _p(dw),
-                      N, plan.E, H, _stream())
+            _c("cal_gcn_norm_bwd", plan.rowptr_dst, plan.nbr_dst, plan.eid_dst,
+                      plan.rowptr_src, plan.nbr_src, plan.eid_src, plan.row32, plan.col32,
+                      w, dis, loop_w, h, dz, gn, gself, ddeg, dw,
+                      N, plan.E, H)
         return dh, dw, dbias, None, None, None
 
 
@@ -102,8 +101,8 @@ class _EdgeAttention(Function):
             raise ValueError("edge_att_mlp.weight must be [2, 2*hidden]")
         att = _empty(2 * plan.E, x.device)[:2 * plan.E].view(2, plan.E)
         pq = _empty(4 * N, x.device)
-        _lib.call("cal_edge_att_fwd", _p(x), _p(W), _p(b), _p(plan.row32), _p(plan.col32), _p(pq), _p(att),
-                  N, plan.E, H, _stream())
+        _c("cal_edge_att_fwd", x, W, b, plan.row32, plan.col32, pq, att,
+                  N, plan.E, H)
         ctx.plan = plan
         ctx.save_for_backward(x, W, att)
         return att
@@ -117,9 +116,9 @@ class _EdgeAttention(Function):
         dx = torch.empty_like(x)
         dW = torch.empty_like(W)
         db = torch.empty(2, dtype=torch.float32, device=x.device)
-        ws = _empty(_lib.query("cal_edge_att_bwd_ws", N, plan.E, H), x.device)
-        _lib.call("cal_edge_att_bwd", _p(x), _p(W), _p(att), _p(datt), _p(plan.rowptr_src), _p(plan.eid_src),
-                  _p(plan.rowptr_dst), _p(plan.eid_dst), _p(dx), 0, _p(dW), _p(db), _p(ws), N, plan.E, H, _stream())
+        ws = _empty(_q(x, "cal_edge_att_bwd_ws", N, plan.E, H), x.device)
+        _c("cal_edge_att_bwd", x, W, att, datt, plan.rowptr_src, plan.eid_src,
+                  plan.rowptr_dst, plan.eid_dst, dx, 0, dW, db, ws, N, plan.E, H)
         return dx, dW, db, None
 
 
@@ -136,7 +135,7 @@ class _NodeAttentionSplit(Function):
         N, H = x.shape
         att = _empty(2 * N, x.device)[:2 * N].view(N, 2)
         xc, xo = torch.empty_like(x), torch.empty_like(x)
-        _lib.call("cal_node_att_split_fwd", _p(x), _p(Wn), _p(bn), _p(att), _p(xc), _p(xo), N, H, _stream())
+        _c("cal_node_att_split_fwd", x, Wn, bn, att, xc, xo, N, H)
         ctx.save_for_backward(x, Wn, att)
         ctx.mark_non_differentiable(att)
         return xc, xo, att
@@ -149,9 +148,9 @@ class _NodeAttentionSplit(Function):
         dxo = torch.zeros_like(x) if dxo is None else _f32(dxo, "grad_xo")
         dx, dWn = torch.empty_like(x), torch.empty_like(Wn)
         dbn = torch.empty(2, dtype=torch.float32, device=x.device)
-        ws = _empty(_lib.query("cal_node_att_bwd_ws", N, H), x.device)
-        _lib.call("cal_node_att_split_bwd", _p(x), _p(Wn), _p(att), _p(dxc), _p(dxo), _p(dx), _p(dWn), _p(dbn),
-                  _p(ws), N, H, _stream())
+        ws = _empty(_q(x, "cal_node_att_bwd_ws", N, H), x.device)
+        _c("cal_node_att_split_bwd", x, Wn, att, dxc, dxo, dx, dWn, dbn,
+                  ws, N, H)
         return dx, dWn, dbn
 
 
@@ -169,7 +168,7 @@ class _AddPool(Function):
         B, S = plan.B, plan.pool_splits()
         out = torch.empty(B, H, dtype=torch.float32, device=x.device)
         part = _empty(S * B * H, x.device) if S > 1 else None
-        _lib.call("cal_add_pool_fwd", _p(x), _p(plan.gptr), _p(out), _p(part), B, H, S, _stream())
+        _c("cal_add_pool_fwd", x, plan.gptr, out, part, B, H, S)
         ctx.plan, ctx.N = plan, N
         return out
 
@@ -178,7 +177,7 @@ class _AddPool(Function):
         dout = _f32(dout, "grad")
         H = dout.size(1)
         dx = torch.empty(ctx.N, H, dtype=torch.float32, device=dout.device)
-        _lib.call("cal_add_pool_bwd", _p(dout), _p(ctx.plan.batch), _p(dx), ctx.N, H, _stream())
+        _c("cal_add_pool_bwd", dout, ctx.plan.batch, dx, ctx.N, H)
         return dx, None
 
 
@@ -205,8 +204,8 @@ class _GATAggregate(Function):
         dev = z.device
         out = torch.empty_like(z)
         adst, asrc, mx, den = (_empty(N * K, dev) for _ in range(4))
-        _lib.call("cal_gat_fwd", _p(plan.rowptr_dst), _p(plan.nbr_dst), _p(plan.eid_dst), _p(z), _p(att), _p(bias),
-                  int(relu), slope, p, seed, _p(out), _p(adst), _p(asrc), _p(mx), _p(den), N, plan.E, K, D, _stream())
+        _c("cal_gat_fwd", plan.rowptr_dst, plan.nbr_dst, plan.eid_dst, z, att, bias,
+                  int(relu), slope, p, seed, out, adst, asrc, mx, den, N, plan.E, K, D)
         ctx.plan, ctx.K, ctx.D, ctx.slope, ctx.p, ctx.seed, ctx.relu = plan, K, D, slope, p, seed, relu
         ctx.has_bias = bias is not None
         ctx.att_shape = att.shape
@@ -224,15 +223,15 @@ class _GATAggregate(Function):
         g = torch.empty_like(gout) if ctx.relu else gout
         dbias = torch.empty(H, dtype=torch.float32, device=dev) if need_bias else None
         if ctx.relu or need_bias:
-            part = _empty(_lib.query("cal_colsum_parts", N) * H, dev) if need_bias else None
-            _lib.call("cal_relu_bwd_colsum", _p(gout), _p(out) if ctx.relu else None,
-                      _p(g) if ctx.relu else None, _p(dbias), _p(part), N, H, _stream())
+            part = _empty(_q(gout, "cal_colsum_parts", N) * H, dev) if need_bias else None
+            _c("cal_relu_bwd_colsum", gout, out if ctx.relu else None,
+                      g if ctx.relu else None, dbias, part, N, H)
         dz = torch.empty_like(gout)
         datt = torch.empty(K * 2 * D, dtype=torch.float32, device=dev)
-        ws = _empty(_lib.query("cal_gat_bwd_ws", N, plan.E, K, D), dev)
-        _lib.call("cal_gat_bwd", _p(plan.rowptr_dst), _p(plan.nbr_dst), _p(plan.eid_dst), _p(plan.rowptr_src),
-                  _p(plan.nbr_src), _p(plan.eid_src), _p(z), _p(att), _p(adst), _p(asrc), _p(mx), _p(den), _p(g),
-                  ctx.slope, ctx.p, ctx.seed, _p(dz), _p(datt), _p(ws), N, plan.E, K, D, _stream())
+        ws = _empty(_q(gout, "cal_gat_bwd_ws", N, plan.E, K, D), dev)
+        _c("cal_gat_bwd", plan.rowptr_dst, plan.nbr_dst, plan.eid_dst, plan.rowptr_src,
+                  plan.nbr_src, plan.eid_src, z, att, adst, asrc, mx, den, g,
+                  ctx.slope, ctx.p, ctx.seed, dz, datt, ws, N, plan.E, K, D)
         return dz, datt.view(ctx.att_shape), dbias, None, None, None, None, None, None
 
 
@@ -244,7 +243,7 @@ def gat_aggregate(z, att, bias, plan: GraphPlan, heads: int, negative_slope: flo
 def gat_dropout_mask(seed: int, plan: GraphPlan, heads: int, p: float) -> torch.Tensor:
     """The keep mask ([E + N, heads] of 0/1) the kernels derive from ``seed`` (for tests)."""
     m = torch.empty(plan.E + plan.N, heads, dtype=torch.float32, device=plan.device)
-    _lib.call("cal_gat_dropout_mask", seed, plan.E, plan.N, heads, p, _p(m), _stream())
+    _c("cal_gat_dropout_mask", seed, plan.E, plan.N, heads, p, m)
     return m
 
 
@@ -263,7 +262,7 @@ class _Linear(Function):
         if bias is not None:
             bias = _f32(bias, "bias")
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        _lib.call("cal_gemm", 0, 1 if out_in else 0, _p(x), _p(weight), _p(y), _p(bias), int(relu), None, M, N, K, _stream())
+        _c("cal_gemm", 0, 1 if out_in else 0, x, weight, y, bias, int(relu), None, M, N, K)
         ctx.out_in, ctx.relu, ctx.has_bias = out_in, relu, bias is not None
         ctx.save_for_backward(x, weight, y if relu else None)
         return y
@@ -279,22 +278,22 @@ class _Linear(Function):
         g = torch.empty_like(gy) if ctx.relu else gy
         db = torch.empty(N, dtype=torch.float32, device=dev) if need_b else None
         if ctx.relu or need_b:
-            part = _empty(_lib.query("cal_colsum_parts", M) * N, dev) if need_b else None
-            _lib.call("cal_relu_bwd_colsum", _p(gy), _p(y) if ctx.relu else None, _p(g) if ctx.relu else None,
-                      _p(db), _p(part), M, N, _stream())
+            part = _empty(_q(gy, "cal_colsum_parts", M) * N, dev) if need_b else None
+            _c("cal_relu_bwd_colsum", gy, y if ctx.relu else None, g if ctx.relu else None,
+                      db, part, M, N)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=torch.float32, device=dev)
             # out_in: dx = g @ W ([N,K] as stored);  else dx = g @ W^T (W stored [K,N])
-            _lib.call("cal_gemm", 0, 0 if ctx.out_in else 1, _p(g), _p(weight), _p(dx), None, 0, None, M, K, N, _stream())
+            _c("cal_gemm", 0, 0 if ctx.out_in else 1, g, weight, dx, None, 0, None, M, K, N)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight)
             if ctx.out_in:      # dW [N,K] = g^T @ x
-                ws = _empty(_lib.query("cal_gemm_ws", N, K, M), dev)
-                _lib.call("cal_gemm", 1, 0, _p(g), _p(x), _p(dw), None, 0, _p(ws), N, K, M, _stream())
+                ws = _empty(_q(gy, "cal_gemm_ws", N, K, M), dev)
+                _c("cal_gemm", 1, 0, g, x, dw, None, 0, ws, N, K, M)
             else:               # dW [K,N] = x^T @ g
-                ws = _empty(_lib.query("cal_gemm_ws", K, N, M), dev)
-                _lib.call("cal_gemm", 1, 0, _p(x), _p(g), _p(dw), None, 0, _p(ws), K, N, M, _stream())
+                ws = _empty(_q(gy, "cal_gemm_ws", K, N, M), dev)
+                _c("cal_gemm", 1, 0, x, g, dw, None, 0, ws, K, N, M)
         return dx, dw, db, None, None
 
 
@@ -318,8 +317,8 @@ class _GINAggregate(Function):
         N, H = x.shape
         ones_n, ones_e = plan.ones()
         out = torch.empty_like(x)
-        _lib.call("cal_spmm_fwd", _p(plan.rowptr_dst), _p(plan.nbr_dst), _p(plan.eid_dst), _p(ones_e), _p(ones_n),
-                  1.0 + eps, _p(x), None, 0, _p(out), N, H, _stream())
+        _c("cal_spmm_fwd", plan.rowptr_dst, plan.nbr_dst, plan.eid_dst, ones_e, ones_n,
+                  1.0 + eps, x, None, 0, out, N, H)
         ctx.plan, ctx.eps = plan, eps
         return out
 
@@ -330,8 +329,8 @@ class _GINAggregate(Function):
         plan = ctx.plan
         ones_n, ones_e = plan.ones()
         dx = torch.empty_like(g)
-        _lib.call("cal_spmm_fwd", _p(plan.rowptr_src), _p(plan.nbr_src), _p(plan.eid_src), _p(ones_e), _p(ones_n),
-                  1.0 + ctx.eps, _p(g), None, 0, _p(dx), N, H, _stream())
+        _c("cal_spmm_fwd", plan.rowptr_src, plan.nbr_src, plan.eid_src, ones_e, ones_n,
+                  1.0 + ctx.eps, g, None, 0, dx, N, H)
         return dx, None, None
 
 

@@ -26,6 +26,30 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _c(name: str, *args):
+    """Call entry point ``name`` with tensors passed AS TENSORS: they become their data pointers, the library is
+    chosen by where they live (CUDA -> libcalhip.so on torch's current stream, CPU -> libcalhost.so), and tensors of
+    one call may not straddle devices."""
+    dev, conv = None, []
+    for a in args:
+        if torch.is_tensor(a):
+            d = a.device.type
+            if dev is None:
+                dev = d
+            elif d != dev:
+                raise _lib.CalError("%s: tensors on both %s and %s in one call" % (name, dev, d))
+            conv.append(a.data_ptr())
+        else:
+            conv.append(a)
+    host = dev == "cpu"
+    _lib.call(name, *conv, None if host else _stream(), host=host)
+
+
+def _q(ref: torch.Tensor, name: str, *args) -> int:
+    """Size query against the library that will serve ``ref``'s device."""
+    return _lib.query(name, *args, host=not ref.is_cuda)
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -38,8 +62,6 @@ class GraphPlan:
     def __init__(self, edge_index: torch.Tensor, num_nodes: int,
                  batch: Optional[torch.Tensor] = None, num_graphs: Optional[int] = None,
                  validate: bool = False):
-        if not edge_index.is_cuda:
-            raise _lib.CalError("GraphPlan needs CUDA/HIP tensors (cal_amd has no CPU path)")
         if edge_index.dtype != torch.long or edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError("edge_index must be int64 [2, E]")
         self.device = edge_index.device
@@ -59,15 +81,15 @@ class GraphPlan:
         for k, v in sizes.items():
             setattr(self, k, self._ints[off:off + v])
             off += _al4(max(v, 1))
-        _lib.call("cal_plan_build", _p(ei), E, N, _p(self.rowptr_dst), _p(self.nbr_dst), _p(self.eid_dst),
-                  _p(self.rowptr_src), _p(self.nbr_src), _p(self.eid_src), _p(self.row32), _p(self.col32),
-                  _p(self.work), _p(self.status), _stream())
+        _c("cal_plan_build", ei, E, N, self.rowptr_dst, self.nbr_dst, self.eid_dst,
+                  self.rowptr_src, self.nbr_src, self.eid_src, self.row32, self.col32,
+                  self.work, self.status)
         self.batch = None
         if batch is not None:
             if batch.dtype != torch.long or batch.numel() != N:
                 raise ValueError("batch must be int64 [N]")
             self.batch = batch.contiguous()
-            _lib.call("cal_graph_ptr", _p(self.batch), N, B, _p(self.gptr), _p(self.status), _stream())
+            _c("cal_graph_ptr", self.batch, N, B, self.gptr, self.status)
         self._unit: Dict[float, Tuple[torch.Tensor, torch.Tensor]] = {}
         if validate:
             self.check()
@@ -86,8 +108,8 @@ class GraphPlan:
         if key not in self._unit:
             dis = torch.empty(max(self.N, 1), dtype=torch.float32, device=self.device)
             norm = torch.empty(max(self.E, 1), dtype=torch.float32, device=self.device)
-            _lib.call("cal_gcn_norm_fwd", _p(self.rowptr_src), _p(self.eid_src), _p(self.row32), _p(self.col32),
-                      None, key, self.N, self.E, _p(dis), _p(norm), _stream())
+            _c("cal_gcn_norm_fwd", self.rowptr_src, self.eid_src, self.row32, self.col32,
+                      None, key, self.N, self.E, dis, norm)
             self._unit[key] = (dis, norm)
         return self._unit[key]
 

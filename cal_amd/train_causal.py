@@ -17,11 +17,13 @@ from torch.optim.lr_scheduler import CosineAnnealingLR
 from .data import DataLoader
 
 
-def _device():
-    if not torch.cuda.is_available():
-        raise RuntimeError("cal_amd needs an MI355X (torch.cuda.is_available() is False); "
-                           "there is no CPU fallback")
-    return torch.device("cuda")
+def _device(args=None):
+    """train_causal.py:10: ``cuda`` when available, else ``cpu`` -- where the reference's CPU plumbing run
+    (BASELINE.json configs[0]) lands; ``args.device`` (not a reference flag) pins it.  On the CPU the models run the
+    operator-level path on libcalhost.so (the host implementation of the same C-ABI symbols); nothing GPU-resident is
+    ever computed there."""
+    forced = getattr(args, "device", None)
+    return torch.device(forced if forced else ("cuda" if torch.cuda.is_available() else "cpu"))
 
 
 def _check_engine(model):
@@ -95,7 +97,7 @@ def eval_acc_causal(model, loader, device, args):
 
 def train_causal_syn(train_set, val_set, test_set, model_func=None, args=None, log=print):
     """train_causal.py:11-61."""
-    device = _device()
+    device = _device(args)
     train_loader = DataLoader(train_set, args.batch_size, shuffle=True)
     val_loader = DataLoader(val_set, args.batch_size, shuffle=False)
     test_loader = DataLoader(test_set, args.batch_size, shuffle=False)
@@ -138,7 +140,7 @@ def train_causal_real(dataset=None, model_func=None, args=None, log=print):
     one whose fold-mean ``test_acc_o`` is highest (``test_acc_o``), mean and std over folds.
     Returns a dict with those figures and the per-fold / per-epoch tensors."""
     from .tu import k_fold
-    device = _device()
+    device = _device(args)
     train_accs, test_accs, test_accs_c, test_accs_o = [], [], [], []
     random_guess = 1.0 / dataset.num_classes
     for fold, (train_idx, test_idx, val_idx) in enumerate(zip(*k_fold(dataset, args.folds, args.epoch_select))):

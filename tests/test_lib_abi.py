@@ -1,6 +1,6 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
 every symbol include/cal_hip.h declares; modules keep the reference's
-state-dict surface; compute fails loudly without a GPU."""
+state-dict surface; GPU-only pieces fail loudly for CPU data."""
 import argparse
 import subprocess
 
@@ -32,16 +32,32 @@ def test_header_parses_and_library_exports_every_symbol():
     assert all(s.startswith("cal_") or s.startswith("_") for s in exported)
 
 
-def test_no_cpu_fallback():
-    from cal_amd import ops
-    from cal_amd.plan import GraphPlan
-    with pytest.raises(_lib.CalError):
-        GraphPlan(torch.zeros(2, 3, dtype=torch.long), 4)
+def test_host_library_exports_the_operator_level_symbols():
+    """libcalhost.so (plain C++, no HIP): the same names and prototypes as libcalhip.so for every operator-level entry."""
+    h = _lib.host_lib()
+    assert h.cal_version() >= 100
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.HOST_LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l}
+    assert set(_lib.HOST_SYMBOLS) <= exported and set(_lib.HOST_SYMBOLS) <= set(_lib.parse_header())
+    assert all(s.startswith("cal_") or s.startswith("_") for s in exported)
+    deps = subprocess.run(["ldd", _lib.HOST_LIB_PATH], capture_output=True, text=True).stdout
+    assert "amdhip" not in deps and "torch" not in deps          # no HIP runtime, no torch: loads on any host
+
+
+def test_gpu_only_pieces_refuse_cpu_tensors_and_devices_do_not_mix():
+    """The step engine, the device-resident dataset and everything else without a host twin raise for CPU data; the
+    host library is only ever chosen for CPU-resident tensors, never as a substitute for a missing libcalhip.so."""
     from cal_amd.model import CausalGCN
-    from tests.helpers import ref_batch
+    from cal_amd.engine import StepEngine
+    from cal_amd.device_data import DeviceDataset
+    from tests.helpers import ref_graphs
     m = CausalGCN(10, 4, _args(layers=1, hidden=16))
     with pytest.raises(_lib.CalError):
-        m(ref_batch([0, 1]))
+        StepEngine(m)
+    with pytest.raises(_lib.CalError):
+        DeviceDataset(ref_graphs([0, 1]), device="cpu")
+    with pytest.raises(_lib.CalError):
+        _lib.call("cal_randperm", None, 4, 1, None, None, host=True)
 
 
 @pytest.mark.parametrize("name", ["CausalGCN", "CausalGAT"])
