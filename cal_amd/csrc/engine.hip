@@ -955,8 +955,9 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         d.p = parts_alloc(c, (size_t)PN * cols); d.P = PN; d.stride = cols;
         return d.p ? Acc(nullptr, d.p, cols) : Acc();
     };
-    auto deferred_g = [&](int cols, Deferred& d) -> Acc {          // two partial rows per graph (k_att_bwd_graph, grid (2 B))
-        d.p = parts_alloc(c, (size_t)2 * B * cols); d.P = 2 * B; d.stride = cols;
+    const int ag_split = 2;                                        // workgroups per graph of k_att_bwd_graph
+    auto deferred_g = [&](int cols, Deferred& d) -> Acc {          // one partial row per workgroup of k_att_bwd_graph
+        d.p = parts_alloc(c, (size_t)ag_split * B * cols); d.P = ag_split * B; d.stride = cols;
         return d.p ? Acc(nullptr, d.p, cols) : Acc();
     };
     Deferred d_convb[MAX_LAYERS], d_cb, d_ob, d_dwn, d_dwe, d_bn0;
@@ -1050,6 +1051,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         CAL_CHECK_LAUNCH("k_readout_bwd_tail"); STAGE();
     }
     const bool gcb = use_gcb(c);
+    const bool agb = gcb && B <= 256;           // per-graph attention backward (two workgroups per graph: one wave of the chip)
     // P1. add-pool backward + ReLU of the causal/trivial convs + their bias gradients
     // (per-graph fused backward: both are built while k_gconv_bwd stages dOut, and it emits gn / gself as well)
     if (!gcb) {
@@ -1118,13 +1120,17 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             gb[k].rs = e->anode + k; gb[k].rs_stride = 2; gb[k].bn = bnref(c, L + 1 + k, N, 0);
             gb[k].dxp0 = e->dXhco + (size_t)k * NH; gb[k].dxp1 = e->dzco + (size_t)k * NH;
             gb[k].coef_in = e->coef + (size_t)(1 + k) * E;
-            gb[k].gn_slot = 1;                  // consumed by k_att_bwd_graph in slot order
+            gb[k].gn_slot = agb ? 1 : 0;        // consumed by k_att_bwd_graph in slot order (else by k_normbwd_* in edge-id order)
             dst[k] = e->G + (k ? e->o_ow : e->o_cw); dsum[k] = bn_dsum(c, L + 1 + k); dprod[k] = bn_dprod(c, L + 1 + k);
         }
         RC(gconv_bwd(c, gd, gb, 2, dst, dsum, dprod, fa, slab_off, true)); STAGE();
         RC(flush_finals(c)); STAGE();
-        // (the edge-weight gradients through the normalisation -- k_normbwd_node2 / k_normbwd_edge of the unfused path --
-        //  are part of the per-graph attention backward below)
+        // the edge-weight gradients through the normalisation are part of the per-graph attention backward below; big
+        // batches (a per-graph launch would be several waves of one-per-CU workgroups) keep the node- / edge-parallel kernels
+        if (!agb) {
+            const bool two = H > GC_N;
+            RC(norm_bwd(two ? e->gn + 2 * (size_t)E : nullptr, two ? e->gself + 2 * (size_t)N : nullptr));
+        }
     }
     // P6. dW_k = BN_k(a_k x)^T @ dz_k
     if (!gcb) {
@@ -1159,7 +1165,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         aa.Wn = e->P + e->o_natt_w; aa.We = e->P + e->o_eatt_w; aa.dl = e->dl;
         aa.fnode = e->no_node_att ? 0.f : 1.f; aa.fedge = e->no_edge_att ? 0.f : 1.f;
         aa.gs = gs; aa.gd = gd; aa.dZ = e->dZ;
-        if (gcb) {       // per graph: d deg, d edge logits and the row pass in one kernel (engine_attbwd.hpp)
+        if (agb) {       // per graph: d deg, d edge logits and the row pass in one kernel (engine_attbwd.hpp)
             aa.dbias = L > 0 ? deferred_g(H, d_convb[L - 1]) : Acc();
             aa.dWn = deferred_g(H + 4, d_dwn); aa.dWe = deferred_g(2 * H + 4, d_dwe);
             if (!aa.dWn.on() || !aa.dWe.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
@@ -1170,7 +1176,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             ag.loop_w = e->loop_w; ag.E = E; ag.N = N; ag.status = e->status;
             RC(with_g(H, [&](auto g) {
                 constexpr int G = decltype(g)::value;
-                hipLaunchKernelGGL((k_att_bwd_graph<4, G>), dim3(2 * B), dim3(512), 0, st, ag, 1, H);
+                hipLaunchKernelGGL((k_att_bwd_graph<4, G>), dim3(ag_split * B), dim3(512), 0, st, ag, 1, H, ag_split);
                 return 0;
             }));
             CAL_CHECK_LAUNCH("k_att_bwd_graph"); STAGE();

@@ -10,7 +10,8 @@
 // and per-node `ddeg` going through HBM.  Both endpoints of an edge are in the same graph, so one workgroup that
 // owns the graph keeps the per-slot terms, ddeg, dl, sp and sq in LDS.
 //
-//   grid (2 B), 512 threads: two workgroups per graph (same edge phase, one half of the rows each); graphs of at most
+//   grid (nsplit B), 512 threads: nsplit = 2 workgroups per graph (same edge phase, one half of the rows each) for B <= 256,
+//   else one; graphs of at most
 //   64 nodes and GP_E stored edges -- the bounds of the per-graph fused backward (use_gcb in engine.hip).
 //
 // Edge phase: only the by-destination CSR rows of the graph are read, and everything per edge arrives in SLOT order
@@ -42,7 +43,7 @@ constexpr int AG_T = 64;                  // nodes per graph
 constexpr int AG_LD = AG_T + 1;
 
 template <int VEC, int G>
-__global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga, int relu, int H) {
+__global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga, int relu, int H, int nsplit) {
     constexpr int RPB = 512 / G, UR = 2, HALF = AG_T / 2;
     const AttBwdArgs& a = ga.a;
     // dense per-graph blocks, [source r][destination c]: Tc / To = sum over the edges r -> c of g_k w_k (d deg terms),
@@ -57,7 +58,9 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
     // two workgroups per graph: both run the (cheap) edge phase, each takes one half of the rows -- the row phase streams
     // five [rows, H] tensors the previous kernel wrote on other XCDs, and 128 workgroups leave half the chip's CUs (and
     // their share of the fabric bandwidth) idle: 8.3 us until the first barrier with one workgroup per graph
-    const int b = blockIdx.x >> 1, half = blockIdx.x & 1, t = threadIdx.x, grp = t / G, l = t % G;
+    // (nsplit = 2 while 2 B workgroups still fit the chip in one wave; bigger batches keep one workgroup per graph: the
+    //  duplicated edge phase would only add to a launch that already covers every CU several times)
+    const int b = nsplit == 2 ? blockIdx.x >> 1 : blockIdx.x, half = nsplit == 2 ? blockIdx.x & 1 : 0, t = threadIdx.x, grp = t / G, l = t % G;
     const int g0 = ga.gptr[b], rows = ga.gptr[b + 1] - g0, e0 = ga.eptr[b], ne = ga.eptr[b + 1] - e0;
     const int64_t E = ga.E;
     const int N = ga.N;
@@ -112,7 +115,7 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
                 hc2[u] = V::ld(dxhc2 + v * H + cc); ho2[u] = V::ld(dxho2 + v * H + cc);
             }
         };
-        const int rbeg = half * HALF, rend = min(rows, rbeg + HALF);      // this workgroup's rows
+        const int rbeg = half * HALF, rend = nsplit == 2 ? min(rows, rbeg + HALF) : rows;      // this workgroup's rows
         load_rows(rbeg + grp);
         int dn[2];
         float dgc[2], dgo[2], dwc[2], dwo[2], dgc2[2], dgo2[2];            // per-slot values: everything is in slot order, no edge-id round

@@ -1,0 +1,33 @@
+"""profiles/pmc_traffic.json from the two per-kernel PMC summaries of scripts/profile_round.sh:
+    python scripts/pmc_traffic.py gpurun_out/<tag>/pmc_FETCH_SIZE.json gpurun_out/<tag>/pmc_WRITE_SIZE.json <workload> > profiles/pmc_traffic.json
+HBM-side bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB counters; FETCH_SIZE doubled as MI355X_MICROARCH.md
+prescribes for gfx950: wide coalesced reads are tallied at half their bytes; WRITE_SIZE as reported).  bench.py copies
+`bytes_per_launch` of the kernel classes it times into `roofline.traffic`."""
+import json, sys
+fetch, write, workload = json.load(open(sys.argv[1])), json.load(open(sys.argv[2])), sys.argv[3]
+# bench.py roofline class -> substring of the kernel name in the PMC summaries
+classes = {
+    "k_gconv_fwd": "k_gconv_fwd<false", "k_gconv_fwd_co": "k_gconv_fwd<true", "k_gconv_bwd": "k_gconv_bwd<false, 1>",
+    "k_gconv_bwd_top": "k_gconv_bwd<false, 0>", "k_gconv_bwd_co": "k_gconv_bwd<true, 2>", "k_att_fwd_graph": "k_att_fwd_graph",
+    "k_att_bwd_graph": "k_att_bwd_graph", "k_finish": "k_finish", "k_espmm": "k_espmm", "k_gemm_backbone": "k_gemm<",
+    "k_gemm_dual": "k_gemm_dual", "k_ggat_fwd": "k_ggat_fwd", "k_ggat_bwd": "k_ggat_bwd", "k_gat_fwd": "k_gat_fwd",
+    "k_gat_bwd_dst": "k_gat_bwd_dst", "k_gat_bwd_src": "k_gat_bwd_src", "k_gemm_big": "k_gemm_big<", "k_gemm_big_dual": "k_gemm_big_dual",
+}
+def mean(summary, sub):
+    tot, n = 0.0, 0
+    for k, v in summary.items():
+        if sub in k:
+            tot += v["mean_KB"] * v["calls"]; n += v["calls"]
+    return (tot / n, n) if n else (None, 0)
+out = {"workload": workload,
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two separate passes of the eager step "
+                 "(scripts/profile_round.sh); bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 "
+                 "(gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md); per-kernel means"}
+for cls, sub in classes.items():
+    f, nf = mean(fetch, sub)
+    w, nw = mean(write, sub)
+    if f is None or w is None:
+        continue
+    out[cls] = {"fetch_KB_raw": round(f, 1), "write_KB": round(w, 1), "launches_sampled": nf,
+                "bytes_per_launch": int((2 * f + w) * 1024)}
+json.dump(out, sys.stdout, indent=1)

@@ -15,6 +15,8 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
     f=$(find /tmp/prof_$tag/$ctr -name "*counter_collection.csv" | head -1)
     python scripts/pmc_summary.py $f $ctr > gpurun_out/$tag/pmc_$ctr.json
 done
+python scripts/pmc_traffic.py gpurun_out/$tag/pmc_FETCH_SIZE.json gpurun_out/$tag/pmc_WRITE_SIZE.json spmotif_b0.9_causalgcn_h128_l3_bs128 > gpurun_out/$tag/pmc_traffic.json
+cp gpurun_out/$tag/pmc_traffic.json profiles/pmc_traffic.json       # so that the bench line below carries roofline.traffic
 python bench.py > gpurun_out/$tag/bench_default.log 2>&1
 tail -1 gpurun_out/$tag/bench_default.log > gpurun_out/$tag/bench_engine_graph.json
 head -12 gpurun_out/$tag/rocprof_kernel_stats_engine.csv | cut -c1-160
