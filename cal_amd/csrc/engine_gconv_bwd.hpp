@@ -483,20 +483,26 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
     float xr[8];                                         // x0[g0 .. g0 + rows) is contiguous: rows * F <= 4096 floats
 #pragma unroll
     for (int u = 0; u < 8; ++u) xr[u] = a.x0[(size_t)g0 * F + min(t + u * GB_NT, rows * F - 1)];
+    // BatchNorm constants: unconditional loads on clamped columns, pinned with the tile loads (BNRaw, engine.hpp)
+    const int uc = min(t, H - 1), fc = min(max(t - 128, 0), F - 1);
+    BNRaw uraw = bn_raw_load(a.ubn, uc), raw0 = bn_raw_load(a.bn0, fc);
+    double ud1 = a.udot_sum[uc], ud2 = a.udot_prod[uc];
+    bn_raw_pin(uraw); bn_raw_pin(raw0);
+    asm volatile("" : "+v"(ud1), "+v"(ud2));
     if (t < H) {
-        float m1[1], r1[1];
-        bn_mean_rstd_v<1>(a.ubn, t, m1, r1);
-        um_s[t] = m1[0]; ur_s[t] = r1[0];
-        ug_s[t] = (a.ubn.gamma ? a.ubn.gamma[t] : 1.f) * r1[0];
-        u1_s[t] = (float)(a.udot_sum[t] * (double)a.ubn.inv_n);
-        u2_s[t] = (float)(a.udot_prod[t] * (double)a.ubn.inv_n);
+        float m1, r1;
+        bn_raw_mean_rstd(a.ubn, uraw, m1, r1);
+        um_s[t] = m1; ur_s[t] = r1;
+        ug_s[t] = uraw.g * r1;
+        u1_s[t] = (float)(ud1 * (double)a.ubn.inv_n);
+        u2_s[t] = (float)(ud2 * (double)a.ubn.inv_n);
     } else if (t - 128 < F && t >= 128) {
         const int f = t - 128;
-        float m1[1], r1[1];
-        bn_mean_rstd_v<1>(a.bn0, f, m1, r1);
-        m0_s[f] = m1[0]; r0_s[f] = r1[0];
-        g0_s[f] = a.bn0.gamma ? a.bn0.gamma[f] : 1.f;
-        b0_s[f] = a.bn0.beta ? a.bn0.beta[f] : 0.f;
+        float m1, r1;
+        bn_raw_mean_rstd(a.bn0, raw0, m1, r1);
+        m0_s[f] = m1; r0_s[f] = r1;
+        g0_s[f] = raw0.g;
+        b0_s[f] = raw0.b;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(xr[u]));

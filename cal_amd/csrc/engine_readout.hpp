@@ -300,9 +300,14 @@ __global__ void __launch_bounds__(256) k_ro_fwd_b(const RoArgs a) {
         auto stw = [&](int c, int k, const float4 v) { *reinterpret_cast<float4*>(W2s + c * RO_WLD + k * 4) = v; };
         ro_issue(by, nb, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(a.y1 + ((size_t)hd * B + b0 + b) * K + c * 4); });
         if (small) ro_issue(bws, C, K4, ldw); else ro_issue(bwl, C, K4, ldw);
-        for (int k = threadIdx.x; k < K; k += 256) {
-            bn_scale_shift(h.bn2, k, sc_s[k], sh_s[k]);
-            if (a.training && blockIdx.y == 0) bn_update_running(h.bn2, k);
+        {   // BN2 constants (K <= 256: one column per lane), loaded unconditionally with the tiles (BNRaw, engine.hpp)
+            const int k = threadIdx.x;
+            BNRaw raw = bn_raw_load(h.bn2, min(k, K - 1));
+            bn_raw_pin(raw);
+            if (k < K) {
+                bn_raw_scale_shift(h.bn2, raw, sc_s[k], sh_s[k]);
+                if (a.training && blockIdx.y == 0) bn_raw_update_running(h.bn2, raw, k);
+            }
         }
         if (small) ro_commit(bws, C, K4, stw); else ro_commit(bwl, C, K4, stw);
         __syncthreads();
