@@ -228,18 +228,21 @@ def engine_roofline(trainer, batches, workload, iters=20):
     # HBM-side traffic per launch from the PMC passes (separate rocprofv3 --pmc runs of this command;
     # committed under profiles/): null when the summary is absent
     pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if pmc.get("workload", HEADLINE) != workload:      # the counters were collected on another workload
+    for cand in ("pmc_traffic_%s.json" % workload, "pmc_traffic.json"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            if pmc.get("workload", HEADLINE) == workload:
+                break
+            pmc = {}                                       # the counters were collected on another workload
+        except Exception:
             pmc = {}
-    except Exception:
-        pass
     if workload == HEADLINE:
         note = ("config-2 working set (3.7 MB activations) is cache-resident and every launch is a few hundred "
                 "workgroups of one ~10 us dependent chain: the step is latency-bound by construction (SURVEY.md 8d); "
                 "event pairs include the launch gap")
     else:
-        note = "event pairs include the launch gap; no PMC pass was collected for this workload (traffic null)"
+        note = ("event pairs include the launch gap" if pmc else
+                "event pairs include the launch gap; no PMC pass was collected for this workload (traffic null)")
     mfma = {
         "gemm": ("k_gemm", "k_gemm / k_gemm_big<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers, unfused path; 128x128 tiles from 16k rows)", "k_gemm_backbone"),
         "gconv": ("k_gconv_fwd", "k_gconv_fwd: per-graph fused BN + [n,H]x[H,64] MFMA GEMM + dense-block aggregation MFMA + "
@@ -277,13 +280,17 @@ def engine_roofline(trainer, batches, workload, iters=20):
                                             timed_launches_per_step=per_step)
     # GATConv layers (CausalGAT): scores + edge softmax + aggregation (forward), the five backward kernels
     # algorithmic bytes: z and the output once each, CSR slot + 3 logits-sized [E',K] passes (+3*E'*K*4)
-    for key, label in (("gat_fwd", "GATConv forward: k_gat_scores + k_gat_fwd (edge softmax, dropout, aggregation, bias, ReLU)"),
-                       ("gat_bwd", "GATConv backward: k_gat_bwd_dst / _src / datt_part (alpha recomputed)")):
+    def _sum_traffic(keys):
+        vals = [pmc.get(k, {}).get("bytes_per_launch") for k in keys]
+        return int(sum(vals)) if vals and all(v is not None for v in vals) else None
+    gat_traffic = {"gat_fwd": _sum_traffic(["k_gat_fwd"]), "gat_bwd": _sum_traffic(["k_gat_bwd_dst", "k_gat_bwd_src"])}
+    for key, label in (("gat_fwd", "GATConv forward: k_gat_fwd_fused (scores + online edge softmax + dropout + aggregation + bias + ReLU, one pass)"),
+                       ("gat_bwd", "GATConv backward: k_gat_bwd_dst_c / k_gat_bwd_src / k_gat_datt_part (alpha recomputed)")):
         if key in out:
             dur, work, per_step = out[key]
             ach = work / dur / 1e9
             roof["roofline_" + key] = dict(bound="hbm", kernel=label, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
-                                           traffic=None, avg_launch_us=dur * 1e6, algorithmic_bytes_per_launch=work,
+                                           traffic=gat_traffic.get(key), avg_launch_us=dur * 1e6, algorithmic_bytes_per_launch=work,
                                            timed_launches_per_step=per_step)
     return roof
 
