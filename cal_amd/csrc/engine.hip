@@ -26,6 +26,7 @@
 #include "engine_ggat.hpp"
 #include "engine_plan.hpp"
 #include "engine_attbwd.hpp"
+#include "engine_gin.hpp"
 
 namespace cal {
 
@@ -118,6 +119,9 @@ struct Engine {
     int F, H, C, L;
     int cat;                    // cat_or_add == "cat": the co readout takes cat(xc[perm], xo) [B, 2H] (model.py:65-69,153-154)
     int no_node_att, no_edge_att;   // without_node_attention / without_edge_attention: constant 0.5 masks (model.py:99-107)
+    int gin;                    // backbone of GINConv(Linear, BN, ReLU, Linear, ReLU) layers (CausalGIN, model.py:188-194)
+    int o_gin_w2[MAX_LAYERS], o_gin_b2[MAX_LAYERS];      // second Linear of every GIN layer (o_conv_w / o_conv_b: the first)
+    float *gagg, *gt1, *gy, *ones;   // GIN: per layer aggregation output, pre-BN activations, relu(BN(.)) [L][N,H]; ones [N]
     float loop_w;
     // bound buffers
     float *P, *G, *M1, *M2, *step, *lr;
@@ -214,7 +218,7 @@ CAL_EXPORT void cal_engine_destroy(void* h) {
     delete e;
 }
 
-CAL_EXPORT int64_t cal_engine_num_param_slots(void* h) { Engine* e = (Engine*)h; return 3 + 4 * e->L + 12 + 24; }
+CAL_EXPORT int64_t cal_engine_num_param_slots(void* h) { Engine* e = (Engine*)h; return 3 + (e->gin ? 6 : 4) * e->L + 12 + 24; }
 CAL_EXPORT int64_t cal_engine_num_bn(void* h) { return ((Engine*)h)->nbn; }
 
 // Bind the flat parameter / gradient / Adam-state buffers.
@@ -243,6 +247,7 @@ CAL_EXPORT int cal_engine_bind(void* h, float* P, float* G, float* M1, float* M2
     for (int i = 0; i < L; ++i) {
         bn_g[k] = (int)offs[s++]; bn_b[k] = (int)offs[s++]; bn_w[k] = H; ++k;
         e->o_conv_w[i] = (int)offs[s++]; e->o_conv_b[i] = (int)offs[s++];
+        if (e->gin) { e->o_gin_w2[i] = (int)offs[s++]; e->o_gin_b2[i] = (int)offs[s++]; }
     }
     e->o_eatt_w = (int)offs[s++]; e->o_eatt_b = (int)offs[s++];
     e->o_natt_w = (int)offs[s++]; e->o_natt_b = (int)offs[s++];
@@ -297,6 +302,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
         return std::max<size_t>(std::max<size_t>(512 * 64 * 64, (size_t)B * M * Nn), big) + 2 * M * Nn;
     };
     slab += slab_of(F, H) + (L + 2) * slab_of(H, H) + 2 * slab_of(H, H) + slab_of(H, 2 * H) + 3 * slab_of(C, H);
+    if (e->gin) slab += L * slab_of(H, H);            // two weight gradients per GIN layer
     if (e->K > 0) slab += L * (size_t)1024 * H;      // GATConv: <= 512 partial rows of d att [2H] per layer
     if (assign) e->slab_floats = slab;
     F32(e->slabs, slab);
@@ -319,6 +325,10 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     I32(e->eptr, B + 1);
     F32(e->coef, 3 * E);
     F32(e->wslot, 2 * E);
+    if (e->gin) {
+        const size_t Lg = L > 0 ? L : 1;
+        F32(e->gagg, Lg * N * H); F32(e->gt1, Lg * N * H); F32(e->gy, Lg * N * H); F32(e->ones, N);
+    }
     if (e->K > 0) {
         const size_t K = e->K;
         F32(e->gz, (L > 0 ? L : 1) * N * H); F32(e->gsc, (L > 0 ? L : 1) * 4 * al(N * K));
@@ -369,7 +379,7 @@ CAL_EXPORT int64_t cal_engine_buffer_offset(void* h, const char* name) {
         {"dl", e->dl}, {"dzco", e->dzco}, {"dXhco", e->dXhco}, {"dZ", e->dZ}, {"dzi", e->dzi}, {"dXh", e->dXh},
         {"arena", e->arena}, {"gptr", e->gptr}, {"status", e->status}, {"eptr", e->eptr},
         {"rowptr_dst", e->rowptr_dst}, {"nbr_dst", e->nbr_dst}, {"eid_dst", e->eid_dst},
-        {"rowptr_src", e->rowptr_src}, {"nbr_src", e->nbr_src}, {"eid_src", e->eid_src}, {"perm", e->perm_dev},
+        {"rowptr_src", e->rowptr_src}, {"nbr_src", e->nbr_src}, {"eid_src", e->eid_src}, {"perm", e->perm_dev}, {"ones", e->ones},
     };
     for (auto& t : tab)
         if (!strcmp(t.n, name)) return ((char*)t.p - e->ws) / 4;
@@ -655,6 +665,22 @@ static std::vector<const char*> g_stage_names;      // launch-site names of the 
 #define STAGE() do { if (g_stop_after == 0) g_stage_names.push_back(cal::g_last_launch); \
                      if (g_stop_after > 0 && ++g_stage >= g_stop_after) return -12345; } while (0)
 
+// launch helper of the row-wise GIN passes (engine_gin.hpp): mode 0 forward BN + ReLU, 1 masked BatchNorm-backward sums,
+// 2 BatchNorm backward behind the ReLU, 3 ReLU mask + column sums
+int gin_rows(Ctx& c, int mode, const GinRowArgs& ga) {
+    const int N = c.N, H = c.e->H;
+    hipStream_t st = c.st;
+    return with_g(H, [&](auto g) {
+        constexpr int G = decltype(g)::value;
+        const dim3 grid(cdiv(N, c.rpb_n));
+        if (mode == 0) hipLaunchKernelGGL((k_gin_rows<4, G, 0>), grid, dim3(256), 0, st, ga, N, H, c.rpb_n);
+        else if (mode == 1) hipLaunchKernelGGL((k_gin_rows<4, G, 1>), grid, dim3(256), 0, st, ga, N, H, c.rpb_n);
+        else if (mode == 2) hipLaunchKernelGGL((k_gin_rows<4, G, 2>), grid, dim3(256), 0, st, ga, N, H, c.rpb_n);
+        else hipLaunchKernelGGL((k_gin_rows<4, G, 3>), grid, dim3(256), 0, st, ga, N, H, c.rpb_n);
+        return 0;
+    });
+}
+
 int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int64_t* batch, const int64_t* y,
                    const int64_t* perm, float wc, float wo, float wco, int want_grad) {
     Engine* e = c.e;
@@ -700,7 +726,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         GemmArgs a = gemm_args(N, H, F, false, false, 1);
         a.p[0].A = x0; a.p[0].B = e->P + e->o_feat_w; a.p[0].C = e->h;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 1);
-        if (c.training && L > 0) gemm_stats(c, a.p[0], N, H, bn_stsum(c, 1), bn_stsq(c, 1), false, F);
+        if (c.training && L > 0 && !e->gin) gemm_stats(c, a.p[0], N, H, bn_stsum(c, 1), bn_stsq(c, 1), false, F);    // (a GIN layer starts with the aggregation, not a BatchNorm)
         RC(fwd_gemm(c, false, a, 1)); STAGE();
         RC(flush_finals(c)); STAGE();
     }
@@ -708,6 +734,42 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     const bool gc = use_gc(c);
     const bool gat = e->K > 0;
     for (int i = 1; i <= L; ++i) {
+        if (e->gin) {    // GINConv: unit-coefficient aggregation -> Linear -> BN -> ReLU -> Linear -> ReLU (model.py:188-194)
+            const float* hin = e->h + (size_t)(i - 1) * NH;
+            float* agg = e->gagg + (size_t)(i - 1) * NH;
+            float* t1 = e->gt1 + (size_t)(i - 1) * NH;
+            float* yy = e->gy + (size_t)(i - 1) * NH;
+            {
+                SpmmBranch br{hin, agg, nullptr, nullptr, e->ones, Acc(), Acc()};
+                RC(with_g(H, [&](auto g) {
+                    constexpr int G = decltype(g)::value;
+                    hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gd, br, br, 0, 1.0f, N, H, spmm_rpb(H, false));
+                    return 0;
+                }));
+                CAL_CHECK_LAUNCH("k_espmm(gin)"); STAGE();
+            }
+            {
+                GemmArgs a = gemm_args(N, H, H, false, true, 0);
+                a.p[0].A = agg; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].bias = e->P + e->o_conv_b[i - 1]; a.p[0].C = t1;
+                if (c.training) gemm_stats(c, a.p[0], N, H, bn_stsum(c, i), bn_stsq(c, i), false, H);
+                RC(fwd_gemm(c, true, a, 1)); STAGE();
+                RC(flush_finals(c)); STAGE();
+            }
+            {
+                GinRowArgs ga;
+                memset(&ga, 0, sizeof(ga));
+                ga.a = t1; ga.out = yy; ga.bn = bnref(c, i, N, 1);
+                RC(gin_rows(c, 0, ga));
+                CAL_CHECK_LAUNCH("k_gin_bn_relu"); STAGE();
+            }
+            {
+                GemmArgs a = gemm_args(N, H, H, false, true, 1);
+                a.p[0].A = yy; a.p[0].B = e->P + e->o_gin_w2[i - 1]; a.p[0].bias = e->P + e->o_gin_b2[i - 1];
+                a.p[0].C = e->h + (size_t)i * NH;
+                RC(fwd_gemm(c, true, a, 1)); STAGE();
+            }
+            continue;
+        }
         if (gat) {       // z = BN_i(h) W_i; attention scores, edge softmax (+dropout), aggregation, bias, ReLU (GATConv)
             const int K = e->K, D = H / K;
             float* zi = e->gz + (size_t)(i - 1) * NH;
@@ -1194,9 +1256,78 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     }
     bool feat_done = false;     // the per-graph feature-layer backward (k_feat_bwd) has run
     // Q. backbone layers, last to first
+    Deferred d_gin_b1[MAX_LAYERS];
+    memset(d_gin_b1, 0, sizeof(d_gin_b1));
     for (int i = L; i >= 1; --i) {
         float* dzi = e->dzi + (size_t)(i - 1) * NH;     // per layer: the side-stream dW GEMM reads it later
         const bool gat = e->K > 0;
+        if (e->gin) {
+            // GINConv backward (model.py:188-194 differentiated).  e->dZ holds dz2 = d h_i masked by h_i > 0 (its column sums,
+            // d b2, are already deferred): dW2 = dz2^T y, dy = dz2 W2, BatchNorm backward behind the ReLU -> dt1 (+ d b1),
+            // dW1 = dt1^T agg, dagg = dt1 W1, d h_{i-1} = dagg + A^T dagg, masked by h_{i-1} > 0 for the layer below
+            const float* agg = e->gagg + (size_t)(i - 1) * NH;
+            const float* t1 = e->gt1 + (size_t)(i - 1) * NH;
+            const float* yy = e->gy + (size_t)(i - 1) * NH;
+            {
+                GemmArgs a = gemm_args(H, H, N, true, false, 0);
+                a.p[0].A = e->dZ; a.p[0].B = yy;
+                float* dst[1] = {e->G + e->o_gin_w2[i - 1]};
+                RC(grad_gemm(c, a, 1, dst, fa, slab_off)); STAGE();
+            }
+            {
+                GemmArgs a = gemm_args(N, H, H, false, false, 0);
+                a.p[0].A = e->dZ; a.p[0].B = e->P + e->o_gin_w2[i - 1]; a.p[0].C = e->dXh;      // dy
+                RC(fwd_gemm(c, false, a, 1)); STAGE();
+            }
+            {
+                GinRowArgs ga;
+                memset(&ga, 0, sizeof(ga));
+                ga.a = e->dXh; ga.y = yy; ga.t1 = t1; ga.bn = bnref(c, i, N, 0);
+                ga.acc0 = node_acc(c, bn_dsum(c, i), H); ga.acc1 = node_acc(c, bn_dprod(c, i), H);
+                RC(gin_rows(c, 1, ga));
+                CAL_CHECK_LAUNCH("k_gin_dots"); STAGE();
+                RC(flush_finals(c)); STAGE();
+            }
+            {
+                GinRowArgs ga;
+                memset(&ga, 0, sizeof(ga));
+                ga.a = e->dXh; ga.y = yy; ga.t1 = t1; ga.out = dzi; ga.bn = bnref(c, i, N, 0);       // dt1
+                ga.dot_sum = bn_dsum(c, i); ga.dot_prod = bn_dprod(c, i);
+                ga.acc0 = deferred(H, d_gin_b1[i - 1]);
+                if (!ga.acc0.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
+                RC(gin_rows(c, 2, ga));
+                CAL_CHECK_LAUNCH("k_gin_bn_bwd"); STAGE();
+            }
+            {
+                GemmArgs a = gemm_args(H, H, N, true, false, 0);
+                a.p[0].A = dzi; a.p[0].B = agg;
+                float* dst[1] = {e->G + e->o_conv_w[i - 1]};
+                RC(grad_gemm(c, a, 1, dst, fa, slab_off)); STAGE();
+            }
+            {
+                GemmArgs a = gemm_args(N, H, H, false, false, 0);
+                a.p[0].A = dzi; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->dXh;            // dagg
+                RC(fwd_gemm(c, false, a, 1)); STAGE();
+            }
+            {
+                SpmmBranch br{e->dXh, e->z, nullptr, nullptr, e->ones, Acc(), Acc()};                // d h_{i-1}
+                RC(with_g(H, [&](auto g) {
+                    constexpr int G = decltype(g)::value;
+                    hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, br, br, 0, 1.0f, N, H, spmm_rpb(H, false));
+                    return 0;
+                }));
+                CAL_CHECK_LAUNCH("k_espmm(gin,T)"); STAGE();
+            }
+            {
+                GinRowArgs ga;
+                memset(&ga, 0, sizeof(ga));
+                ga.a = e->z; ga.y = e->h + (size_t)(i - 1) * NH; ga.out = e->dZ;                     // masked by h_{i-1} > 0
+                ga.acc0 = i >= 2 ? deferred(H, d_convb[i - 2]) : Acc();                                  // d b2 of the layer below
+                RC(gin_rows(c, 3, ga));
+                CAL_CHECK_LAUNCH("k_gin_mask"); STAGE();
+            }
+            continue;
+        }
         if (gat && gcb && (H / e->K == 32 || H / e->K == 64) && e->max_edges <= GGB_E) {
             // GATConv layer backward per graph (engine_ggat.hpp): attention backward + dX' (two slice partials) + dW / d att
             // slabs.  As in the GCNConv path below, layer i < L builds its dOut from layer i+1's partials while staging
@@ -1415,7 +1546,12 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     }
     for (int i = 0; i < L; ++i) {
         if (!d_convb[i].p) { set_error("engine: missing bias-gradient partials"); return 2; }
-        commit_p(d_convb[i].p, d_convb[i].P, d_convb[i].stride, e->o_conv_b[i], H, 1.f);
+        // GCNConv / GATConv: the layer's bias; GINConv: the bias of its second Linear (the first one's has its own sums)
+        commit_p(d_convb[i].p, d_convb[i].P, d_convb[i].stride, e->gin ? e->o_gin_b2[i] : e->o_conv_b[i], H, 1.f);
+        if (e->gin) {
+            if (!d_gin_b1[i].p) { set_error("engine: missing bias-gradient partials"); return 2; }
+            commit_p(d_gin_b1[i].p, d_gin_b1[i].P, d_gin_b1[i].stride, e->o_conv_b[i], H, 1.f);
+        }
     }
     commit_p(d_cb.p, d_cb.P, d_cb.stride, e->o_cb, H, 1.f);
     commit_p(d_ob.p, d_ob.P, d_ob.stride, e->o_ob, H, 1.f);
@@ -1611,6 +1747,16 @@ CAL_EXPORT int cal_engine_set_options(void* h, int cat, int no_node_att, int no_
     Engine* e = (Engine*)h;
     CAL_REQUIRE(e != nullptr, "bad arguments");
     e->cat = cat ? 1 : 0; e->no_node_att = no_node_att ? 1 : 0; e->no_edge_att = no_edge_att ? 1 : 0;
+    return 0;
+}
+// CausalGIN (model.py:166-264): the backbone layers are GINConv(Sequential(Linear, BatchNorm1d, ReLU, Linear, ReLU)) (model.py:188-194,
+// eps = 0): per layer the slots {nn.1.weight, nn.1.bias, nn.0.weight, nn.0.bias, nn.3.weight, nn.3.bias} replace the four of a
+// GCNConv layer in `offs`, and BatchNorm i of `bn_ptrs` is convs.(i-1).nn.1.  Call before cal_engine_bind.  The workspace buffer
+// "ones" ([N] floats) must hold 1.0 (unit aggregation coefficients).
+CAL_EXPORT int cal_engine_set_gin(void* h, int on) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e != nullptr && (!on || e->K == 0), "bad arguments");
+    e->gin = on ? 1 : 0;
     return 0;
 }
 // Random-intervention permutation drawn by the step itself (mode bit 16; model.py:147-152): keyed by (seed, *counter), the

@@ -10,8 +10,7 @@ memory), binds gradients / Adam state, owns the device workspace and exposes
 each as ONE C call that enqueues the fused kernels on torch's current stream
 (hipGraph-capturable).  ``supported(model)`` says what is covered: CausalGCN and
 CausalGAT, ``cat_or_add`` "add" or "cat", with or without the node / edge
-attention (``opts.get_model``'s causal variants except CausalGIN, which stays
-on the operator-level path of ``cal_amd.model``).
+attention and CausalGIN (every causal variant ``opts.get_model`` builds).
 """
 from __future__ import annotations
 
@@ -33,12 +32,17 @@ def _gat_heads(model) -> int:
     return int(convs[0].heads) if convs and isinstance(convs[0], GATConv) else 0
 
 
+def _is_gin(model) -> bool:
+    from .model import CausalGIN
+    return isinstance(model, CausalGIN)
+
+
 def supported(model) -> bool:
-    from .model import CausalGCN, CausalGAT
+    from .model import CausalGCN, CausalGAT, CausalGIN, GINConv
     from .gcn_conv import GCNConv
     a = model.args
     h = a.hidden
-    if not (isinstance(model, (CausalGCN, CausalGAT)) and a.cat_or_add in ("add", "cat")
+    if not (isinstance(model, (CausalGCN, CausalGAT, CausalGIN)) and a.cat_or_add in ("add", "cat")
             and h % 4 == 0 and h <= 256 and a.layers <= 6 and model.num_classes <= 64):
         return False
     # the engine hard-wires the normalised, non-improved GCNConv with a bias (gcn_conv.py:72-92 defaults): a model
@@ -53,13 +57,21 @@ def supported(model) -> bool:
         d = h // k if k else 0
         return (k > 0 and h % k == 0 and d % 4 == 0 and (d // 4) & (d // 4 - 1) == 0
                 and all(c.heads == k and c.bias is not None for c in model.convs))
+    if isinstance(model, CausalGIN):
+        # GINConv(Sequential(Linear, BatchNorm1d, ReLU, Linear, ReLU)), eps = 0 (model.py:188-194)
+        return all(isinstance(c, GINConv) and c.initial_eps == 0.0 and len(c.nn) == 5 and c.nn[0].bias is not None
+                   and c.nn[3].bias is not None for c in model.convs)
     return True
 
 
-def _slot_names(layers: int):
+def _slot_names(layers: int, gin: bool = False):
     names = ["bn_feat.weight", "bn_feat.bias", "conv_feat.weight"]
     for i in range(layers):
-        names += [f"bns_conv.{i}.weight", f"bns_conv.{i}.bias", f"convs.{i}.weight", f"convs.{i}.bias"]
+        if gin:     # cal_engine_set_gin: BatchNorm, first Linear, second Linear of GINConv's Sequential (model.py:189-194)
+            names += [f"convs.{i}.nn.1.weight", f"convs.{i}.nn.1.bias", f"convs.{i}.nn.0.weight", f"convs.{i}.nn.0.bias",
+                      f"convs.{i}.nn.3.weight", f"convs.{i}.nn.3.bias"]
+        else:
+            names += [f"bns_conv.{i}.weight", f"bns_conv.{i}.bias", f"convs.{i}.weight", f"convs.{i}.bias"]
     names += ["edge_att_mlp.weight", "edge_att_mlp.bias", "node_att_mlp.weight", "node_att_mlp.bias",
               "bnc.weight", "bnc.bias", "bno.weight", "bno.bias",
               "context_convs.weight", "context_convs.bias", "objects_convs.weight", "objects_convs.bias"]
@@ -110,7 +122,7 @@ class StepEngine:
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.0, flat=None):
         if not supported(model):
-            raise ValueError("StepEngine covers CausalGCN / CausalGAT (hidden % 4 == 0, <= 256, <= 6 layers, <= 64 classes)")
+            raise ValueError("StepEngine covers CausalGCN / CausalGAT / CausalGIN (hidden % 4 == 0, <= 256, <= 6 layers, <= 64 classes)")
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise _lib.CalError("StepEngine needs the model on the GPU (no CPU fallback)")
@@ -133,17 +145,21 @@ class StepEngine:
         _lib.call("cal_engine_set_options", self._h, int(a.cat_or_add == "cat"),
                   int(bool(getattr(model, "without_node_attention", False))),
                   int(bool(getattr(model, "without_edge_attention", False))))
+        self.gin = _is_gin(model)
+        if self.gin:
+            _lib.call("cal_engine_set_gin", self._h, 1)
         # parameter offsets in slot order
         base = self.flat_p.data_ptr()
         params = dict(model.named_parameters())
         offs = []
-        for n in _slot_names(self.L):
+        for n in _slot_names(self.L, self.gin):
             p = params[n]
             off = (p.data_ptr() - base) // 4
             assert 0 <= off and off + p.numel() <= self.flat_p.numel(), n
             offs.append(off)
         assert len(offs) == _lib.query("cal_engine_num_param_slots", self._h)
-        bns = [model.bn_feat] + list(model.bns_conv) + [getattr(model, n) for n in _BN_ORDER_TAIL]
+        backbone_bns = [c.nn[1] for c in model.convs] if self.gin else list(model.bns_conv)
+        bns = [model.bn_feat] + backbone_bns + [getattr(model, n) for n in _BN_ORDER_TAIL]
         ptrs = []
         for bn in bns:
             ptrs += [bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()]
@@ -213,6 +229,8 @@ class StepEngine:
         _lib.call("cal_engine_set_workspace", self._h, _p(self._ws), nbytes, N, E, B)
         self._cap = (N, E, B)
         self.buffer("status", 4, torch.int32).zero_()       # [0] = latest step, [1] = sticky OR of the earlier steps
+        if self.gin:
+            self.buffer("ones", N).fill_(1.0)                 # unit aggregation coefficients of the GINConv layers
 
     _STATUS_BITS = ((1, "edge_index has entries outside [0, num_nodes)"),
                     (2, "batch vector is not sorted / has ids outside [0, num_graphs), or ptr / edge_ptr do not match it"),

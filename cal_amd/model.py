@@ -79,7 +79,7 @@ class _CausalBase(torch.nn.Module):
 
     def _engine_for(self, x):
         from . import engine as eng_mod
-        if not (self.use_engine and x.is_cuda and isinstance(self, (CausalGCN, CausalGAT)) and eng_mod.supported(self)):
+        if not (self.use_engine and x.is_cuda and isinstance(self, (CausalGCN, CausalGAT, CausalGIN)) and eng_mod.supported(self)):
             return None
         eng = getattr(self, "_engine", None)
         p0 = next(self.parameters())

@@ -155,6 +155,10 @@ CAL_API void cal_engine_destroy(void* engine);
 /* model variants (model.py:24-31,65-69,99-107): cat = cat_or_add "cat" (fc1_bn_co / fc1_co are 2H wide), no_node_att / no_edge_att =
  * without_node_attention / without_edge_attention (constant 0.5 masks).  Call before cal_engine_bind. */
 CAL_API int cal_engine_set_options(void* engine, int cat, int no_node_att, int no_edge_att);
+/* CausalGIN (model.py:166-264): GINConv(Sequential(Linear, BatchNorm1d, ReLU, Linear, ReLU)) backbone layers (model.py:188-194); per
+ * layer the `offs` slots are {nn.1.weight, nn.1.bias, nn.0.weight, nn.0.bias, nn.3.weight, nn.3.bias}, BatchNorm i of `bn_ptrs` is
+ * convs.(i-1).nn.1; the workspace buffer "ones" ([N] floats) must hold 1.0.  Call before cal_engine_bind. */
+CAL_API int cal_engine_set_gin(void* engine, int on);
 CAL_API int64_t cal_engine_num_param_slots(void* engine);
 CAL_API int64_t cal_engine_num_bn(void* engine);
 CAL_API int cal_engine_bind(void* engine, float* P, float* G, float* M1, float* M2, float* step,

@@ -13,7 +13,7 @@ for w in ba5000_causalgat_h256_l3_bs32 ba5000_causalgcn_h256_l3_bs32; do
     python scripts/pmc_traffic.py gpurun_out/$tag/pmc_FETCH_SIZE_$w.json gpurun_out/$tag/pmc_WRITE_SIZE_$w.json $w > gpurun_out/$tag/pmc_traffic_$w.json
     cp gpurun_out/$tag/pmc_traffic_$w.json profiles/pmc_traffic_$w.json
 done
-for w in spmotif_b0.9_causalgcn_nodenum15_bs32 spmotif_b0.9_causalgat_h128_l3_bs128 mutaglike_causalgat_h128_l3_bs64 nci1like_causalgcn_h128_l3_bs512 ba5000_causalgcn_h256_l3_bs32 ba5000_causalgat_h256_l3_bs32; do
+for w in spmotif_b0.9_causalgcn_nodenum15_bs32 spmotif_b0.9_causalgat_h128_l3_bs128 spmotif_b0.9_causalgin_h128_l3_bs128 mutaglike_causalgat_h128_l3_bs64 nci1like_causalgcn_h128_l3_bs512 ba5000_causalgcn_h256_l3_bs32 ba5000_causalgat_h256_l3_bs32; do
     python bench.py --workload $w --steps 100 --warmup 10 --batches 4 --no-e2e --cpu-seconds 8 > gpurun_out/$tag/bench_$w.json 2> gpurun_out/$tag/bench_$w.err
 done
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
