@@ -689,7 +689,8 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     hipStream_t st = c.st;
     const size_t NH = (size_t)N * H;
     // per-graph plan (engine_plan.hpp) when the host vouches for the batch layout
-    const bool fast_plan = e->node_ptr && e->edge_ptr && B > 0 && e->max_nodes > 0 && e->max_nodes <= GP_T && e->max_edges <= GP_E;
+    const bool fast_plan = e->node_ptr && e->edge_ptr && B > 0 && e->max_nodes > 0 && e->max_nodes <= GP_T2 && e->max_edges <= GP_E2;
+    const bool wide_plan = fast_plan && (e->max_nodes > GP_T || e->max_edges > GP_E);
     const bool plan_stats = fast_plan && c.training && F <= 64;      // bn_feat's statistics ride in k_plan_graph
     // 0. zero the fp64 arena and the GraphPlan counters (one kernel, not memset nodes)
     {
@@ -701,7 +702,8 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     }
     // 1. GraphPlan
     if (fast_plan) {
-        hipLaunchKernelGGL(k_plan_graph, dim3(B), dim3(256), 0, st, edge_index, E, N, B, e->node_ptr, e->edge_ptr, batch, e->loop_w,
+        auto kern = wide_plan ? k_plan_graph<GP_T2, GP_E2> : k_plan_graph<GP_T, GP_E>;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(256), 0, st, edge_index, E, N, B, e->node_ptr, e->edge_ptr, batch, e->loop_w,
                            e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src, e->row32, e->col32,
                            e->gptr, e->eptr, e->dis_unit, e->status, plan_stats ? x0 : nullptr, F, bn_stsum(c, 0), bn_stsq(c, 0));
         CAL_CHECK_LAUNCH("k_plan_graph"); STAGE();

@@ -16,9 +16,12 @@
 
 namespace cal {
 
-constexpr int GP_T = 128;                 // nodes per graph
+constexpr int GP_T = 128;                 // nodes per graph (the per-graph attention / conv kernels' LDS arrays)
 constexpr int GP_E = 1024;                // edges per graph
+constexpr int GP_T2 = 256;                // the wider instantiation of k_plan_graph (SPMotif at the reference's default
+constexpr int GP_E2 = 2048;               // node_num = 15: up to ~250 nodes per graph)
 
+template <int GT, int GE>
 __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ ei, int64_t E, int N, int B,
                                                     const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr,
                                                     const int64_t* __restrict__ batch, float loop_w,
@@ -31,9 +34,11 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     // x0 != null: also the column sums / sums of squares of the raw features (bn_feat's batch statistics, model.py:90;
     // F <= 64), pre-reduced per graph in LDS and added to the zeroed accumulators with F fp64 atomics per workgroup
     __shared__ double fs[2][64];
-    __shared__ int deg_in[GP_T], deg_out[GP_T], off_in[GP_T + 1], off_out[GP_T + 1], cur_in[GP_T], cur_out[GP_T];
-    __shared__ short rl[GP_E], cl[GP_E];                 // local endpoints of the graph's edges (edge-id order)
-    __shared__ short tn_d[GP_E], te_d[GP_E], tn_s[GP_E], te_s[GP_E];     // unordered row contents: neighbour, local edge id
+    constexpr int EU = GE / 256;                         // edges per lane
+    constexpr int SU = GT / 64;                          // scan elements per lane
+    __shared__ int deg_in[GT], deg_out[GT], off_in[GT + 1], off_out[GT + 1], cur_in[GT], cur_out[GT];
+    __shared__ short rl[GE], cl[GE];                     // local endpoints of the graph's edges (edge-id order)
+    __shared__ short tn_d[GE], te_d[GE], tn_s[GE], te_s[GE];             // unordered row contents: neighbour, local edge id
     const int b = blockIdx.x, t = threadIdx.x;
     const int g0 = (int)node_ptr[b], rows = (int)node_ptr[b + 1] - g0;
     const int64_t e0 = edge_ptr[b];
@@ -44,17 +49,17 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
         if (b == B - 1 && (g0 + rows != N || e0 + m != E)) atomicOr(status, 2);
         if (b == 0 && (g0 != 0 || e0 != 0)) atomicOr(status, 2);
     }
-    if (rows < 0 || rows > GP_T || m < 0 || m > GP_E) { if (t == 0) atomicOr(status, 8); return; }
-    // edges: 4 per lane, both endpoints requested before anything waits
-    int64_t rv[4], cv[4];
+    if (rows < 0 || rows > GT || m < 0 || m > GE) { if (t == 0) atomicOr(status, 8); return; }
+    // edges: EU per lane, both endpoints requested before anything waits
+    int64_t rv[EU], cv[EU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < EU; ++u) {
         const int64_t e = e0 + max(min(t + u * 256, m - 1), 0);
         rv[u] = m > 0 ? ei[e] : 0;
         cv[u] = m > 0 ? ei[E + e] : 0;
     }
     const int64_t bv = rows > 0 ? batch[g0 + min(t, rows - 1)] : (int64_t)b;
-    if (t < GP_T) { deg_in[t] = 0; deg_out[t] = 0; cur_in[t] = 0; cur_out[t] = 0; }
+    if (t < GT) { deg_in[t] = 0; deg_out[t] = 0; cur_in[t] = 0; cur_out[t] = 0; }
     if (t < 128) fs[t >> 6][t & 63] = 0.0;
     __syncthreads();
     if (x0) {
@@ -73,7 +78,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     }
     if (t < rows && bv != b) atomicOr(status, 2);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < EU; ++u) {
         const int s = t + u * 256;
         if (s < m) {
             int r = (int)(rv[u] - g0), c = (int)(cv[u] - g0);
@@ -87,22 +92,24 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
         }
     }
     __syncthreads();
-    // exclusive scans of the two degree arrays: waves 0 / 1, rows <= 128 = two elements per lane
+    // exclusive scans of the two degree arrays: waves 0 / 1, SU consecutive elements per lane
     if (t < 128) {
         const int* deg = t < 64 ? deg_in : deg_out;
         int* off = t < 64 ? off_in : off_out;
         const int l = t & 63;
-        const int a0 = 2 * l < rows ? deg[2 * l] : 0, a1 = 2 * l + 1 < rows ? deg[2 * l + 1] : 0;
-        int x = a0 + a1;
+        int a[SU], x = 0;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) { a[u] = SU * l + u < rows ? deg[SU * l + u] : 0; x += a[u]; }
+        const int own = x;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int y = __shfl_up(x, o, 64);
             if (l >= o) x += y;
         }
-        const int ex = x - a0 - a1;
-        if (2 * l <= rows) off[2 * l] = ex;
-        if (2 * l + 1 <= rows) off[2 * l + 1] = ex + a0;
-        if (l == 63) off[rows] = x;                      // the total (rows == 128 has no lane for it above)
+        int ex = x - own;
+#pragma unroll
+        for (int u = 0; u < SU; ++u) { if (SU * l + u <= rows) off[SU * l + u] = ex; ex += a[u]; }
+        if (l == 63) off[rows] = x;                      // the total (rows == GT has no lane for it above)
     }
     __syncthreads();
     if (x0 && t < F) { atomicAdd(st_sum + t, fs[0][t]); atomicAdd(st_sq + t, fs[1][t]); }
@@ -114,7 +121,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     }
     // scatter into the rows (arbitrary order inside a row) ...
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < EU; ++u) {
         const int s = t + u * 256;
         if (s < m) {
             const int r = rl[s], c = cl[s];
