@@ -26,6 +26,7 @@
 #include "engine_ggat.hpp"
 #include "engine_plan.hpp"
 #include "engine_attbwd.hpp"
+#include "engine_ro_step.hpp"
 #include "engine_gin.hpp"
 
 namespace cal {
@@ -140,12 +141,13 @@ struct Engine {
     BNSlot bn[MAX_LAYERS + 9];
     int nbn;
     // arena offsets (doubles)
-    int a_convb[MAX_LAYERS], a_cb, a_ob, a_dwn, a_dwe, a_db1, a_db2, arena_n;
+    int a_convb[MAX_LAYERS], a_cb, a_ob, a_dwn, a_dwe, a_db1, a_db2, a_sync, arena_n;
     // workspace
     char* ws; size_t ws_bytes;
     int64_t capN, capE, capB;
     // float regions
-    float *h, *z, *zco, *hco, *anode, *pq, *att, *dis_unit, *dis_co, *pooled, *xco, *y1, *zl, *logp, *stats;
+    float *h, *z, *zco, *hco, *anode, *pq, *att, *dis_unit, *dis_co, *pooled, *xco, *y1, *zl, *logp, *stats, *zpart;
+    int ro_step;             // 1: training steps run the readout as one launch (k_ro_step); CAL_AMD_RO_STEP=0 keeps the four kernels
     float *dzl, *dyh1, *dy1, *dxh, *dpool, *dZco, *gn, *gself, *ddeg, *dl, *dzco, *dXhco, *dZ, *dzi, *dXh, *slabs;
     size_t slab_floats;
     double* arena;
@@ -198,6 +200,7 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     }
     Engine* e = new Engine();
     memset(e, 0, sizeof(Engine));
+    { const char* v = getenv("CAL_AMD_RO_STEP"); e->ro_step = !(v && v[0] == '0'); }
     e->F = (int)F; e->H = (int)H; e->C = (int)C; e->L = (int)L;
     e->loop_w = 1.f;
     e->grad_scale = 1.f;
@@ -276,6 +279,7 @@ CAL_EXPORT int cal_engine_bind(void* h, float* P, float* G, float* M1, float* M2
     e->a_dwe = a; a += 2 * H + 4;
     e->a_db1 = a; a += 3 * H;
     e->a_db2 = a; a += (3 * C + 3) / 4 * 4;
+    e->a_sync = a; a += 4;                            // 6 barrier counters of k_ro_step (ints), zeroed with the arena
     e->arena_n = a;
     (void)C;
     return 0;
@@ -289,7 +293,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     F32(e->h, (L + 1) * N * H); F32(e->z, N * H); F32(e->zco, 2 * N * H); F32(e->hco, 2 * N * H);
     F32(e->anode, 2 * N); F32(e->pq, 4 * N); F32(e->att, 2 * E); F32(e->dis_unit, N); F32(e->dis_co, 2 * N);
     F32(e->pooled, 2 * B * H); F32(e->xco, 2 * B * H); F32(e->y1, 3 * B * H); F32(e->zl, 3 * B * C); F32(e->logp, 3 * B * C);
-    F32(e->stats, 8);
+    F32(e->stats, 8); F32(e->zpart, 3 * ((H + 15) / 16) * B * C);
     F32(e->dzl, 3 * B * C); F32(e->dyh1, 3 * B * H); F32(e->dy1, 3 * B * H); F32(e->dxh, 4 * B * H); F32(e->dpool, 2 * B * H);
     F32(e->dZco, 2 * N * H); F32(e->gn, 4 * E); F32(e->gself, 4 * N); F32(e->ddeg, 2 * N); F32(e->dl, E);
     F32(e->dzco, 2 * N * H); F32(e->dXhco, 2 * N * H); F32(e->dZ, N * H); F32(e->dzi, (L > 0 ? L : 1) * N * H); F32(e->dXh, N * H);
@@ -399,6 +403,7 @@ struct Ctx {
     const int64_t* y; const int64_t* perm; float wc, wo, wco; int want_grad;
     int draw_perm;      // the step draws its own intervention permutation (first kernel) into Engine::perm_dev
     int tick_in_finish; // the step ends with the Adam update: k_finish advances the step counter
+    int ro_done;        // the forward's k_ro_step already ran the readout backward
     size_t parts_off;   // bump allocator over Engine::parts
     FinalArgs fin;      // pending k_stats_final tasks
 };
@@ -940,6 +945,15 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         STAGE();
     }
     // 10. readouts (model.py:125-164)
+    if (use_ro(c) && want_grad && c.training && B <= RS_B && H <= RS_K && e->ro_step) {
+        // the whole readout, forward and backward, in one launch (engine_ro_step.hpp)
+        RoStepArgs sa;
+        sa.a = make_ro(c); sa.zpart = e->zpart; sa.sync = reinterpret_cast<int*>(e->arena + e->a_sync);
+        hipLaunchKernelGGL(k_ro_step, dim3(3, H / RO_CW), dim3(256), 0, st, sa);
+        CAL_CHECK_LAUNCH("k_ro_step"); STAGE();
+        c.ro_done = 1;
+        return 0;
+    }
     if (use_ro(c)) {
         const RoArgs ra = make_ro(c);
         hipLaunchKernelGGL(k_ro_fwd_a, dim3(3, H / RO_CW), dim3(256), 0, st, ra);
@@ -1030,11 +1044,13 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
 
     const bool ro = use_ro(c);
     if (ro) {
-        const RoArgs ra = make_ro(c);
-        hipLaunchKernelGGL(k_ro_bwd_a, dim3(3, H / RO_CW), dim3(256), 0, st, ra);
-        CAL_CHECK_LAUNCH("k_ro_bwd_a"); STAGE();
-        hipLaunchKernelGGL(k_ro_bwd_b, dim3(3, H / RO_CW), dim3(256), 0, st, ra);
-        CAL_CHECK_LAUNCH("k_ro_bwd_b"); STAGE();
+        if (!c.ro_done) {
+            const RoArgs ra = make_ro(c);
+            hipLaunchKernelGGL(k_ro_bwd_a, dim3(3, H / RO_CW), dim3(256), 0, st, ra);
+            CAL_CHECK_LAUNCH("k_ro_bwd_a"); STAGE();
+            hipLaunchKernelGGL(k_ro_bwd_b, dim3(3, H / RO_CW), dim3(256), 0, st, ra);
+            CAL_CHECK_LAUNCH("k_ro_bwd_b"); STAGE();
+        }
         fa.stats = e->stats; fa.wc = c.wc; fa.wo = c.wo; fa.wco = c.wco;
     }
     // R1. dW2_h = dz_h^T @ BN2(y1_h)
@@ -1606,6 +1622,7 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     c.parts_off = 0;
     c.fin.nt = 0;
     c.nfork = 0;
+    c.ro_done = 0;
     const int want_grad = (mode & 2) ? 1 : 0;
     c.draw_perm = (mode & 16) ? 1 : 0;
     CAL_REQUIRE(!c.draw_perm || (e->perm_ctr && B <= ZP_CAP), "mode bit 16 needs cal_engine_set_perm_rng and at most 1024 graphs per batch");
@@ -1653,7 +1670,7 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
     c.rpb_b = std::max(32, cdiv(B, 64));
     c.parts_off = 0; c.fin.nt = 0; c.nfork = 0;
     c.y = nullptr; c.perm = nullptr; c.wc = c.wo = c.wco = 0.f; c.want_grad = 1;
-    c.tick_in_finish = 0; c.draw_perm = 0;
+    c.tick_in_finish = 0; c.draw_perm = 0; c.ro_done = 0;
     hipLaunchKernelGGL(k_logsoftmax_bwd, dim3(1), dim3(256), 0, c.st, e->logp, dlogp, e->dzl, e->arena + e->a_db2, (int)B, e->C);
     CAL_CHECK_LAUNCH("k_logsoftmax_bwd");
     g_stage = 0;

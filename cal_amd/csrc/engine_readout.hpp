@@ -116,6 +116,21 @@ __device__ __forceinline__ void ro_commit(RoBatch<T, U>& bt, int rows, int cols,
     }
 }
 
+// two batches over the same item grid, committed together: st(row, col, v1, v2)
+template <int NT = 256, class T, int U, class StoreF>
+__device__ __forceinline__ void ro_commit2(RoBatch<T, U>& b1, RoBatch<T, U>& b2, int rows, int cols, StoreF st) {
+    const int total = rows * cols, q = NT / cols, r = NT % cols;
+    int row = (int)threadIdx.x / cols, col = (int)threadIdx.x % cols;
+#pragma unroll
+    for (int u = 0; u < U; ++u) { ro_pin(b1.v[u]); ro_pin(b2.v[u]); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if ((int)threadIdx.x + u * NT < total) st(row, col, b1.v[u], b2.v[u]);
+        row += q; col += r;
+        if (col >= cols) { col -= cols; ++row; }
+    }
+}
+
 __device__ __forceinline__ float dot4(const float4 a, const float4 b, float acc) {
     return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, fmaf(a.x, b.x, acc))));
 }

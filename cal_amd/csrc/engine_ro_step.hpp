@@ -1,0 +1,436 @@
+// The whole readout of a training step -- the four kernels of engine_readout.hpp (model.py:125-164, the three-term
+// loss of train_causal.py:176-183 and their backward) -- as ONE launch, for B <= 128 graphs and H <= 128.
+//
+// The four kernels are 24 workgroups each and exchange [B,H]-sized tiles through HBM; what they cost is three kernel
+// boundaries and, in every one of them, a first round of loads from buffers another XCD just wrote (45 us of a 287 us
+// step for 25 MFLOP).  Here the 24 workgroups stay resident and meet at two barriers per head instead:
+//   grid (3 heads, H/16 chunks), 256 threads, one workgroup per CU (133 KB of LDS) -- all co-resident by
+//   construction (24 <= 256 CUs and nothing else runs on the stream), which is what makes a spin barrier legal.
+//   A  (k_ro_fwd_a)  x_co = xc[perm] + xo, BN1 of all columns, y1[:, chunk] = relu(BN1(x) W1[chunk]^T + b1), BN2 of the
+//                    chunk (column-local), and the chunk's PARTIAL logits zp = BN2(y1)[:, chunk] W2[:, chunk]^T
+//   -- barrier 1 of the head: the H/16 partial logit tiles ([B,C] each) are the only exchange --
+//   B  (k_ro_fwd_b + k_ro_bwd_a)  every workgroup sums the partials in chunk order (all of them get the same bits),
+//                    log_softmax / loss / dz for all B graphs (redundantly: B*C values), then fc2 + BN2 + ReLU backward
+//                    of its chunk: dy1[:, chunk], d W2[:, chunk], d b1, BN2's d gamma / d beta sums
+//   -- barrier 2 of the head: dy1 chunks --
+//   C  (k_ro_bwd_b)  over INPUT columns: d(BN1 out)[:, chunk] = dy1 W1[:, chunk], BN1 backward -> dxin chunk, d W1[:, chunk]
+// Barriers: one counter per (head, barrier) in the step's zeroed fp64 arena; arrive = workgroup barrier + agent-scope
+// release increment by lane 0, wait = acquire spin by lane 0 + workgroup barrier + agent-scope acquire fence (the
+// partner may sit on another XCD, whose L2 is not coherent with ours: the release writes the stores back, the acquire
+// drops our stale lines).
+#pragma once
+#include "engine_readout.hpp"
+
+namespace cal {
+
+constexpr int RS_B = 128;                 // graphs
+constexpr int RS_K = 128;                 // hidden width
+constexpr int RS_LD = RS_K + 4;           // row stride of the [B][K] tile and of the weight chunks
+
+struct RoStepArgs {
+    RoArgs a;
+    float* zpart;                         // [3][H/16][B*C] partial logits
+    int* sync;                            // [3][2] barrier counters (zero at the start of the step)
+};
+
+__device__ __forceinline__ void ro_step_arrive(int* ctr) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every wave: its global stores are written back past our L2
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ro_step_wait(int* ctr, int n) {
+    if (threadIdx.x == 0)
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void ro_step_barrier(int* ctr, int n) {
+    ro_step_arrive(ctr);
+    ro_step_wait(ctr, n);
+}
+__global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
+    const RoArgs& a = sa.a;
+    __shared__ __attribute__((aligned(16))) float Xs[RS_B * RS_LD];         // raw input rows; phase C: dy1 rows
+    __shared__ __attribute__((aligned(16))) float Ws[RO_CW * RS_LD];        // W1[j0 + j][:]
+    __shared__ __attribute__((aligned(16))) float W1t[RO_CW * RS_LD];       // W1[:, j0 + i] stored [i][j]
+    __shared__ __attribute__((aligned(16))) float scratch[2 * RS_B * RO_CW];// phase A: 8 x 256 doubles; phase B: dyh | yn
+    __shared__ __attribute__((aligned(16))) float xn[RS_B * RO_CW];         // input chunk [B][16] (raw -> BN1 output)
+    __shared__ __attribute__((aligned(16))) float y1c[RS_B * RO_CW];        // relu(fc1) chunk [B][16] (raw)
+    __shared__ __attribute__((aligned(16))) float zs[2048];                 // logits -> dz, [B][C]
+    __shared__ __attribute__((aligned(16))) float W2c[64 * RO_CW];          // W2[c][j0 + j]
+    __shared__ float sc_s[RS_K], sh_s[RS_K], mean1_s[RS_K], rstd1_s[RS_K];
+    __shared__ int perm_s[256];
+    __shared__ double red[2][256];
+    __shared__ float c2[6][RO_CW];             // BN2 of the chunk: mean, rstd, gamma, beta; m1, m2 of a BatchNorm backward
+    const int hd = blockIdx.x, ch = blockIdx.y, j0 = ch * RO_CW, nch = gridDim.y;
+    const int B = a.B, K = a.H, C = a.C, ld = RS_LD, K4 = K / 4, BC = B * C;
+    const RoHead& h = a.h[hd];
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, j = l & 15, lk = l >> 4;     // j == threadIdx.x % 16
+    const int rl = threadIdx.x / RO_CW;
+    float* dyh = scratch;
+    float* yn = scratch + RS_B * RO_CW;
+    double (*red8)[256] = reinterpret_cast<double (*)[256]>(scratch);
+    const int B16 = (B + 15) & ~15, ntiles = B16 / 16;
+    // the per-head extras are spread over the chunks (the barriers wait for the slowest workgroup of the head)
+    const bool duty_out = ch == 1 % nch, duty_loss = ch == 2 % nch, duty_db2 = ch == 3 % nch,
+               duty_xco = ch == 4 % nch, duty_run1 = ch == 5 % nch;
+
+    RO_CLK(40);
+    // =============================== A: fc1 forward of the chunk ===============================================
+    const bool colfix = 256 % K4 == 0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    auto add_stats = [&](const float4 v) {
+        s[0] += (double)v.x; q[0] += (double)v.x * (double)v.x; s[1] += (double)v.y; q[1] += (double)v.y * (double)v.y;
+        s[2] += (double)v.z; q[2] += (double)v.z * (double)v.z; s[3] += (double)v.w; q[3] += (double)v.w * (double)v.w;
+    };
+    // Loads of the kernel's first round.  The co head gathers xc[perm]: its perm entry is requested FIRST (loads return in
+    // order: asked for behind the tiles it arrived after all of them, and the gather was a second full round, 6.9 us to
+    // 41), the weight chunks go out behind it, and the input rows and the gathered rows follow once it is here.
+    int pv = hd == 2 ? (int)a.perm[min((int)threadIdx.x, B - 1)] : 0;
+    float g2 = h.bn2.gamma[j0 + j], b2n = h.bn2.beta[j0 + j], rm2 = h.bn2.run_mean[j0 + j], rv2 = h.bn2.run_var[j0 + j];
+    float bias1 = h.b1[j0 + j];
+    float rm1 = h.bn1.run_mean[min((int)threadIdx.x, K - 1)], rv1 = h.bn1.run_var[min((int)threadIdx.x, K - 1)];
+    int ylab = (int)a.y[min((int)threadIdx.x, B - 1)];
+    {
+        RoBatch<float4, 2> bw;
+        RoBatch<float, 8> bt;
+        RoBatch<float, 4> bw2;
+        ro_issue(bw, RO_CW, K4, [&](int jj, int c) { return *reinterpret_cast<const float4*>(h.W1 + (size_t)(j0 + jj) * K + c * 4); });
+        ro_issue(bt, K, RO_CW, [&](int jj, int ii) { return h.W1[(size_t)jj * K + j0 + ii]; });
+        ro_issue(bw2, C, RO_CW, [&](int c, int jj) { return h.W2[(size_t)c * K + j0 + jj]; });
+        auto commit_weights = [&]() {
+            ro_commit(bw, RO_CW, K4, [&](int jj, int c, const float4 v) { *reinterpret_cast<float4*>(Ws + jj * ld + c * 4) = v; });
+            ro_commit(bt, K, RO_CW, [&](int jj, int ii, float v) { W1t[ii * ld + jj] = v; });
+            ro_commit(bw2, C, RO_CW, [&](int c, int jj, float v) { W2c[c * RO_CW + jj] = v; });
+            asm volatile("" : "+v"(g2), "+v"(b2n), "+v"(rm2), "+v"(rv2), "+v"(bias1), "+v"(ylab), "+v"(rm1), "+v"(rv1));
+        };
+        RoBatch<float4, 16> bx;
+        if (hd == 2) {
+            asm volatile("" : "+v"(pv));
+            perm_s[threadIdx.x] = pv;
+            __syncthreads();
+            RoBatch<float4, 16> bp;
+            ro_issue(bx, B, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(a.pooled + (size_t)(B + b) * K + c * 4); });
+            ro_issue(bp, B, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(a.pooled + (size_t)perm_s[b] * K + c * 4); });
+            commit_weights();
+            ro_commit2(bx, bp, B, K4, [&](int b, int c, const float4 o, const float4 p) {
+                const float4 v = make_float4(p.x + o.x, p.y + o.y, p.z + o.z, p.w + o.w);
+                *reinterpret_cast<float4*>(Xs + b * ld + c * 4) = v;
+                if (colfix) add_stats(v);
+                if (duty_xco) *reinterpret_cast<float4*>(a.xco + (size_t)b * K + c * 4) = v;
+            });
+            if (duty_xco && (int)threadIdx.x < B) a.iperm[pv] = threadIdx.x;
+        } else {
+            const float* src = a.pooled + (hd == 0 ? (size_t)0 : (size_t)B * K);
+            ro_issue(bx, B, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(src + (size_t)b * K + c * 4); });
+            commit_weights();
+            ro_commit(bx, B, K4, [&](int b, int c, const float4 v) {
+                *reinterpret_cast<float4*>(Xs + b * ld + c * 4) = v;
+                if (colfix) add_stats(v);
+            });
+        }
+        __syncthreads();
+    }
+    RO_CLK(41);
+    // BN1 statistics of all K columns: lane = (4-column group, row part), then one lane per column
+    {
+        const int np = 256 / K4, cg = threadIdx.x % K4, part = threadIdx.x / K4;
+        if (!colfix && part < np) {
+#pragma unroll 4
+            for (int b = part; b < B; b += np) add_stats(*reinterpret_cast<const float4*>(Xs + b * ld + 4 * cg));
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { red8[c][threadIdx.x] = s[c]; red8[4 + c][threadIdx.x] = q[c]; }
+        __syncthreads();
+        if ((int)threadIdx.x < K) {
+            const int k = threadIdx.x, g = k >> 2, c = k & 3;
+            double S = 0.0, Q = 0.0;
+            for (int p = 0; p < np; ++p) { S += red8[c][p * K4 + g]; Q += red8[4 + c][p * K4 + g]; }
+            float sc, sh, mean, rstd;
+            ro_bn_from_sums(h.bn1, k, S, Q, sc, sh, mean, rstd);
+            sc_s[k] = sc; sh_s[k] = sh; mean1_s[k] = mean; rstd1_s[k] = rstd;
+            if (duty_run1) {
+                const double m = S * (double)h.bn1.inv_n;
+                double v = Q * (double)h.bn1.inv_n - m * m;
+                if (v < 0.0) v = 0.0;
+                h.bn1.run_mean[k] = 0.9f * rm1 + 0.1f * (float)m;
+                h.bn1.run_var[k] = 0.9f * rv1 + 0.1f * (float)(v * (double)h.bn1.unbias);
+                if (k == 0 && h.bn1.nbt) *h.bn1.nbt += 1;
+            }
+        }
+        __syncthreads();
+    }
+    RO_CLK(42);
+    // this workgroup's INPUT chunk for phase C (the big tile is overwritten by dy1 there); rows B .. B16 zero
+    for (int idx = threadIdx.x; idx < B16 * RO_CW; idx += 256) {
+        const int b = idx / RO_CW, ii = idx % RO_CW;
+        xn[idx] = b < B ? Xs[b * ld + j0 + ii] : 0.f;
+    }
+    // y1[:, chunk] = relu(BN1(x) W1[chunk]^T + b1) on MFMA
+    ro_f32x4 acc[4] = {};
+    ro_mfma_tiles(ntiles, K, [&](int row, int k) { return fmaf(Xs[min(row, B - 1) * ld + k], sc_s[k], sh_s[k]); },
+                  [&](int k, int col) { return Ws[col * ld + k]; }, acc);
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = (w + 4 * t) * 16 + lk * 4 + r;
+            if (b < B) {
+                const float v = fmaxf(acc[t][r] + bias1, 0.f);
+                y1c[b * RO_CW + j] = v;
+                s1 += (double)v; s2 += (double)v * (double)v;
+            }
+        }
+    RO_CLK(43);
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < RO_CW) {                 // BN2 of the chunk (column-local: final values)
+        double S = 0.0, Q = 0.0;
+        for (int p = 0; p < 16; ++p) { S += red[0][p * RO_CW + threadIdx.x]; Q += red[1][p * RO_CW + threadIdx.x]; }
+        h.st2_sum[j0 + threadIdx.x] = S;
+        h.st2_sq[j0 + threadIdx.x] = Q;
+        const double m = S * (double)h.bn2.inv_n;
+        double v = Q * (double)h.bn2.inv_n - m * m;
+        if (v < 0.0) v = 0.0;
+        c2[0][threadIdx.x] = (float)m; c2[1][threadIdx.x] = 1.0f / sqrtf((float)v + h.bn2.eps);
+        c2[2][threadIdx.x] = g2; c2[3][threadIdx.x] = b2n;
+        h.bn2.run_mean[j0 + threadIdx.x] = 0.9f * rm2 + 0.1f * (float)m;
+        h.bn2.run_var[j0 + threadIdx.x] = 0.9f * rv2 + 0.1f * (float)(v * (double)h.bn2.unbias);
+        if (ch == 0 && threadIdx.x == 0 && h.bn2.nbt) *h.bn2.nbt += 1;
+    }
+    __syncthreads();
+    const float mean2 = c2[0][j], rstd2 = c2[1][j], gam2 = c2[2][j], bet2 = c2[3][j];
+    {   // BN2 output of the chunk (fc2's input; d W2 needs it again), then the partial logits
+        const float sc = gam2 * rstd2, sh = bet2 - mean2 * sc;
+        for (int b = rl; b < B; b += 16) yn[b * RO_CW + j] = fmaf(y1c[b * RO_CW + j], sc, sh);
+    }
+    __syncthreads();
+    {
+        float* zp = sa.zpart + ((size_t)hd * nch + ch) * BC;
+        for (int o = threadIdx.x; o < BC; o += 256) {
+            const int b = o / C, c = o % C;
+            const float4* yr = reinterpret_cast<const float4*>(yn + b * RO_CW);
+            const float4* wr = reinterpret_cast<const float4*>(W2c + c * RO_CW);
+            zp[o] = dot4(yr[3], wr[3], dot4(yr[2], wr[2], dot4(yr[1], wr[1], dot4(yr[0], wr[0], 0.f))));
+        }
+    }
+    RO_CLK(44);
+    ro_step_barrier(sa.sync + hd * 2, nch);
+    RO_CLK(45);
+
+    // =============================== B: logits, loss, dz; fc2 + BN2 + ReLU backward of the chunk ===============
+    for (int o0 = 0; o0 < BC; o0 += 512) {     // two outputs per lane and round: B*C <= 512 is one round of loads
+        float pz[2][8], bz[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int o = min(o0 + v * 256 + (int)threadIdx.x, BC - 1);
+            bz[v] = h.b2[o % C];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) pz[v][p] = sa.zpart[((size_t)hd * nch + min(p, nch - 1)) * BC + o];
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            ro_pin(bz[v]);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) ro_pin(pz[v][p]);
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const int o = o0 + v * 256 + (int)threadIdx.x;
+            float z = 0.f;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) z += p < nch ? pz[v][p] : 0.f;
+            z += bz[v];
+            if (o < BC) {
+                zs[o] = z;
+                if (duty_out) a.zl[(size_t)hd * BC + o] = z;
+            }
+        }
+    }
+    __syncthreads();
+    float lv = 0.f, cv = 0.f;
+    if ((int)threadIdx.x < B) {                // log_softmax / per-graph loss / dz (in place): one lane per graph
+        const int b = threadIdx.x;
+        const float u = 1.0f / (float)C, invB = 1.0f / (float)B, logu = logf(u);
+        const float wgt = hd == 0 ? a.wc : (hd == 1 ? a.wo : a.wco);
+        float* zr = zs + b * C;
+        float m = -INFINITY;
+        for (int k = 0; k < C; ++k) m = fmaxf(m, zr[k]);
+        float se = 0.f;
+        for (int k = 0; k < C; ++k) se += expf(zr[k] - m);
+        const float lse = m + logf(se);
+        const int yy = ylab;
+        int arg = 0; float best = -INFINITY;
+        double lrow = hd != 0 ? (double)(-(zr[yy] - lse)) : 0.0;
+        for (int k = 0; k < C; ++k) {
+            const float lp = zr[k] - lse;
+            if (lp > best) { best = lp; arg = k; }
+            if (hd == 0) lrow += (double)(u * (logu - lp));
+            const float p = expf(lp);
+            const float dz = wgt * invB * (hd == 0 ? (p - u) : (p - (k == yy ? 1.f : 0.f)));
+            zr[k] = dz;
+            if (duty_out) { a.logp[(size_t)hd * BC + b * C + k] = lp; a.dzl[(size_t)hd * BC + b * C + k] = dz; }
+        }
+        lv = (float)lrow; cv = hd == 1 && arg == yy ? 1.f : 0.f;
+    }
+    if (duty_loss) {                           // per-head loss = mean of the per-graph losses, correct_o = number of hits
+        double ls = (double)lv, cs = (double)cv;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ls += __shfl_xor(ls, o, 64); cs += __shfl_xor(cs, o, 64); }
+        if (l == 0) { red[0][w] = ls; red[1][w] = cs; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.stats[1 + hd] = (float)((red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (double)B);
+            if (hd == 1) a.stats[4] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        }
+    }
+    __syncthreads();
+    RO_CLK(46);
+    const float* dzs = zs;
+    {
+        double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            const int b = rl + 16 * qq;
+            if (b < B) {
+                float d = 0.f;
+                for (int c = 0; c < C; ++c) d = fmaf(dzs[b * C + c], W2c[c * RO_CW + j], d);
+                const float n = (y1c[b * RO_CW + j] - mean2) * rstd2;
+                dyh[b * RO_CW + j] = d;
+                t1 += (double)d; t2 += (double)d * (double)n;
+            }
+        }
+        red[0][threadIdx.x] = t1; red[1][threadIdx.x] = t2;
+        __syncthreads();
+        if (rl == 0) {
+            for (int p = 1; p < 16; ++p) { t1 += red[0][p * RO_CW + j]; t2 += red[1][p * RO_CW + j]; }
+            h.d2_sum[j0 + j] = t1; h.d2_prod[j0 + j] = t2;
+            c2[4][j] = (float)(t1 * (double)h.bn2.inv_n); c2[5][j] = (float)(t2 * (double)h.bn2.inv_n);
+        }
+        __syncthreads();
+        const float m1 = c2[4][j], m2 = c2[5][j], gs = gam2 * rstd2;
+        double sb = 0.0;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            const int b = rl + 16 * qq;
+            if (b < B) {
+                const float yv = y1c[b * RO_CW + j];
+                const float n = (yv - mean2) * rstd2;
+                const float dy = yv > 0.f ? gs * (dyh[b * RO_CW + j] - m1 - n * m2) : 0.f;     // ReLU mask
+                a.dy1[((size_t)hd * B + b) * K + j0 + j] = dy;
+                sb += (double)dy;
+            }
+        }
+        red[0][threadIdx.x] = sb;
+        __syncthreads();
+        if (rl == 0) {
+            for (int p = 1; p < 16; ++p) sb += red[0][p * RO_CW + j];
+            h.db1[j0 + j] = sb;
+        }
+    }
+    // barrier 2 of the head, then phase C's dy1 tile is requested at once; d b2 and d W2 (LDS only; gradients nobody in
+    // this kernel reads) run while it is in flight
+    RO_CLK(47);
+    ro_step_arrive(sa.sync + hd * 2 + 1);
+    RO_CLK(48);
+    ro_step_wait(sa.sync + hd * 2 + 1, nch);
+    RO_CLK(49);
+    // =============================== C: fc1 + BN1 backward over the INPUT chunk =================================
+    float* Ds = Xs;
+    RoBatch<float4, 16> bd;
+    ro_issue(bd, B, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(a.dy1 + ((size_t)hd * B + b) * K + c * 4); });
+    if (duty_db2) {                            // d b2[c] = sum_b dz[b, c]
+        const int np = 256 / C, c = threadIdx.x % C, part = threadIdx.x / C;
+        double sdz = 0.0;
+        if (part < np) for (int b = part; b < B; b += np) sdz += (double)dzs[b * C + c];
+        red[0][threadIdx.x] = sdz;
+        __syncthreads();
+        if (part == 0) {
+            for (int p2 = 1; p2 < np; ++p2) sdz += red[0][p2 * C + c];
+            h.db2[c] = sdz;
+        }
+        __syncthreads();
+    }
+    {   // d W2[c, chunk] = sum_b dz[b,c] * BN2out[b, chunk]
+        const int nout = C * RO_CW;
+        float* fred = dyh;                     // dead (all reads precede the barrier above)
+        for (int o0 = 0; o0 < nout; o0 += 256) {
+            const int no = min(256, nout - o0), np = 256 / no;
+            const int o = o0 + threadIdx.x % no, part = threadIdx.x / no;
+            const int c = o / RO_CW, jj = o % RO_CW;
+            float accw = 0.f;
+            if (part < np) {
+#pragma unroll 4
+                for (int b = part; b < B; b += np) accw = fmaf(dzs[b * C + c], yn[b * RO_CW + jj], accw);
+            }
+            __syncthreads();
+            fred[threadIdx.x] = accw;
+            __syncthreads();
+            if (part == 0) {
+                for (int p = 1; p < np; ++p) accw += fred[p * no + threadIdx.x];
+                h.gW2[(size_t)c * K + j0 + jj] = accw;
+            }
+        }
+    }
+    ro_commit(bd, B, K4, [&](int b, int c, const float4 v) { *reinterpret_cast<float4*>(Ds + b * ld + c * 4) = v; });
+    for (int idx = threadIdx.x; idx < (B16 - B) * ld; idx += 256) Ds[B * ld + idx] = 0.f;
+    __syncthreads();
+    RO_CLK(50);
+    const int i = j, i0 = j0;
+    const float mean1 = mean1_s[i0 + i], rstd1 = rstd1_s[i0 + i], gs1 = sc_s[i0 + i], sh1 = sh_s[i0 + i];
+    ro_f32x4 dacc[4] = {};
+    ro_mfma_tiles(ntiles, K, [&](int row, int k) { return Ds[min(row, B - 1) * ld + k]; },
+                  [&](int k, int col) { return W1t[col * ld + k]; }, dacc);
+    double u1 = 0.0, u2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = (w + 4 * t) * 16 + lk * 4 + r;
+            if (b < B) {
+                const float n = (xn[b * RO_CW + i] - mean1) * rstd1;
+                u1 += (double)dacc[t][r]; u2 += (double)dacc[t][r] * (double)n;
+            }
+        }
+    red[0][threadIdx.x] = u1; red[1][threadIdx.x] = u2;
+    __syncthreads();
+    if (threadIdx.x < RO_CW) {
+        double S = 0.0, Q = 0.0;
+        for (int p = 0; p < 16; ++p) { S += red[0][p * RO_CW + threadIdx.x]; Q += red[1][p * RO_CW + threadIdx.x]; }
+        h.d1_sum[i0 + threadIdx.x] = S; h.d1_prod[i0 + threadIdx.x] = Q;
+        c2[4][threadIdx.x] = (float)(S * (double)h.bn1.inv_n); c2[5][threadIdx.x] = (float)(Q * (double)h.bn1.inv_n);
+    }
+    __syncthreads();
+    {
+        const float m1 = c2[4][i], m2 = c2[5][i];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = (w + 4 * t) * 16 + lk * 4 + r;
+                if (b < B) {
+                    const float xr = xn[b * RO_CW + i];
+                    const float n = (xr - mean1) * rstd1;
+                    a.dxin[((size_t)hd * B + b) * K + i0 + i] = gs1 * (dacc[t][r] - m1 - n * m2);
+                    xn[b * RO_CW + i] = fmaf(xr, gs1, sh1);      // BN1 output (fc1 input) for d W1
+                }
+            }
+    }
+    __syncthreads();
+    RO_CLK(51);
+    // d W1[j, chunk] = sum_b dy1[b, j] * BN1out[b, chunk] on MFMA (rows = j, cols = chunk, reduction over graphs)
+    ro_f32x4 wacc[4] = {};
+    ro_mfma_tiles(K / 16, B16, [&](int row, int k) { return Ds[k * ld + min(row, K - 1)]; },
+                  [&](int k, int col) { return xn[k * RO_CW + col]; }, wacc);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (w + 4 * t < K / 16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                h.gW1[(size_t)((w + 4 * t) * 16 + lk * 4 + r) * K + i0 + i] = wacc[t][r];
+        }
+    RO_CLK(52);
+}
+
+}  // namespace cal

@@ -13,11 +13,16 @@ eng = StepEngine(m)
 b = Batch.from_data_list(spmotif.train_mix(128, seed=5)).to("cuda")
 perm = torch.randperm(128, device="cuda")
 for _ in range(5): eng.train_step(b, perm, adam=False)
+if len(sys.argv) > 1:      # graph replay: the timings of a kernel inside a dense launch sequence
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(4): eng.train_step(b, perm, adam=False)
+    for _ in range(5): g.replay()
 torch.cuda.synchronize()
 out = (ctypes.c_longlong * 64)()
 f = _lib.lib().cal_debug_ro_clocks
 f.argtypes = [ctypes.c_void_p]; f.restype = ctypes.c_int
 assert f(out) == 0
 v = list(out)
-for name, lo, hi in (("gconv", 32, 39), ("fwd_a", 0, 5), ("fwd_b", 6, 10), ("bwd_a", 24, 28), ("bwd_b", 16, 21)):
+for name, lo, hi in (("gconv", 32, 39), ("fwd_a", 0, 5), ("fwd_b", 6, 10), ("bwd_a", 24, 28), ("bwd_b", 16, 21), ("ro_step", 40, 52)):
     print(name, " ".join("%.2fus" % ((v[k + 1] - v[k]) / 100.0) for k in range(lo, hi)), "total %.2fus" % ((v[hi] - v[lo]) / 100.0))
