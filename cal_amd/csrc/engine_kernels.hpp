@@ -14,8 +14,14 @@ namespace cal {
 __device__ long long g_blk_clk[4 * 2048];     // 4 timestamps per workgroup: entry, two free marks, exit
 #define BLK_CLK(which) do { const int b_ = blockIdx.x + gridDim.x * blockIdx.y; \
                             if (threadIdx.x == 0 && b_ < 2048) g_blk_clk[4 * b_ + ((which) == 1 ? 3 : (which) == 0 ? 0 : (which) - 1)] = wall_clock64(); } while (0)
+// the same from lane 0 of wave `wv`, after everything the wave has in flight (memory counters, and the MFMA chain that
+// ends in accumulator element `dep`: reading it with a VALU instruction waits for the matrix pipe)
+#define BLK_CLK_W(which, wv, dep) do { const int b_ = blockIdx.x + gridDim.x * blockIdx.y; int d_; \
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(d_) : "v"(dep)); \
+                            if ((int)threadIdx.x == 64 * (wv) && b_ < 2048) g_blk_clk[4 * b_ + ((which) == 1 ? 3 : (which) == 0 ? 0 : (which) - 1)] = wall_clock64() + (d_ & 0); } while (0)
 #else
 #define BLK_CLK(which) do {} while (0)
+#define BLK_CLK_W(which, wv, dep) do {} while (0)
 #endif
 
 struct CSR {
