@@ -42,13 +42,23 @@ struct FinishArgs {
     float* stats;            // fused readout: stats[0] = wc*stats[1] + wo*stats[2] + wco*stats[3]
     float wc, wo, wco;
     float* tick;             // Adam step counter to advance (the update follows in the same step) or null
-    int blk0[MAX_SLABS + MAX_COMMITS + 1];   // first block of every task in the flattened 1-D grid (filled at launch)
+    // Adam inside this kernel (single-process steps, mode bit 4 without bit 8): every gradient element is updated by the
+    // thread that finishes it, the ranges no task writes (gradients other kernels stored directly) by `nar` extra tasks
+    // of 256 elements per block; the step counter was advanced by the step's FIRST kernel (a ticket of 2700 blocks on one
+    // address, each behind a device-scope fence, cost 47 us)
+    AdamArgs adam;
+    AdamRange ar[MAX_ADAM_RANGES];
+    int nar;
+    int blk0[MAX_SLABS + MAX_COMMITS + MAX_ADAM_RANGES + 1];   // first block of every task in the flattened 1-D grid (filled at launch)
 };
 // grid: 1-D, task t owns blocks [blk0[t], blk0[t+1]): n/64 per slab task, ceil(n/16) per commit task (a
 // (64, tasks) grid spent most of its ~12k blocks on nothing once the slab tasks wanted 256 blocks each)
 __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __restrict__ grad) {
     int task = 0;
-    const int ntask = fa.nst + fa.nct;
+    const int ntask = fa.nst + fa.nct + fa.nar;
+    const AdamArgs& A = fa.adam;
+    float adam_t = 0.f, adam_lr = 0.f;
+    if (A.on) { adam_t = A.step[0]; adam_lr = A.lr[0]; }      // the step's first kernel has already advanced the counter
     while (task + 1 < ntask && (int)blockIdx.x >= fa.blk0[task + 1]) ++task;
     const int bx = blockIdx.x - fa.blk0[task], nbx = fa.blk0[task + 1] - fa.blk0[task];
     if (fa.stats && blockIdx.x == 0 && threadIdx.x == 0)
@@ -81,7 +91,11 @@ __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __re
             }
             sred[threadIdx.x] = s0 + s1;
             __syncthreads();
-            if (grp == 0 && i0 + el < t.n) t.dst[i] = (sred[el] + sred[64 + el]) + (sred[128 + el] + sred[192 + el]);
+            if (grp == 0 && i0 + el < t.n) {
+                const float gsum = (sred[el] + sred[64 + el]) + (sred[128 + el] + sred[192 + el]);
+                t.dst[i] = gsum;
+                if (A.on) adam_update(A, (t.dst - grad) + i, gsum, adam_t, adam_lr);
+            }
             __syncthreads();
         }
     } else if (task - fa.nst < fa.nct) {
@@ -107,10 +121,16 @@ __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __re
                 double tot = 0.0;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) tot += red[k * 16 + cl];
-                grad[t.dst + c] = t.scale * (float)tot;
+                const float gv = t.scale * (float)tot;
+                grad[t.dst + c] = gv;
+                if (A.on) adam_update(A, t.dst + c, gv, adam_t, adam_lr);
             }
             __syncthreads();
         }
+    } else if (A.on) {
+        const AdamRange r = fa.ar[task - fa.nst - fa.nct];
+        const int64_t i = r.begin + (int64_t)bx * 256 + threadIdx.x;
+        if (i < r.end) adam_update(A, i, grad[i], adam_t, adam_lr);
     }
 }
 
@@ -147,6 +167,7 @@ struct Engine {
     int64_t capN, capE, capB;
     // float regions
     float *h, *z, *zco, *hco, *anode, *pq, *att, *dis_unit, *dis_co, *pooled, *xco, *y1, *zl, *logp, *stats, *zpart;
+    int adam_fused;          // 1: mode-4 steps apply Adam inside k_finish; CAL_AMD_ADAM_FUSED=0 keeps the k_adam launch
     int ro_step;             // 1: training steps run the readout as one launch (k_ro_step); CAL_AMD_RO_STEP=0 keeps the four kernels
     float *dzl, *dyh1, *dy1, *dxh, *dpool, *dZco, *gn, *gself, *ddeg, *dl, *dzco, *dXhco, *dZ, *dzi, *dXh, *slabs;
     size_t slab_floats;
@@ -201,6 +222,7 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     Engine* e = new Engine();
     memset(e, 0, sizeof(Engine));
     { const char* v = getenv("CAL_AMD_RO_STEP"); e->ro_step = !(v && v[0] == '0'); }
+    { const char* v = getenv("CAL_AMD_ADAM_FUSED"); e->adam_fused = !(v && v[0] == '0'); }
     e->F = (int)F; e->H = (int)H; e->C = (int)C; e->L = (int)L;
     e->loop_w = 1.f;
     e->grad_scale = 1.f;
@@ -404,6 +426,7 @@ struct Ctx {
     int draw_perm;      // the step draws its own intervention permutation (first kernel) into Engine::perm_dev
     int tick_in_finish; // the step ends with the Adam update: k_finish advances the step counter
     int ro_done;        // the forward's k_ro_step already ran the readout backward
+    int adam_in_finish; // k_finish applies Adam to every gradient it completes (no k_adam launch)
     size_t parts_off;   // bump allocator over Engine::parts
     FinalArgs fin;      // pending k_stats_final tasks
 };
@@ -702,7 +725,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         const int64_t ni = fast_plan ? 0 : 4 * ((int64_t)N + 1);
         hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256) + (c.draw_perm ? 1 : 0)), dim3(256), 0, st,
                            e->arena, (int64_t)e->arena_n, e->work, ni, e->status, (e->K > 0 && c.training) ? e->gat_ctr : nullptr,
-                           c.draw_perm ? e->perm_dev : nullptr, B, e->perm_seed, e->perm_ctr);
+                           c.draw_perm ? e->perm_dev : nullptr, B, e->perm_seed, e->perm_ctr, c.adam_in_finish ? e->step : nullptr);
         CAL_CHECK_LAUNCH("k_zero_f64"); STAGE();
     }
     // 1. GraphPlan
@@ -1019,7 +1042,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     const float* xin[3] = {e->pooled, e->pooled + BH, e->xco};
     FinishArgs fa;
     memset(&fa, 0, sizeof(fa));
-    fa.tick = c.tick_in_finish ? e->step : nullptr;
+    fa.tick = (c.tick_in_finish && !c.adam_in_finish) ? e->step : nullptr;      // (adam_in_finish: k_zero_f64 did it)
     size_t slab_off = 0;
     auto commit_p = [&](const double* src, int P, int stride, int dst, int n, float scale) {
         if (fa.nct < MAX_COMMITS) fa.ct[fa.nct] = CommitTask{src, P, stride, dst, n, scale};
@@ -1588,10 +1611,36 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     if (fa.nct > MAX_COMMITS) { set_error("engine: too many commit tasks"); return 2; }
     join_side(c);
     {
+        if (c.adam_in_finish) {
+            // Adam rides in this kernel: parameter ranges no task writes (gradients stored directly by the readout /
+            // single-slab GEMMs) become update-only tasks
+            fa.adam = AdamArgs{e->P, e->M1, e->M2, e->step, e->lr, e->beta1, e->beta2, e->eps, e->wd, e->grad_scale, 1};
+            std::vector<std::pair<int64_t, int64_t>> iv;
+            for (int i = 0; i < fa.nst; ++i) iv.push_back({fa.st[i].dst - e->G, (fa.st[i].dst - e->G) + fa.st[i].n});
+            for (int i = 0; i < fa.nct; ++i) iv.push_back({fa.ct[i].dst, (int64_t)fa.ct[i].dst + fa.ct[i].n});
+            std::sort(iv.begin(), iv.end());
+            int64_t pos = 0;
+            bool ok = true;
+            auto gap = [&](int64_t a, int64_t b) {
+                if (b <= a) return;
+                if (fa.nar >= MAX_ADAM_RANGES) { ok = false; return; }
+                fa.ar[fa.nar++] = AdamRange{a, b};
+            };
+            for (auto& r : iv) {
+                if (r.first < pos) { ok = false; break; }          // two tasks finish the same element: not expected
+                gap(pos, r.first);
+                pos = r.second;
+            }
+            gap(pos, e->nparam);
+            if (!ok || pos > e->nparam) {                          // keep the separate k_adam launch
+                fa.adam.on = 0; fa.nar = 0; c.adam_in_finish = 2;     // 2: k_adam follows, counter already advanced
+            }
+        }
         int nblk = 0;
         for (int i = 0; i < fa.nst; ++i) { fa.blk0[i] = nblk; nblk += std::max(1, cdiv(fa.st[i].n, 64)); }
         for (int i = 0; i < fa.nct; ++i) { fa.blk0[fa.nst + i] = nblk; nblk += std::max(1, cdiv(fa.ct[i].n, 16)); }
-        fa.blk0[fa.nst + fa.nct] = nblk;
+        for (int i = 0; i < fa.nar; ++i) { fa.blk0[fa.nst + fa.nct + i] = nblk; nblk += (int)cdiv(fa.ar[i].end - fa.ar[i].begin, 256); }
+        fa.blk0[fa.nst + fa.nct + fa.nar] = nblk;
         hipLaunchKernelGGL(k_finish, dim3(nblk), dim3(256), 0, st, fa, e->G);
     }
     CAL_CHECK_LAUNCH("k_finish"); STAGE();
@@ -1623,6 +1672,7 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     c.fin.nt = 0;
     c.nfork = 0;
     c.ro_done = 0;
+    c.adam_in_finish = ((mode & 4) && e->adam_fused) ? 1 : 0;
     const int want_grad = (mode & 2) ? 1 : 0;
     c.draw_perm = (mode & 16) ? 1 : 0;
     CAL_REQUIRE(!c.draw_perm || (e->perm_ctr && B <= ZP_CAP), "mode bit 16 needs cal_engine_set_perm_rng and at most 1024 graphs per batch");
@@ -1646,7 +1696,7 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
             if (rc) return rc;
         }
     }
-    if (mode & 4) {          // k_finish has already advanced the step counter (c.tick_in_finish)
+    if ((mode & 4) && c.adam_in_finish != 1) {          // k_finish has already advanced the step counter (c.tick_in_finish)
         hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, c.st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
                            e->beta2, e->eps, e->wd, e->nparam, 1, e->grad_scale);
         CAL_CHECK_LAUNCH("k_adam");
@@ -1670,7 +1720,7 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
     c.rpb_b = std::max(32, cdiv(B, 64));
     c.parts_off = 0; c.fin.nt = 0; c.nfork = 0;
     c.y = nullptr; c.perm = nullptr; c.wc = c.wo = c.wco = 0.f; c.want_grad = 1;
-    c.tick_in_finish = 0; c.draw_perm = 0; c.ro_done = 0;
+    c.tick_in_finish = 0; c.draw_perm = 0; c.ro_done = 0; c.adam_in_finish = 0;
     hipLaunchKernelGGL(k_logsoftmax_bwd, dim3(1), dim3(256), 0, c.st, e->logp, dlogp, e->dzl, e->arena + e->a_db2, (int)B, e->C);
     CAL_CHECK_LAUNCH("k_logsoftmax_bwd");
     g_stage = 0;

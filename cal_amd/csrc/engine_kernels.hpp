@@ -129,7 +129,7 @@ constexpr int ZP_CAP = 1024;
 __global__ void __launch_bounds__(256) k_zero_f64(double* __restrict__ a, int64_t n, int* __restrict__ ints, int64_t ni,
                                                   int* __restrict__ status, unsigned long long* __restrict__ tick,
                                                   int64_t* __restrict__ perm, int B, unsigned long long seed,
-                                                  unsigned long long* __restrict__ counter) {
+                                                  unsigned long long* __restrict__ counter, float* __restrict__ adam_step) {
     __shared__ unsigned long long key[ZP_CAP];
     __shared__ int idx[ZP_CAP];
     if (perm && blockIdx.x == gridDim.x - 1) { randperm_block<256>(perm, B, seed, counter, key, idx); return; }
@@ -138,6 +138,7 @@ __global__ void __launch_bounds__(256) k_zero_f64(double* __restrict__ a, int64_
     if (i < ni) ints[i] = 0;
     if (i == 0 && status) { status[1] |= status[0]; status[0] = 0; }
     if (i == 0 && tick) *tick += 1;
+    if (i == 0 && adam_step) adam_step[0] += 1.f;       // the step ends with Adam inside k_finish, which reads the counter
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1017,6 +1018,21 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
 // ------------------------------------------------------------------------------------------------
 struct SlabTask { const float* slabs; float* dst; int n; int S; };
 struct CommitTask { const double* src; int P; int stride; int dst; int n; float scale; };   // (partial rows of) fp64 sums -> flat-gradient offset
+
+// the same update for one element, for kernels that finish a gradient and apply it on the spot (k_finish)
+constexpr int MAX_ADAM_RANGES = 24;
+struct AdamArgs { float* p; float* m; float* v; float* step; const float* lr; float beta1, beta2, eps, wd, gscale; int on; };
+struct AdamRange { int64_t begin, end; };
+__device__ __forceinline__ void adam_update(const AdamArgs& A, int64_t i, float g, float t, float lr) {
+    float gi = g * A.gscale;
+    if (A.wd != 0.f) gi = fmaf(A.wd, A.p[i], gi);
+    const float mi = A.beta1 * A.m[i] + (1.f - A.beta1) * gi;
+    const float vi = A.beta2 * A.v[i] + (1.f - A.beta2) * gi * gi;
+    A.m[i] = mi; A.v[i] = vi;
+    const float bc1 = 1.f - powf(A.beta1, t), bc2 = 1.f - powf(A.beta2, t);
+    const float denom = sqrtf(vi) / sqrtf(bc2) + A.eps;
+    A.p[i] -= (lr / bc1) * (mi / denom);
+}
 
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        float* __restrict__ step, const float* __restrict__ lr_ptr, float beta1, float beta2, float eps,
