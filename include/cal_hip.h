@@ -144,9 +144,10 @@ CAL_API int cal_engine_set_gat(void* engine, int64_t heads, float p, float slope
 
 /* ---- native CausalGCN step engine ------------------------------------------------
  * The whole train step of train_causal.py:173-192 on model.py:85-164 (forward, 3-term loss,
- * backward, Adam) as one call enqueuing a few dozen fused kernels (32 at BASELINE config 2); see cal_amd/csrc/engine.hip for the
+ * backward, Adam) as one call enqueuing a few dozen fused kernels (25 at BASELINE config 2); see cal_amd/csrc/engine.hip for the
  * slot order of `offs` / `bn_ptrs`.  mode bits: 1 = training-mode forward, 2 = loss gradient +
- * backward into the flat gradient buffer, 4 = Adam, 8 = Adam follows separately (cal_engine_adam_ticked),
+ * backward into the flat gradient buffer, 4 = Adam (applied inside the step's last kernel; the step counter is advanced by
+ * its first one), 8 = Adam follows separately (cal_engine_adam_ticked),
  * 16 = draw the random-intervention permutation on the device inside the step's first kernel (`perm` ignored; cal_engine_set_perm_rng).  Outputs ("logp" [3,B,C], "stats" [5] =
  * loss, c_loss, o_loss, co_loss, correct_o) live in the caller-owned workspace at
  * cal_engine_buffer_offset(name) floats from its base. */
