@@ -152,8 +152,11 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
         // the dense blocks are cleared while the loads are in flight
         for (int i = t; i < AG_T * AG_LD; i += 512) { Tc[i] = 0.f; To[i] = 0.f; Dm[i] = 0.f; }
         if (t <= rows) dp_s[t] = pdv - e0;
+        if (t < AG_T) {                                   // (rows past the graph: zero, the block sums below run over all 64)
+            dis_c_s[t] = t < rows ? dcv : 0.f; dis_o_s[t] = t < rows ? dov : 0.f;
+        }
         if (t < rows) {
-            dis_c_s[t] = dcv; dis_o_s[t] = dov; gs_c_s[t] = gsc; gs_o_s[t] = gso;
+            gs_c_s[t] = gsc; gs_o_s[t] = gso;
             for (int s = pdv - e0; s < pdn - e0; ++s) d_own[s] = (short)t;
         }
 #pragma unroll
@@ -182,12 +185,17 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
             const int v = t >> 3, k = (t >> 2) & 1, p = t & 3;
             const float* T = k ? To : Tc;
             const float* dsv = k ? dis_o_s : dis_c_s;
+            // (unconditional over the lane's 16 columns: entries past the graph are zero, and so is their deg^-1/2; with
+            //  `if (j < rows)` inside, every iteration was a branch with its own LDS round trip)
             float acc = 0.f;
-            if (v < rows) {
-#pragma unroll 4
-                for (int j = p * 16; j < p * 16 + 16; ++j)
-                    if (j < rows) acc += (T[v * AG_LD + j] + T[j * AG_LD + v]) * dsv[j];
+            float tv[16], tw[16], dj[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const int j = p * 16 + jj;
+                tv[jj] = T[v * AG_LD + j]; tw[jj] = T[j * AG_LD + v]; dj[jj] = dsv[j];
             }
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) acc = fmaf(tv[jj] + tw[jj], dj[jj], acc);
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
             if (v < rows && p == 0) {                     // + the self loop; d deg = d(deg^-1/2) chain
@@ -211,11 +219,11 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
         {
             const int v = t >> 3, k = (t >> 2) & 1, p = t & 3;
             float acc = 0.f;
-            if (v < rows) {
-#pragma unroll 4
-                for (int j = p * 16; j < p * 16 + 16; ++j)
-                    if (j < rows) acc += k ? Dm[j * AG_LD + v] : Dm[v * AG_LD + j];
-            }
+            float dv[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) { const int j = p * 16 + jj; dv[jj] = Dm[k ? j * AG_LD + v : v * AG_LD + j]; }
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) acc += dv[jj];
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
             if (v < rows && p == 0) (k ? sqv_s : spv_s)[v] = acc;

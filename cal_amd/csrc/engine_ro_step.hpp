@@ -78,10 +78,12 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     RO_CLK(40);
     // =============================== A: fc1 forward of the chunk ===============================================
     const bool colfix = 256 % K4 == 0;
-    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    // a lane's <= 16 terms per column are summed in fp32 (fp64 conversions and adds issue at a fraction of the fp32 rate:
+    // 192 of them per lane were most of this phase), everything across lanes in fp64
+    float sf[4] = {0.f, 0.f, 0.f, 0.f}, qf[4] = {0.f, 0.f, 0.f, 0.f};
     auto add_stats = [&](const float4 v) {
-        s[0] += (double)v.x; q[0] += (double)v.x * (double)v.x; s[1] += (double)v.y; q[1] += (double)v.y * (double)v.y;
-        s[2] += (double)v.z; q[2] += (double)v.z * (double)v.z; s[3] += (double)v.w; q[3] += (double)v.w * (double)v.w;
+        sf[0] += v.x; qf[0] = fmaf(v.x, v.x, qf[0]); sf[1] += v.y; qf[1] = fmaf(v.y, v.y, qf[1]);
+        sf[2] += v.z; qf[2] = fmaf(v.z, v.z, qf[2]); sf[3] += v.w; qf[3] = fmaf(v.w, v.w, qf[3]);
     };
     // Loads of the kernel's first round.  The co head gathers xc[perm]: its perm entry is requested FIRST (loads return in
     // order: asked for behind the tiles it arrived after all of them, and the gather was a second full round, 6.9 us to
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
             for (int b = part; b < B; b += np) add_stats(*reinterpret_cast<const float4*>(Xs + b * ld + 4 * cg));
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { red8[c][threadIdx.x] = s[c]; red8[4 + c][threadIdx.x] = q[c]; }
+        for (int c = 0; c < 4; ++c) { red8[c][threadIdx.x] = (double)sf[c]; red8[4 + c][threadIdx.x] = (double)qf[c]; }
         __syncthreads();
         if ((int)threadIdx.x < K) {
             const int k = threadIdx.x, g = k >> 2, c = k & 3;
@@ -170,20 +172,18 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     ro_f32x4 acc[4] = {};
     ro_mfma_tiles(ntiles, K, [&](int row, int k) { return fmaf(Xs[min(row, B - 1) * ld + k], sc_s[k], sh_s[k]); },
                   [&](int k, int col) { return Ws[col * ld + k]; }, acc);
-    double s1 = 0.0, s2 = 0.0;
+    float s1 = 0.f, s2 = 0.f;                  // (16 terms per lane in fp32, see add_stats)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = (w + 4 * t) * 16 + lk * 4 + r;
-            if (b < B) {
-                const float v = fmaxf(acc[t][r] + bias1, 0.f);
-                y1c[b * RO_CW + j] = v;
-                s1 += (double)v; s2 += (double)v * (double)v;
-            }
+            const float v = b < B ? fmaxf(acc[t][r] + bias1, 0.f) : 0.f;
+            if (b < B) y1c[b * RO_CW + j] = v;
+            s1 += v; s2 = fmaf(v, v, s2);
         }
     RO_CLK(43);
-    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    red[0][threadIdx.x] = (double)s1; red[1][threadIdx.x] = (double)s2;
     __syncthreads();
     if (threadIdx.x < RO_CW) {                 // BN2 of the chunk (column-local: final values)
         double S = 0.0, Q = 0.0;
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     RO_CLK(46);
     const float* dzs = zs;
     {
-        double t1 = 0.0, t2 = 0.0;
+        float t1f = 0.f, t2f = 0.f;
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
             const int b = rl + 16 * qq;
@@ -298,9 +298,10 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
                 for (int c = 0; c < C; ++c) d = fmaf(dzs[b * C + c], W2c[c * RO_CW + j], d);
                 const float n = (y1c[b * RO_CW + j] - mean2) * rstd2;
                 dyh[b * RO_CW + j] = d;
-                t1 += (double)d; t2 += (double)d * (double)n;
+                t1f += d; t2f = fmaf(d, n, t2f);
             }
         }
+        double t1 = (double)t1f, t2 = (double)t2f;
         red[0][threadIdx.x] = t1; red[1][threadIdx.x] = t2;
         __syncthreads();
         if (rl == 0) {
@@ -310,7 +311,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         }
         __syncthreads();
         const float m1 = c2[4][j], m2 = c2[5][j], gs = gam2 * rstd2;
-        double sb = 0.0;
+        float sbf = 0.f;
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
             const int b = rl + 16 * qq;
@@ -319,9 +320,10 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
                 const float n = (yv - mean2) * rstd2;
                 const float dy = yv > 0.f ? gs * (dyh[b * RO_CW + j] - m1 - n * m2) : 0.f;     // ReLU mask
                 a.dy1[((size_t)hd * B + b) * K + j0 + j] = dy;
-                sb += (double)dy;
+                sbf += dy;
             }
         }
+        double sb = (double)sbf;
         red[0][threadIdx.x] = sb;
         __syncthreads();
         if (rl == 0) {
@@ -382,18 +384,17 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     ro_f32x4 dacc[4] = {};
     ro_mfma_tiles(ntiles, K, [&](int row, int k) { return Ds[min(row, B - 1) * ld + k]; },
                   [&](int k, int col) { return W1t[col * ld + k]; }, dacc);
-    double u1 = 0.0, u2 = 0.0;
+    float u1 = 0.f, u2 = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = (w + 4 * t) * 16 + lk * 4 + r;
-            if (b < B) {
-                const float n = (xn[b * RO_CW + i] - mean1) * rstd1;
-                u1 += (double)dacc[t][r]; u2 += (double)dacc[t][r] * (double)n;
-            }
+            const float n = (xn[min(b, B16 - 1) * RO_CW + i] - mean1) * rstd1;      // (rows past B: dacc is zero there)
+            const float dv = b < B ? dacc[t][r] : 0.f;
+            u1 += dv; u2 = fmaf(dv, n, u2);
         }
-    red[0][threadIdx.x] = u1; red[1][threadIdx.x] = u2;
+    red[0][threadIdx.x] = (double)u1; red[1][threadIdx.x] = (double)u2;
     __syncthreads();
     if (threadIdx.x < RO_CW) {
         double S = 0.0, Q = 0.0;
