@@ -255,22 +255,39 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         const float u = 1.0f / (float)C, invB = 1.0f / (float)B, logu = logf(u);
         const float wgt = hd == 0 ? a.wc : (hd == 1 ? a.wo : a.wco);
         float* zr = zs + b * C;
-        float m = -INFINITY;
-        for (int k = 0; k < C; ++k) m = fmaxf(m, zr[k]);
-        float se = 0.f;
-        for (int k = 0; k < C; ++k) se += expf(zr[k] - m);
-        const float lse = m + logf(se);
         const int yy = ylab;
         int arg = 0; float best = -INFINITY;
-        double lrow = hd != 0 ? (double)(-(zr[yy] - lse)) : 0.0;
-        for (int k = 0; k < C; ++k) {
-            const float lp = zr[k] - lse;
+        double lrow = 0.0;
+        auto finish = [&](int k, float zk, float lse) {       // class k of this graph: log-prob, loss term, dz
+            const float lp = zk - lse;
             if (lp > best) { best = lp; arg = k; }
             if (hd == 0) lrow += (double)(u * (logu - lp));
+            else if (k == yy) lrow = (double)(-lp);
             const float p = expf(lp);
             const float dz = wgt * invB * (hd == 0 ? (p - u) : (p - (k == yy ? 1.f : 0.f)));
             zr[k] = dz;
             if (duty_out) { a.logp[(size_t)hd * BC + b * C + k] = lp; a.dzl[(size_t)hd * BC + b * C + k] = dz; }
+        };
+        if (C <= 8) {                              // the row in registers: one batch of LDS reads instead of three passes
+            float zc[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) zc[k] = zr[min(k, C - 1)];
+            float m = zc[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) m = fmaxf(m, zc[k]);
+            float se = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) se += k < C ? expf(zc[k] - m) : 0.f;
+            const float lse = m + logf(se);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k < C) finish(k, zc[k], lse);
+        } else {
+            float m = -INFINITY;
+            for (int k = 0; k < C; ++k) m = fmaxf(m, zr[k]);
+            float se = 0.f;
+            for (int k = 0; k < C; ++k) se += expf(zr[k] - m);
+            const float lse = m + logf(se);
+            for (int k = 0; k < C; ++k) finish(k, zr[k], lse);
         }
         lv = (float)lrow; cv = hd == 1 && arg == yy ? 1.f : 0.f;
     }
@@ -289,16 +306,26 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     RO_CLK(46);
     const float* dzs = zs;
     {
+        // d(BN2 out)[b, j] = sum_c dz[b, c] W2[c, j] for this lane's 8 rows: the class loop outside, so that a step is
+        // nine independent LDS reads (inside the row guard it was one read pair + wait per (row, class))
         float t1f = 0.f, t2f = 0.f;
+        float dq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+            const float wc2 = W2c[c * RO_CW + j];
+            float dzv[8];
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) dzv[qq] = dzs[min(rl + 16 * qq, B - 1) * C + c];
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) dq[qq] = fmaf(dzv[qq], wc2, dq[qq]);
+        }
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
             const int b = rl + 16 * qq;
+            const float yv = y1c[min(b, B - 1) * RO_CW + j];
             if (b < B) {
-                float d = 0.f;
-                for (int c = 0; c < C; ++c) d = fmaf(dzs[b * C + c], W2c[c * RO_CW + j], d);
-                const float n = (y1c[b * RO_CW + j] - mean2) * rstd2;
-                dyh[b * RO_CW + j] = d;
-                t1f += d; t2f = fmaf(d, n, t2f);
+                const float n = (yv - mean2) * rstd2;
+                dyh[b * RO_CW + j] = dq[qq];
+                t1f += dq[qq]; t2f = fmaf(dq[qq], n, t2f);
             }
         }
         double t1 = (double)t1f, t2 = (double)t2f;
