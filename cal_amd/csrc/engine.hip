@@ -889,7 +889,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             constexpr int G = decltype(g)::value;
             hipLaunchKernelGGL((k_att_fwd_graph<4, G>), dim3(B), dim3(512), 0, st, e->gptr, gs, x, e->P + e->o_natt_w, e->P + e->o_natt_b,
                                e->P + e->o_eatt_w, e->P + e->o_eatt_b, e->anode, e->pq, e->att, e->dis_co, e->dis_co + N, a0, a1, a2, a3,
-                               e->loop_w, H, E, e->status, e->no_node_att ? 0.f : 1.f, e->no_edge_att ? 0.f : 1.f);
+                               e->loop_w, H, E, e->status, e->no_node_att ? 0.f : 1.f, e->no_edge_att ? 0.f : 1.f, e->eptr);
             return 0;
         }));
         CAL_CHECK_LAUNCH("k_att_fwd_graph"); STAGE();

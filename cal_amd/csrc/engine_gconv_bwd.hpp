@@ -469,6 +469,7 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
     __shared__ float um_s[FB_H], ur_s[FB_H], ug_s[FB_H], u1_s[FB_H], u2_s[FB_H];
     __shared__ float m0_s[FB_F], r0_s[FB_F], g0_s[FB_F], b0_s[FB_F];
     __shared__ float dX0[FB_T * FB_F];
+    BLK_CLK(0);
     const int b = blockIdx.x, t = threadIdx.x, LDZ = FB_H + 4;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0;
     float* slab = a.slab + (size_t)b * F * H;
@@ -550,6 +551,7 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
         }
     }
     __syncthreads();
+    BLK_CLK(2);
     // dW_feat slab: output (f, 4 consecutive n), reduction over the graph's rows; x0_hat' = gamma0 x0_hat + beta0
     for (int o = t; o < F * H4; o += GB_NT) {
         const int f = o / H4, n = 4 * (o % H4);
@@ -563,31 +565,56 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
         }
         *reinterpret_cast<float4*>(slab + (size_t)f * H + n) = acc;
     }
+    BLK_CLK(3);
     // BatchNorm_0 backward sums: dX0[j][f] = <dZ[j], W[f]>: lane = (row j = t / 4, quarter qn of the H columns) keeps its
     // quarter row of dZ in registers and walks the features; then one lane per feature sums over the rows (fixed order)
     {
         const int j = (t & 255) >> 2, qn = t & 3, nq4 = H >> 4;  // float4s per quarter row (H % 16 == 0)
         const int fh = (F + 1) >> 1, f_lo = t < 256 ? 0 : fh, f_hi = t < 256 ? fh : F;     // the two halves of the block split the features
+        // (reads unconditional on a clamped float4 index, masked afterwards: `k < nq4 ? read : 0` compiles to one branch with
+        //  its own LDS round trip per element -- 40 serial reads in the feature loop below)
         float4 dz[FB_H / 16];
 #pragma unroll
         for (int k = 0; k < FB_H / 16; ++k)
-            dz[k] = k < nq4 ? *reinterpret_cast<const float4*>(Dz + min(j, rows - 1) * LDZ + 4 * (qn * nq4 + k)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dz[k] = *reinterpret_cast<const float4*>(Dz + min(j, rows - 1) * LDZ + 4 * (qn * nq4 + min(k, nq4 - 1)));
+#pragma unroll
+        for (int k = 0; k < FB_H / 16; ++k) { ro_pin(dz[k]); if (k >= nq4) dz[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
         for (int f = f_lo; f < f_hi; ++f) {
             const float4* wr = reinterpret_cast<const float4*>(Ws + f * LDZ) + qn * nq4;
+            float4 wv[FB_H / 16];
+#pragma unroll
+            for (int k = 0; k < FB_H / 16; ++k) wv[k] = wr[min(k, nq4 - 1)];
             float p = 0.f;
 #pragma unroll
-            for (int k = 0; k < FB_H / 16; ++k) if (k < nq4) p = dot4(dz[k], wr[k], p);
+            for (int k = 0; k < FB_H / 16; ++k) p = dot4(dz[k], wv[k], p);
             p += __shfl_xor(p, 1, 64);
             p += __shfl_xor(p, 2, 64);
             if (qn == 0 && j < rows) dX0[j * FB_F + f] = p;
         }
     }
     __syncthreads();
-    if (t < F) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int j = 0; j < rows; ++j) { const double v = (double)dX0[j * FB_F + t]; s1 += v; s2 += v * (double)Xn[j * FB_F + t]; }
-        parts[t] = s1; parts[F + t] = s2;
+    // eight lanes per feature, each over every eighth row (<= 8 terms, fp32), combined in fp64 by shuffle: one lane per
+    // feature walked the graph's rows as a chain of 57 dependent LDS round trips + fp64 adds while 500 lanes idled
+    {
+        const int f = t >> 3, p = t & 7, fc = min(f, F - 1);
+        float a1 = 0.f, a2 = 0.f;
+        float dv[FB_T / 8], xv[FB_T / 8];
+#pragma unroll
+        for (int u = 0; u < FB_T / 8; ++u) {
+            const int j = min(p + 8 * u, rows - 1);
+            dv[u] = dX0[j * FB_F + fc]; xv[u] = Xn[j * FB_F + fc];
+        }
+#pragma unroll
+        for (int u = 0; u < FB_T / 8; ++u) {
+            const float v = p + 8 * u < rows ? dv[u] : 0.f;
+            a1 += v; a2 = fmaf(v, xv[u], a2);
+        }
+        double s1 = (double)a1, s2 = (double)a2;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (p == 0 && f < F) { parts[f] = s1; parts[F + f] = s2; }
     }
+    BLK_CLK(1);
 }
 
 }  // namespace cal

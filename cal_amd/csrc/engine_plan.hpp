@@ -170,13 +170,27 @@ __global__ void __launch_bounds__(512) k_att_fwd_graph(const int* __restrict__ g
                                                        float* __restrict__ anode, float* __restrict__ pq, float* __restrict__ att,
                                                        float* __restrict__ dis_c, float* __restrict__ dis_o, const Acc stc_sum,
                                                        const Acc stc_sq, const Acc sto_sum, const Acc sto_sq, float loop_w, int H,
-                                                       int64_t E, int* __restrict__ status, float fnode, float fedge) {
+                                                       int64_t E, int* __restrict__ status, float fnode, float fedge,
+                                                       const int* __restrict__ eptr) {
     // fnode / fedge: 1, or 0 for without_node_attention / without_edge_attention (equal logits -> constant 0.5 masks)
     constexpr int RPB = 512 / G, MAXR = 4 * RPB;
     __shared__ double lds[4 * 512 * (VEC == 4 ? 4 : 1)];
     __shared__ float4 pq_s[MAXR];
     const int b = blockIdx.x, t = threadIdx.x, grp = t / G, l = t % G;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0;
+    // the graph's by-source CSR rows for the edge phase: requested NOW, with the row loads (its slot range is its edge range,
+    // eptr; read after the row phase they were two more dependent rounds of global loads in the middle of the kernel)
+    const int e0 = eptr[b], ne = eptr[b + 1] - e0;
+    const int rcl = max(rows, 0);
+    int pv = gs.ptr[g0 + min(t, rcl)], pn = gs.ptr[g0 + min(t + 1, rcl)];
+    int nd[2], ed[2];
+    const int slot_hi = max(gs.nnz - 1, 0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int s = min(e0 + max(min(t + u * 512, ne - 1), 0), slot_hi);
+        nd[u] = gs.nbr[s];
+        ed[u] = gs.eid[s];
+    }
     using V = Vec<VEC>;
     const int c = l * VEC, cc = min(c, H - VEC);
     const bool cok = c < H;
@@ -236,16 +250,9 @@ __global__ void __launch_bounds__(512) k_att_fwd_graph(const int* __restrict__ g
     __shared__ int sp_s[MAXR + 1];
     __shared__ short sd_s[GP_E], sr_s[GP_E];
     __shared__ float a0_s[GP_E], a1_s[GP_E];
-    const int pv = gs.ptr[g0 + min(t, rows)], pn = gs.ptr[g0 + min(t + 1, rows)];
-    const int e0 = gs.ptr[g0], ne = gs.ptr[g0 + rows] - e0;
     if (ne > GP_E || ne < 0) { if (t == 0) atomicOr(status, 8); return; }
-    int nd[2], ed[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int s = e0 + max(min(t + u * 512, ne - 1), 0);
-        nd[u] = ne > 0 ? gs.nbr[s] : g0;
-        ed[u] = ne > 0 ? gs.eid[s] : 0;
-    }
+    asm volatile("" : "+v"(pv), "+v"(pn), "+v"(nd[0]), "+v"(nd[1]), "+v"(ed[0]), "+v"(ed[1]));
+    if (ne <= 0) { nd[0] = nd[1] = g0; ed[0] = ed[1] = 0; }      // no slot of this graph exists: the clamped loads fetched no index
     if (t <= rows) sp_s[t] = pv - e0;
     if (t < rows) for (int s = pv - e0; s < pn - e0; ++s) sr_s[s] = (short)t;
 #pragma unroll
