@@ -620,28 +620,31 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
         else gb_mma<1, 1, GB_LDJ, GB_LDW>(Zt + li, nullptr, Wt + w * 32 + li, nullptr, GC_N, lk, ident, acc);
         const int k = w * 32 + li;
         float* dxp = sl ? a.dxp1 : a.dxp0;
-        // x_hat of all 32 rows first (one batch of LDS reads; rows past the graph are zero, as are their dz), then the
-        // sums without guards and the stores alone under the row guard: with the LDS read and the fp64 chain inside the
-        // guarded block this loop ran one ~140 ns iteration at a time (4.5 us of a 27 us kernel)
+        // x_hat of all rows as ONE batch of unconditional LDS reads, masked afterwards, and a lane's 32 terms summed in
+        // fp32 (see k_gconv_bwd: the `q < R ? Xs[..] : 0` form is 32 branches with a ds_read + wait each)
         float xh[2][16];
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xh[q][r] = q < R ? Xs[(q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * GB_LDX + k] : 0.f;
-        double s1 = 0.0, s2 = 0.0;
+            for (int r = 0; r < 16; ++r) xh[q][r] = Xs[(q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * GB_LDX + k];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { asm volatile("" : "+v"(xh[q][r])); if (q >= R) xh[q][r] = 0.f; }
+        float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            if (q < R) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    const float v = acc[q][r];
-                    if (i < rows) dxp[(size_t)(g0 + i) * K + k] = v;
-                    s1 += (double)v;
-                    s2 += (double)v * (double)xh[q][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int i = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                const float v = acc[q][r];                   // (row tile 1 of a one-tile graph: zero accumulators)
+                if (i < rows) dxp[(size_t)(g0 + i) * K + k] = v;
+                f1[r & 3] += v;
+                f2[r & 3] = fmaf(v, xh[q][r], f2[r & 3]);
             }
         }
+        double s1 = ((double)f1[0] + (double)f1[1]) + ((double)f1[2] + (double)f1[3]);
+        double s2 = ((double)f2[0] + (double)f2[1]) + ((double)f2[2] + (double)f2[3]);
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         if (lk == 0) { parts[k] = s1; parts[K + k] = s2; }
