@@ -337,6 +337,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     __shared__ float al_s[GGB_E + T], ak_s[GGB_E + T], dk_s[GGB_E + T], S_s[T];     // per slot (edges, then self loops), current head
     __shared__ float att_s[2 * GC_N];
     __shared__ float ad_s[2][T], as_s[2][T], mx_s[2][T], dn_s[2][T], dad_s[2][T], das_s[2][T];
+    BLK_CLK(0);
     const int b = blockIdx.x, sl = blockIdx.y, ns0 = sl * GC_N, t = threadIdx.x;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
     const int lane = t & 63, li = lane & 31, lk = lane >> 5;
@@ -369,35 +370,46 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     ro_issue<GB_NT>(bz, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(a.z + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
     ro_issue<GB_NT>(bx, rows, K4, [&](int i, int k4) { return *reinterpret_cast<const float4*>(a.x + (size_t)(g0 + i) * K + 4 * k4); });
     ro_issue<GB_NT>(bw, K, 16, [&](int k, int n4) { return *reinterpret_cast<const float4*>(a.W + (size_t)k * H + ns0 + 4 * n4); });
-    const int pv = g.ptr[g0 + min(t, rows)];
+    // the small operands: unconditional loads on clamped indices, pinned below (branch-free prologue, see BNRaw in engine.hpp:
+    // as selects / guarded blocks they were six serial round trips behind the tile loads)
+    int pv = g.ptr[g0 + min(t, rows)], pn = g.ptr[g0 + min(t + 1, rows)];
     int nv[2], ev[2];
+    const int slot_hi = max(g.nnz - 1, 0);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int s = e0 + max(min(t + u * GB_NT, ne - 1), 0);
-        nv[u] = ne > 0 ? g.nbr[s] : g0;
-        ev[u] = ne > 0 ? g.eid[s] : 0;
+        const int s = min(e0 + max(min(t + u * GB_NT, ne - 1), 0), slot_hi);
+        nv[u] = g.nbr[s];
+        ev[u] = g.eid[s];
     }
     // forward scores of this slice's heads: lane (kind, head, node) = (t >> 7, (t >> 6) & 1, t & 63)
     const int sn = t & 63, sh = (t >> 6) & 1, sk = t >> 7;
-    float scv = 0.f;
-    if (sh < hs) {
-        const float* src = sk == 0 ? a.adst : (sk == 1 ? a.asrc : (sk == 2 ? a.mx : a.den));
-        scv = src[(size_t)(g0 + min(sn, rows - 1)) * a.heads + h0 + sh];
+    const float* ssrc = sk == 0 ? a.adst : (sk == 1 ? a.asrc : (sk == 2 ? a.mx : a.den));
+    float scv = ssrc[(size_t)(g0 + min(sn, rows - 1)) * a.heads + h0 + min(sh, hs - 1)];
+    float attv = a.att[(size_t)h0 * 2 * D + min(t, 2 * GC_N - 1)];
+    BNRaw braw = bn_raw_load(a.bn, min(t, K - 1));
+    BNRaw uraw;
+    double ud1 = 0.0, ud2 = 0.0;
+    if (UP) {
+        const int c = ns0 + (t & (GC_N - 1));
+        uraw = bn_raw_load(a.ubn, c);
+        ud1 = a.udot_sum[c]; ud2 = a.udot_prod[c];
     }
-    const float attv = t < 2 * GC_N ? a.att[(size_t)h0 * 2 * D + t] : 0.f;
+    bn_raw_pin(braw);
+    if (UP) { bn_raw_pin(uraw); asm volatile("" : "+v"(ud1), "+v"(ud2)); }
+    asm volatile("" : "+v"(pv), "+v"(pn), "+v"(nv[0]), "+v"(nv[1]), "+v"(ev[0]), "+v"(ev[1]), "+v"(scv), "+v"(attv));
+    if (ne <= 0) { nv[0] = g0; nv[1] = g0; ev[0] = 0; ev[1] = 0; }   // no slot of this graph exists: the clamped loads fetched no index
+    if (sh >= hs) scv = 0.f;
+    if (t >= 2 * GC_N) attv = 0.f;
     if (t < K) {
-        float m1[1], r1[1];
-        bn_mean_rstd_v<1>(a.bn, t, m1, r1);
-        mean_s[t] = m1[0]; rstd_s[t] = r1[0];
-        gam_s[t] = a.bn.gamma ? a.bn.gamma[t] : 1.f;
-        bet_s[t] = a.bn.beta ? a.bn.beta[t] : 0.f;
+        float m1, r1;
+        bn_raw_mean_rstd(a.bn, braw, m1, r1);
+        mean_s[t] = m1; rstd_s[t] = r1;
+        gam_s[t] = braw.g;
+        bet_s[t] = braw.b;
     }
     // ---- stage everything in LDS -----------------------------------------------------------------------------------
     if (t <= rows) ptr_s[t] = pv - e0;
-    {
-        const int pn = g.ptr[g0 + min(t + 1, rows)];        // (second pointer of this lane's row: one more load in the first round)
-        if (t < rows) for (int s = pv - e0; s < pn - e0; ++s) er[s] = (signed char)t;
-    }
+    if (t < rows) for (int s = pv - e0; s < pn - e0; ++s) er[s] = (signed char)t;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int s = t + u * GB_NT;
@@ -415,13 +427,12 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     if (t < 2 * GC_N) att_s[t] = attv;
     if (t < 2 * T) { dad_s[t >> 6][t & 63] = 0.f; das_s[t >> 6][t & 63] = 0.f; }
     if (UP && t >= 256 && t < 256 + GC_N) {              // upper BatchNorm constants of this slice's 64 columns
-        const int c = ns0 + t - 256;
-        float m1[1], r1[1];
-        bn_mean_rstd_v<1>(a.ubn, c, m1, r1);
-        um_s[t - 256] = m1[0]; ur_s[t - 256] = r1[0];
-        ug_s[t - 256] = (a.ubn.gamma ? a.ubn.gamma[c] : 1.f) * r1[0];
-        u1_s[t - 256] = (float)(a.udot_sum[c] * (double)a.ubn.inv_n);
-        u2_s[t - 256] = (float)(a.udot_prod[c] * (double)a.ubn.inv_n);
+        float m1, r1;
+        bn_raw_mean_rstd(a.ubn, uraw, m1, r1);
+        um_s[t - 256] = m1; ur_s[t - 256] = r1;
+        ug_s[t - 256] = uraw.g * r1;
+        u1_s[t - 256] = (float)(ud1 * (double)a.ubn.inv_n);
+        u2_s[t - 256] = (float)(ud2 * (double)a.ubn.inv_n);
     }
     if (!UP) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
     ro_commit<GB_NT>(bz, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Zr + j * GB_LDD + 4 * n4) = v; });
@@ -488,6 +499,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     const uint64_t seed = step_seed(a.seed, a.ctr);
     const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
     const int rt = w >> 1, ct = w & 1;                   // waves 0-3: the 32 x 32 tile (rt, ct) of a 64 x 64 product
+    BLK_CLK(2);
     // ---- the heads of the slice, one after the other ------------------------------------------------------------------
     for (int h = 0; h < hs; ++h) {
         const int hg = h0 + h;
@@ -584,6 +596,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
         }
         __syncthreads();
     }
+    BLK_CLK(3);
     // ---- dz = aggregated part + the two rank-1 terms; d att of this slice's heads -----------------------------------------
     if (w < 4 && rt < R) {
         const int n = ct * 32 + li, hh = n / D, d = n % D;
@@ -665,6 +678,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
                 slab[(size_t)kk * H + ns0 + q * 32 + li] = acc[q][r];
             }
     }
+    BLK_CLK(1);
 }
 
 }  // namespace cal
