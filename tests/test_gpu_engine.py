@@ -559,3 +559,43 @@ def test_model_variants_on_the_engine(name, kw, fused):
     out = eng.forward(bd, perm.to(DEV), training=False)
     for r, t in zip(ref, out):
         assert (r - t.cpu()).abs().max().item() < LOGIT_TOL
+
+
+def test_one_launch_readout_and_in_kernel_adam_equal_the_separate_launches():
+    """k_ro_step (readout forward + backward as one launch) and Adam inside k_finish against the launch sequences they
+    replace (CAL_AMD_RO_STEP=0: k_ro_fwd_a/fwd_b/bwd_a/bwd_b, CAL_AMD_ADAM_FUSED=0: k_adam): two Adam steps on the same
+    batch, same permutation; logits, losses, every gradient, parameter, moment and the step counter agree to rounding
+    (the logits are summed over the hidden chunks in a different order, nothing else differs)."""
+    b, bd = _config2_batch(96, seed=23)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=128, layers=3)
+    perm = torch.randperm(96, generator=torch.Generator().manual_seed(3)).to(DEV)
+    runs = []
+    for env in ({"CAL_AMD_RO_STEP": "0", "CAL_AMD_ADAM_FUSED": "0"}, {}):
+        old = {k: os.environ.get(k) for k in ("CAL_AMD_RO_STEP", "CAL_AMD_ADAM_FUSED")}
+        os.environ.update(env)
+        try:
+            m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(), lr=1e-2)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        out = []
+        for _ in range(2):
+            stats = eng.train_step(bd, perm, adam=True).cpu().numpy().copy()
+            out.append((stats, eng.buffer("logp", 3 * 96 * 4).cpu().numpy().copy()))
+        runs.append((out, {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()},
+                     {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters()},
+                     (eng.exp_avg.cpu().numpy().copy(), eng.exp_avg_sq.cpu().numpy().copy(), float(eng.step_count.item()))))
+        eng.check_status()
+    (o0, p0, g0, m0), (o1, p1, g1, m1) = runs
+    for (s0, l0), (s1, l1) in zip(o0, o1):
+        assert np.abs(l0 - l1).max() < 2e-5
+        assert np.allclose(s0[:5], s1[:5], atol=2e-5)
+    for k in p0:
+        assert np.allclose(g0[k], g1[k], atol=2e-6, rtol=2e-3), k
+        assert np.allclose(p0[k], p1[k], atol=2e-4, rtol=1e-3), k
+    assert m0[2] == m1[2] == 2.0                  # both sequences advanced the step counter once per step
+    assert np.allclose(m0[0], m1[0], atol=1e-6, rtol=2e-3)
+    assert np.allclose(m0[1], m1[1], atol=1e-9, rtol=4e-3)
