@@ -320,7 +320,9 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     }
     RO_CLK(38);
     // ---- epilogue: bias, ReLU, store, column sums of this graph ---------------------------------------------------
-    double s1 = 0.0, s2 = 0.0;
+    // a lane's <= 32 terms of the column sums in fp32 (four chains, masked, no guards: inside the row guard every element
+    // was a branch with two fp64 conversions and two dependent fp64 adds), everything across lanes / graphs in fp64
+    float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
     float psum = 0.f;
     const int col = n0 + ct * 32 + li;
     asm volatile("" :: "v"(bias));                       // consume the bias load before the guarded stores (see gemm.hip)
@@ -330,10 +332,9 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
             const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             float v = acc0[r] + bias;
             if (relu) v = fmaxf(v, 0.f);
-            if (row < rows) {
-                br.out[(size_t)(g0 + row) * H + col] = v;
-                s1 += (double)v; s2 += (double)v * (double)v; psum += v;
-            }
+            if (row < rows) br.out[(size_t)(g0 + row) * H + col] = v;
+            const float vm = row < rows ? v : 0.f;
+            f1[r & 3] += vm; f2[r & 3] = fmaf(vm, vm, f2[r & 3]);
         }
         if (r0 + 2 < R) {
 #pragma unroll
@@ -341,13 +342,15 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
                 const int row = (r0 + 2) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 float v = acc1[r] + bias;
                 if (relu) v = fmaxf(v, 0.f);
-                if (row < rows) {
-                    br.out[(size_t)(g0 + row) * H + col] = v;
-                    s1 += (double)v; s2 += (double)v * (double)v; psum += v;
-                }
+                if (row < rows) br.out[(size_t)(g0 + row) * H + col] = v;
+                const float vm = row < rows ? v : 0.f;
+                f1[r & 3] += vm; f2[r & 3] = fmaf(vm, vm, f2[r & 3]);
             }
         }
     }
+    psum = (f1[0] + f1[1]) + (f1[2] + f1[3]);
+    double s1 = ((double)f1[0] + (double)f1[1]) + ((double)f1[2] + (double)f1[3]);
+    double s2 = ((double)f2[0] + (double)f2[1]) + ((double)f2[2] + (double)f2[3]);
     // lanes lk = 0 / 1 hold different rows of the same column; waves w and w ^ 2 hold the other row tiles
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);

@@ -89,32 +89,42 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
         const int idx = t + u * 256, k = min(idx >> 4, K - 1), j4 = idx & 15;
         vb[u] = *reinterpret_cast<const float4*>(a.W + (size_t)k * H + n0 + 4 * j4);
     }
-    const int pv = g.ptr[g0 + min(t, rows)];
+    // small operands: unconditional loads on clamped indices / substituted pointers, pinned with the tiles (branch-free
+    // prologue, BNRaw in engine.hpp)
+    int pv = g.ptr[g0 + min(t, rows)];
     int nv[4], ev[4];
-    if (ne > 0) {
+    const int slot_hi = max(g.nnz - 1, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s = e0 + min(t + u * 256, ne - 1);
-            nv[u] = g.nbr[s];
-            ev[u] = g.eid[s];
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { nv[u] = g0; ev[u] = 0; }
+    for (int u = 0; u < 4; ++u) {
+        const int s = min(e0 + max(min(t + u * 256, ne - 1), 0), slot_hi);
+        nv[u] = g.nbr[s];
+        ev[u] = g.eid[s];
     }
-    const float attv = t < 2 * GC_N ? a.att[(size_t)h0 * 2 * D + t] : 0.f;       // hs heads x 2 D = 128 floats, contiguous
+    float attv = a.att[(size_t)h0 * 2 * D + min(t, 2 * GC_N - 1)];       // hs heads x 2 D = 128 floats, contiguous
     const int lane = t & 63, li = lane & 31, lk = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ct = w & 1, r0 = w >> 1;
-    const float bias = a.bias ? a.bias[n0 + ct * 32 + li] : 0.f;
-    if (t < K) {
-        bn_scale_shift(a.bn, t, sc_s[t], sh_s[t]);
-        if (a.bn.update && blockIdx.x == 0 && blockIdx.y == 0) bn_update_running(a.bn, t);
-    }
+    const float* biasp = a.bias ? a.bias : a.W;          // W: any valid [>= H] float array; the value is masked below
+    float bias = biasp[n0 + ct * 32 + li];
+    BNRaw braw = bn_raw_load(a.bn, min(t, K - 1));
 #pragma unroll
     for (int u = 0; u < UA; ++u) ro_pin(va[u]);
 #pragma unroll
     for (int u = 0; u < 8; ++u) ro_pin(vb[u]);
+    bn_raw_pin(braw);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]));
+    asm volatile("" : "+v"(pv), "+v"(attv), "+v"(bias));
+    if (!a.bias) bias = 0.f;
+    if (t >= 2 * GC_N) attv = 0.f;
+    if (ne <= 0) {                                       // no slot of this graph exists: the clamped loads fetched no index
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { nv[u] = g0; ev[u] = 0; }
+    }
+    if (t < K) {
+        bn_raw_scale_shift(a.bn, braw, sc_s[t], sh_s[t]);
+        if (a.bn.update && blockIdx.x == 0 && blockIdx.y == 0) bn_raw_update_running(a.bn, braw, t);
+    }
     // ---- stage everything in LDS ---------------------------------------------------------------------------
     if (t <= rows) ptr_s[t] = pv - e0;
     if (t < 2 * GC_N) att_s[t] = attv;
@@ -255,21 +265,26 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
     for (int i = 0; i < 16; ++i) acc0[i] = 0.f;
     if (r0 < R) gconv_mma<false, LDA, GC_LDZ>(At + (size_t)((ct * 32) / D) * T * LDA, Zs, rowsP, r0, ct, li, lk, acc0, acc1);
     // ---- epilogue: bias, ReLU, store, column sums of this graph ---------------------------------------------------
-    double s1 = 0.0, s2 = 0.0;
+    // (a lane's 16 terms of the column sums in fp32, masked and unguarded, as in k_gconv_fwd; the denominators in one batch)
+    float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
     const int col = n0 + ct * 32 + li;
     asm volatile("" :: "v"(bias));
     if (r0 < R) {
+        float idn[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) idn[r] = idn_s[(ct * 32) / D][min(r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, T - 1)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             // softmax denominator of (row, head of this column tile), then bias; the backbone always applies ReLU (model.py:390)
-            const float v = fmaxf(fmaf(acc0[r], idn_s[(ct * 32) / D][min(row, T - 1)], bias), 0.f);
-            if (row < rows) {
-                a.out[(size_t)(g0 + row) * H + col] = v;
-                s1 += (double)v; s2 += (double)v * (double)v;
-            }
+            const float v = fmaxf(fmaf(acc0[r], idn[r], bias), 0.f);
+            if (row < rows) a.out[(size_t)(g0 + row) * H + col] = v;
+            const float vm = row < rows ? v : 0.f;
+            f1[r & 3] += vm; f2[r & 3] = fmaf(vm, vm, f2[r & 3]);
         }
     }
+    double s1 = ((double)f1[0] + (double)f1[1]) + ((double)f1[2] + (double)f1[3]);
+    double s2 = ((double)f2[0] + (double)f2[1]) + ((double)f2[2] + (double)f2[3]);
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (lk == 0) { red[w][0][li] = s1; red[w][1][li] = s2; }
