@@ -8,10 +8,17 @@ from cal_amd.engine import StepEngine
 args = argparse.Namespace(layers=3, hidden=128, with_random=True, without_node_attention=False,
                           without_edge_attention=False, fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
 torch.manual_seed(0)
-m = getattr(M, os.environ.get("CAL_STAGE_MODEL", "CausalGCN"))(10, 4, args).cuda().train()
+if os.environ.get("CAL_STAGE_DATA") == "nci1":          # config 4 stand-in: 512 NCI1-like graphs, F = 139, 2 classes
+    from cal_amd import synth
+    gl = synth.tu_like(512, kind="nci1", seed=5)
+    nf, nc = 139, 2
+else:
+    gl = spmotif.train_mix(128, seed=5)
+    nf, nc = 10, 4
+m = getattr(M, os.environ.get("CAL_STAGE_MODEL", "CausalGCN"))(nf, nc, args).cuda().train()
 eng = StepEngine(m)
-b = Batch.from_data_list(spmotif.train_mix(128, seed=5)).to("cuda")
-perm = torch.randperm(128, device="cuda")
+b = Batch.from_data_list(gl).to("cuda")
+perm = torch.randperm(len(gl), device="cuda")
 eng.train_step(b, perm, adam=False)
 torch.cuda.synchronize()
 def timed(stop, reps=30, inner=10):
