@@ -12,7 +12,10 @@
 //   * BatchNorm-backward column sums ride on the GEMM that produces the incoming gradient;
 //   * all parameter gradients that are column sums go through one fp64 arena and one commit
 //     kernel; split-K weight-gradient slabs are reduced deterministically in the same launch;
-//   * Adam is one fused kernel over the flat parameter buffer.
+//   * the three readout heads (BN -> fc1 -> ReLU -> BN -> fc2 -> log_softmax -> loss) and their backward are ONE launch
+//     of resident workgroups that meet at two in-kernel barriers per head (engine_ro_step.hpp);
+//   * Adam runs inside that last commit kernel for single-process steps (every gradient element is updated by the
+//     thread that finishes it), as one kernel over the flat parameter buffer after a gradient exchange.
 #include <string.h>
 
 #include <algorithm>

@@ -7,7 +7,7 @@ MI355X-first choices (DESIGN.md section "step engine"):
   ONE flat gradient buffer -> Adam is a single fused update over one tensor and
   the data-parallel exchange is a single RCCL all-reduce of ~0.5 MB
   (latency-bound on xGMI, so: one bucket, one call);
-* CausalGCN / CausalGAT run on the native step engine (cal_amd/csrc/engine.hip):
+* CausalGCN / CausalGAT / CausalGIN run on the native step engine (cal_amd/csrc/engine.hip):
   forward + 3-term loss + backward + Adam are a few dozen fused kernels enqueued
   by ONE C call; other models run the operator-level autograd path
   (cal_amd.ops) with torch's loss / Adam;
