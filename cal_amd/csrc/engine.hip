@@ -341,7 +341,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
         if (assign) e->arena = (double*)tmp;
         // partial rows of the cross-row sums: <= 1024 producer blocks x (2..6)H columns per set,
         // ~(3L + 16) sets alive per step
-        size_t pcap = (N + 15) / 16 + 1;
+        size_t pcap = std::max<size_t>((N + 15) / 16 + 1, (std::min<int64_t>(N, 16384) + 7) / 8 + 1);
         size_t pd = pcap * (size_t)H * 2 * (3 * L + 20);
         F32(tmp, 2 * pd);
         if (assign) { e->parts = (double*)tmp; e->parts_doubles = pd; }
@@ -477,7 +477,12 @@ int flush_finals(Ctx& c) {
 }
 // aggregation launches: one feature row per lane group when nothing is reduced across rows
 // (most waves in flight for the gather), two rows per group when the epilogue carries statistics
-int spmm_rpb(int H, bool stats) { const int rows = 256 / group_for(H, 4); return stats ? 2 * rows : rows; }
+int spmm_rpb(int H, bool stats, int N = 1 << 30) {
+    // (small batches are latency-bound: a second row per group is a second chain of three dependent gathers, 14 vs 8 us
+    //  at 7.5 k nodes -- one row per group there, the partial-row buffer holds N / 8 rows up to 16 k nodes)
+    const int rows = 256 / group_for(H, 4);
+    return stats && N > 16384 ? 2 * rows : rows;
+}
 Acc spmm_acc(Ctx& c, double* dst, int cols, int rpb) {
     const int P = cdiv(c.N, rpb);
     double* p = parts_alloc(c, (size_t)P * cols);
@@ -869,7 +874,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         { ProfScope ps(st, 0, 2.0 * N * H * H); RC(fwd_gemm(c, false, a, 1)); } STAGE();
         SpmmBranch br{e->z, e->h + (size_t)i * NH, e->P + e->o_conv_b[i - 1], nullptr, e->dis_unit, Acc(), Acc()};
         const bool wst = c.training && i < L;
-        const int rpb = spmm_rpb(H, wst);
+        const int rpb = spmm_rpb(H, wst, N);
         if (wst) { br.st_sum = spmm_acc(c, bn_stsum(c, i + 1), H, rpb); br.st_sq = spmm_acc(c, bn_stsq(c, i + 1), H, rpb); }
         {
             ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0);

@@ -254,10 +254,26 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch b0,
             }
         }
         if (want) {
+            // the block's column sums: row groups of a wave by shuffle, the four waves through LDS, one lane per column
+            // (2 x 2 barriers; eight block_col_atomic calls were 16 barriers with 32 lanes adding serially: 6 of the
+            //  kernel's 14 us at 7.5 k rows)
+            double* L = &lds[0][0];
+            const int wv = threadIdx.x >> 6, ncol = G * VEC, cbase = c - l * VEC;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                block_col_atomic(s1[j], l * VEC + j, grp, RPB, G * VEC, cok, br.st_sum, c + j, lds[0]);
-                block_col_atomic(s2[j], l * VEC + j, grp, RPB, G * VEC, cok, br.st_sq, c + j, lds[0]);
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    double v = cok ? (pass ? s2[j] : s1[j]) : 0.0;
+                    if (G < 64) for (int off = G; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+                    if ((threadIdx.x & 63) < G) L[wv * ncol + l * VEC + j] = v;
+                }
+                __syncthreads();
+                if ((int)threadIdx.x < ncol && cbase + (int)threadIdx.x < H) {
+                    const int q = threadIdx.x;
+                    const double t = (L[q] + L[ncol + q]) + (L[2 * ncol + q] + L[3 * ncol + q]);
+                    (pass ? br.st_sq : br.st_sum).add(cbase + q, t);
+                }
+                __syncthreads();
             }
         }
     }

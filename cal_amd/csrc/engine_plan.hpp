@@ -63,17 +63,26 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     if (t < 128) fs[t >> 6][t & 63] = 0.0;
     __syncthreads();
     if (x0) {
-        for (int i0 = t; i0 - t < rows * F; i0 += 4 * 256) {
-            float v[4];
+        // lane t of the first (256 / F) F lanes walks the elements t, t + lanes, ..: its column (t % F) is fixed, so it sums
+        // in registers (<= ~10 terms, fp32) and adds ONE pair of values to the LDS accumulators -- one fp64 LDS atomic per
+        // element was 480 serialised updates per address at 240-node graphs (5 us of this kernel)
+        const int lanes = (256 / F) * F, tot = rows * F;
+        float s1 = 0.f, s2 = 0.f;
+        if (t < lanes) {
+            for (int i0 = t; i0 < tot; i0 += 4 * lanes) {
+                float v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = x0[(size_t)g0 * F + min(i0 + u * 256, rows * F - 1)];
+                for (int u = 0; u < 4; ++u) v[u] = x0[(size_t)g0 * F + min(i0 + u * lanes, tot - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u]));
+                for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(v[u]));
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * 256;
-                if (i < rows * F) { const double d = (double)v[u]; atomicAdd(&fs[0][i % F], d); atomicAdd(&fs[1][i % F], d * d); }
+                for (int u = 0; u < 4; ++u) {
+                    const float vv = i0 + u * lanes < tot ? v[u] : 0.f;
+                    s1 += vv; s2 = fmaf(vv, vv, s2);
+                }
             }
+            atomicAdd(&fs[0][t % F], (double)s1);
+            atomicAdd(&fs[1][t % F], (double)s2);
         }
     }
     if (t < rows && bv != b) atomicOr(status, 2);
