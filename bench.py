@@ -268,7 +268,8 @@ def engine_roofline(trainer, batches, workload, iters=20):
         dur, work, per_step = out[key]
         ach = work / dur / 1e12
         d = dict(bound="mfma", kernel=mfma[key][1], achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3,
-                 traffic=pmc.get(mfma[key][2], {}).get("bytes_per_launch"), avg_launch_us=dur * 1e6,
+                 traffic=(pmc.get(mfma[key][2]) or pmc.get(mfma[key][2].replace("k_gemm_dual", "k_gemm_big_dual")) or {}).get("bytes_per_launch"),
+                 avg_launch_us=dur * 1e6,
                  algorithmic_flops_per_launch=work, timed_launches_per_step=per_step, note=note)
         roof["roofline" if key == best else "roofline_" + mfma[key][0]] = d
     if "spmm" in out:
