@@ -307,26 +307,56 @@ __device__ __forceinline__ void block(const GemmArgs& a, int bx, int by, int bz,
     }
 }
 
+// workgroup b of a 1-D grid -> (outer, inner): the `inner` tiles of one `outer` index (they share an operand strip) sit 8
+// workgroup ids apart, i.e. on the same XCD (ids are dealt round-robin) right after one another; the last outer % 8
+// indices keep the plain order
+__device__ __forceinline__ void xcd_order(int b, int outer, int inner, int& o, int& i) {
+    const int full = (outer >> 3) * 8 * inner;
+    if (b < full) { const int grp = b / (8 * inner); o = grp * 8 + (b & 7); i = (b >> 3) % inner; }
+    else { const int r = b - full, rem = outer & 7; o = (outer >> 3) * 8 + r % rem; i = r / rem; }
+}
 template <bool A_KC, bool B_KC, int XA>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gemm_big(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Smem<A_KC, B_KC>::FLOATS];
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    block<A_KC, B_KC, XA>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem, lin >= 256 && lin < 512);
+    // tiles that share an operand strip back to back on one XCD (xcd_order below): the column tiles of a row tile for the
+    // node-level products (A_KC), the output tiles of a split-K slice for the weight gradients
+    const int per = gridDim.x * gridDim.y;
+    int bx, by, bz;
+    if (A_KC) {
+        bz = lin / per;
+        xcd_order(lin - bz * per, gridDim.x, gridDim.y, bx, by);
+    } else {
+        int tl;
+        xcd_order(lin, gridDim.z, per, bz, tl);
+        bx = tl % gridDim.x; by = tl / gridDim.x;
+    }
+    block<A_KC, B_KC, XA>(a, bx, by, bz, smem, lin >= 256 && lin < 512);
 }
 
 // dX = dZ W^T (NT) and dW = op(X)^T dZ (TN, split-K) of one layer in one grid: the short NT tiles first, the long
 // split-K slices after them; the two sets fill each other's tails (as k_gemm_dual does at config-2 scale)
-struct Grid2 { int gx1, gy1, n1; int gx2, gy2; };
+struct Grid2 { int gx1, gy1, n1; int gx2, gy2, nz2; };
 template <int XA2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gemm_big_dual(const GemmArgs a1, const GemmArgs a2, const Grid2 g) {
     constexpr int F1 = Smem<true, true>::FLOATS, F2 = Smem<false, false>::FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[F1 > F2 ? F1 : F2];
     int b = blockIdx.x;
     if (b < g.n1) {
-        block<true, true, 0>(a1, b % g.gx1, (b / g.gx1) % g.gy1, b / (g.gx1 * g.gy1), smem, b >= 256 && b < 512);
+        // the column tiles of one row tile read the same dZ rows: back to back on ONE XCD (xcd_order), so the second read is
+        // an L2 hit -- in row-tile-major order they were 1250 workgroups apart on different XCDs and the strip came from HBM
+        // once per column tile (1.78 GB per launch against 0.53 GB algorithmic)
+        const int per = g.gx1 * g.gy1, bz = b / per;
+        int rt, ct;
+        xcd_order(b - bz * per, g.gx1, g.gy1, rt, ct);
+        block<true, true, 0>(a1, rt, ct, bz, smem, b >= 256 && b < 512);
     } else {
         b -= g.n1;
-        block<false, false, XA2>(a2, b % g.gx2, (b / g.gx2) % g.gy2, b / (g.gx2 * g.gy2), smem, false);
+        // likewise the gx2 * gy2 output tiles of one split-K slice (same 1024-node strips of both operands)
+        const int tiles = g.gx2 * g.gy2;
+        int z, tl;
+        xcd_order(b, g.nz2, tiles, z, tl);
+        block<false, false, XA2>(a2, tl % g.gx2, tl / g.gx2, z, smem, false);
     }
 }
 
@@ -401,7 +431,7 @@ int launch_gemm_big_dual(const GemmArgs& ax, int nbx, const GemmArgs& aw, int nb
     }
     big::Grid2 g;
     g.gx1 = cdiv(ax.M, big::T); g.gy1 = cdiv(ax.N, big::T); g.n1 = g.gx1 * g.gy1 * nbx;
-    g.gx2 = cdiv(aw.M, big::T); g.gy2 = cdiv(aw.N, big::T);
+    g.gx2 = cdiv(aw.M, big::T); g.gy2 = cdiv(aw.N, big::T); g.nz2 = nbw * aw.nsplit;
     const dim3 grid(g.n1 + g.gx2 * g.gy2 * nbw * aw.nsplit);
     if (xw == 0) hipLaunchKernelGGL((big::k_gemm_big_dual<0>), grid, dim3(256), 0, stream, ax, aw, g);
     else if (xw == 1) hipLaunchKernelGGL((big::k_gemm_big_dual<1>), grid, dim3(256), 0, stream, ax, aw, g);
