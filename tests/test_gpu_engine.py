@@ -552,6 +552,10 @@ def test_model_variants_on_the_engine(name, kw, fused):
             assert float(p.grad.abs().max()) == 0.0, k
         else:
             assert torch.allclose(p.grad.cpu(), gref, atol=5e-5, rtol=2e-3), k
+            # the Adam update (inside k_finish on this path), where the gradient is not numerically zero: every
+            # parameter of every variant is finished by some task of that kernel or covered by an update-only range
+            mask = gref.abs() > 1e-5
+            assert torch.allclose(p.detach().cpu()[mask], tr.sd[k].detach()[mask], atol=3e-5, rtol=1e-3), k
     # eval-mode forward of the same variant
     m.eval()
     sde = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if not k.endswith(".eps")}
