@@ -240,10 +240,10 @@ def engine_roofline(trainer, batches, workload, iters=20):
     if workload == HEADLINE:
         note = ("config-2 working set (3.7 MB activations) is cache-resident and every launch is a few hundred "
                 "workgroups of one ~10 us dependent chain: the step is latency-bound by construction (SURVEY.md 8d); "
-                "event pairs include the launch gap")
+                "events are attached to the dispatch (hipExtLaunchKernelGGL start/stop) in an eager replica of the step")
     else:
-        note = ("event pairs include the launch gap" if pmc else
-                "event pairs include the launch gap; no PMC pass was collected for this workload (traffic null)")
+        note = ("single-kernel classes: events attached to the dispatch (hipExtLaunchKernelGGL start/stop), eager step" if pmc else
+                "single-kernel classes: events attached to the dispatch, eager step; no PMC pass was collected for this workload (traffic null)")
     mfma = {
         "gemm": ("k_gemm", "k_gemm / k_gemm_big<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers, unfused path; 128x128 tiles from 16k rows)", "k_gemm_backbone"),
         "gconv": ("k_gconv_fwd", "k_gconv_fwd: per-graph fused BN + [n,H]x[H,64] MFMA GEMM + dense-block aggregation MFMA + "

@@ -17,6 +17,7 @@
 //   * Adam runs inside that last commit kernel for single-process steps (every gradient element is updated by the
 //     thread that finishes it), as one kernel over the flat parameter buffer after a gradient exchange.
 #include <string.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -601,6 +602,38 @@ int dual_gemm(Ctx& c, GemmArgs& ax, int nbx, GemmArgs& aw, int nbw, float** dst,
     return launch_gemm_dual(ax, nbx, aw, nbw, c.st);
 }
 
+// live kernel timing for bench.py's roofline block: when enabled, HIP events are attached to the backbone's kernels:
+// unfused forward GEMM ([N,H]x[H,H], class 0), aggregation (k_espmm forward / transposed backward, class 1), per-graph
+// fused convolution forward (class 2, flops), the backward's dX + dW dual GEMM (class 3, flops), the per-graph fused
+// backward (class 4, flops), the GATConv classes 5-8.  Single-kernel scopes (`single`) launch their kernel with
+// hipExtLaunchKernelGGL, which stamps the two events with the START and END of that dispatch -- the kernel's own
+// duration, what rocprofv3 reports; event records on the stream around the launch also measured the two marker packets
+// and the gap between them (20.1 against 16.1 us for k_gconv_bwd).  Multi-kernel scopes (the GEMM helpers of gemm*.hip,
+// the GAT backward) keep the records around the launches.  Events are created here (never in a normal step).
+struct ProfRec { hipEvent_t e0, e1; int cls; double work; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+struct ProfScope;
+static ProfScope* g_prof_cur = nullptr;
+struct ProfScope {
+    hipStream_t st; bool on, single, used; ProfRec r;
+    ProfScope(hipStream_t s, int cls, double work, bool single_kernel = false) : st(s), on(g_prof_on), single(single_kernel), used(false) {
+        if (!on) return;
+        r.cls = cls; r.work = work;
+        hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+        if (single) g_prof_cur = this; else hipEventRecord(r.e0, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        if (single) { g_prof_cur = nullptr; if (used) g_prof.push_back(r); }
+        else { hipEventRecord(r.e1, st); g_prof.push_back(r); }
+    }
+};
+// launch inside a single-kernel ProfScope: the dispatch carries the scope's events when profiling is on
+#define PROF_LAUNCH(kernel, grid, block, shmem, stream, ...) do { \
+        if (g_prof_cur) { hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, g_prof_cur->r.e0, g_prof_cur->r.e1, 0, __VA_ARGS__); g_prof_cur->used = true; } \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); } while (0)
+
 // per-graph fused convolution (engine_gconv.hpp): needs the batch's per-graph bounds from the host
 bool use_gc(const Ctx& c) {
     const Engine* e = c.e;
@@ -636,9 +669,9 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
         final_task(c, p + H, B * nsl, 2 * H, H, dprod[k]);
     }
     const dim3 grid(B, nsl, nb);
-    if (rs) hipLaunchKernelGGL((k_gconv_bwd<true, 2>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
-    else if (gb[0].dout) hipLaunchKernelGGL((k_gconv_bwd<false, 0>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
-    else hipLaunchKernelGGL((k_gconv_bwd<false, 1>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    if (rs) PROF_LAUNCH((k_gconv_bwd<true, 2>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    else if (gb[0].dout) PROF_LAUNCH((k_gconv_bwd<false, 0>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    else PROF_LAUNCH((k_gconv_bwd<false, 1>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
     CAL_CHECK_LAUNCH("k_gconv_bwd");
     return 0;
 }
@@ -676,24 +709,6 @@ RoArgs make_ro(const Ctx& c) {
 }
 
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
-// live kernel timing for bench.py's roofline block: when enabled, HIP events are recorded on the
-// launch stream around the backbone's kernels: unfused forward GEMM ([N,H]x[H,H], class 0), aggregation
-// (k_espmm forward / transposed backward, class 1), per-graph fused convolution forward (class 2, flops), the
-// backward's dX + dW dual GEMM (class 3, flops) and the per-graph fused backward (class 4, flops).  Events are created here (never in a normal step).
-struct ProfRec { hipEvent_t e0, e1; int cls; double work; };
-static bool g_prof_on = false;
-static std::vector<ProfRec> g_prof;
-struct ProfScope {
-    hipStream_t st; bool on; ProfRec r;
-    ProfScope(hipStream_t s, int cls, double work) : st(s), on(g_prof_on) {
-        if (!on) return;
-        r.cls = cls; r.work = work;
-        hipEventCreate(&r.e0); hipEventCreate(&r.e1);
-        hipEventRecord(r.e0, st);
-    }
-    ~ProfScope() { if (on) { hipEventRecord(r.e1, st); g_prof.push_back(r); } }
-};
-
 // profiling aid: cal_engine_debug_stop(k) makes the step return after its k-th launch site (0 = run all)
 static int g_stop_after = 0;
 static int g_stage = 0;
@@ -823,8 +838,8 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
                 ga.heads = K; ga.D = D; ga.slope = e->gat_slope; ga.p = c.training ? e->gat_p : 0.f;
                 ga.seed = e->gat_seed[i - 1]; ga.ctr = (const uint64_t*)e->gat_ctr; ga.E = E;
                 {
-                    ProfScope ps(st, 7, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H);
-                    hipLaunchKernelGGL(k_ggat_fwd, dim3(B, H / GC_N), dim3(256), 0, st, gd, e->gptr, e->eptr, ga, H, H, e->status);
+                    ProfScope ps(st, 7, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
+                    PROF_LAUNCH(k_ggat_fwd, dim3(B, H / GC_N), dim3(256), 0, st, gd, e->gptr, e->eptr, ga, H, H, e->status);
                 }
                 CAL_CHECK_LAUNCH("k_ggat_fwd"); STAGE();
                 RC(flush_finals(c)); STAGE();
@@ -858,10 +873,10 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             if (i == 1) gb.coef_out = e->coef; else gb.coef_in = e->coef;
             if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H); }
             {
-                ProfScope ps(st, 2, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H);
-                if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<false, 64>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, gb, gb, 1,
+                ProfScope ps(st, 2, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
+                if (gc_small(c)) PROF_LAUNCH((k_gconv_fwd<false, 64>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, gb, gb, 1,
                                                     e->loop_w, H, H, e->status);
-                else hipLaunchKernelGGL((k_gconv_fwd<false, GC_T>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, gb, gb, 1,
+                else PROF_LAUNCH((k_gconv_fwd<false, GC_T>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, gb, gb, 1,
                                         e->loop_w, H, H, e->status);
             }
             CAL_CHECK_LAUNCH("k_gconv_fwd"); STAGE();
@@ -877,10 +892,10 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         const int rpb = spmm_rpb(H, wst, N);
         if (wst) { br.st_sum = spmm_acc(c, bn_stsum(c, i + 1), H, rpb); br.st_sq = spmm_acc(c, bn_stsq(c, i + 1), H, rpb); }
         {
-            ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0);
+            ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0, true);
             RC(with_g(H, [&](auto g) {
                 constexpr int G = decltype(g)::value;
-                hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, rpb), 1), dim3(256), 0, st, gd, br, br, 1, e->loop_w, N, H, rpb);
+                PROF_LAUNCH((k_espmm<4, G>), dim3(cdiv(N, rpb), 1), dim3(256), 0, st, gd, br, br, 1, e->loop_w, N, H, rpb);
                 return 0;
             }));
         }
@@ -1419,9 +1434,9 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             final_task(c, pp, B * nsl, 2 * H, H, bn_dsum(c, i));
             final_task(c, pp + H, B * nsl, 2 * H, H, bn_dprod(c, i));
             {
-                ProfScope ps(st, 8, 4.0 * N * H * H + 4.0 * (double)(c.E + N) * H);
-                if (i == L) hipLaunchKernelGGL((k_ggat_bwd<false>), dim3(B, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
-                else hipLaunchKernelGGL((k_ggat_bwd<true>), dim3(B, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+                ProfScope ps(st, 8, 4.0 * N * H * H + 4.0 * (double)(c.E + N) * H, true);
+                if (i == L) PROF_LAUNCH((k_ggat_bwd<false>), dim3(B, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+                else PROF_LAUNCH((k_ggat_bwd<true>), dim3(B, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
             }
             CAL_CHECK_LAUNCH("k_ggat_bwd"); STAGE();
             RC(flush_finals(c)); STAGE();
@@ -1478,7 +1493,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             }
             float* dst[1] = {e->G + e->o_conv_w[i - 1]};
             double* dsum[1] = {bn_dsum(c, i)}; double* dprod[1] = {bn_dprod(c, i)};
-            { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false)); } STAGE();
+            { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false)); } STAGE();
             RC(flush_finals(c)); STAGE();
             if (i == 1 && F <= FB_F && H <= FB_H) {
                 // the feature layer's backward per graph, fed from this layer's partial dX' (no k_bn_bwd, no dZ round trip)
@@ -1527,10 +1542,10 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             slab_off += need;
         } else {
             SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
-            ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0);
+            ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0, true);
             RC(with_g(H, [&](auto g) {
                 constexpr int G = decltype(g)::value;
-                hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, br, br, 0, e->loop_w, N, H, spmm_rpb(H, false));
+                PROF_LAUNCH((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, br, br, 0, e->loop_w, N, H, spmm_rpb(H, false));
                 return 0;
             }));
             CAL_CHECK_LAUNCH("k_espmm(T)");
