@@ -104,6 +104,29 @@ __device__ __forceinline__ void gb_mma(const float* a0, const float* a1, const f
     }
 }
 
+// One 32 x 32 tile from operands stored ROW-MAJOR IN k (A[row * LDA + k], B[col * LDB + k], strides = 4 mod 32 floats: 16 B
+// reads of 32 consecutive rows are bank-conflict free, 4 B reads would be 4-way conflicts): lane (li, lk) takes the four
+// consecutive k of every eight and feeds them to four MFMA steps -- any bijection of k onto (step, lk) is a valid reduction
+// order as long as A and B share it.  a_row / b_row point at this lane's row; kred % 32 == 0.
+__device__ __forceinline__ void gb_mma_rowk(const float* a_row, const float* b_row, int kred, int lk, gc_f32x16& acc) {
+    for (int k0 = 0; k0 < kred; k0 += 32) {
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + 8 * i + 4 * lk;
+            av[i] = *reinterpret_cast<const float4*>(a_row + k);
+            bv[i] = *reinterpret_cast<const float4*>(b_row + k);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[i].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[i].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[i].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[i].w, acc, 0, 0, 0);
+        }
+    }
+}
+
 template <bool RS, int MODE>      // MODE 0: dOut given; 1: UP (from the upper layer's partials); 2: POOL (+ gn / gself)
 __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBwdBranch b0, const GconvBwdBranch b1, float loop_w, int N, int H,

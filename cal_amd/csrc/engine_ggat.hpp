@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
         if (w < 4 && rt < R && ct < R) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-            gb_mma<1, 1, 1, 1>(Ds + (rt * 32 + li) * GB_LDD + h * D, nullptr, Zr + (ct * 32 + li) * GB_LDD + h * D, nullptr, D, lk, ident, acc);
+            gb_mma_rowk(Ds + (rt * 32 + li) * GB_LDD + h * D, Zr + (ct * 32 + li) * GB_LDD + h * D, D, lk, acc[0]);      // (16 B reads: the 4 B form was a 4-way bank conflict)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
