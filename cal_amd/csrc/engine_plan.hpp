@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     __shared__ int deg_in[GT], deg_out[GT], off_in[GT + 1], off_out[GT + 1], cur_in[GT], cur_out[GT];
     __shared__ short rl[GE], cl[GE];                     // local endpoints of the graph's edges (edge-id order)
     __shared__ short tn_d[GE], te_d[GE], tn_s[GE], te_s[GE];             // unordered row contents: neighbour, local edge id
+    BLK_CLK(0);
     const int b = blockIdx.x, t = threadIdx.x;
     const int g0 = (int)node_ptr[b], rows = (int)node_ptr[b + 1] - g0;
     const int64_t e0 = edge_ptr[b];
@@ -101,6 +102,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
         }
     }
     __syncthreads();
+    BLK_CLK(2);
     // exclusive scans of the two degree arrays: waves 0 / 1, SU consecutive elements per lane
     if (t < 128) {
         const int* deg = t < 64 ? deg_in : deg_out;
@@ -141,6 +143,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
         }
     }
     __syncthreads();
+    BLK_CLK(3);
     // ... then every slot moves to its rank by edge id inside its row
     for (int p = t; p < 2 * m; p += 256) {
         const bool d = p < m;
@@ -163,6 +166,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
         if (d) { nbr_dst[slot] = g0 + tn[q]; eid_dst[slot] = (int)(e0 + s); }
         else { nbr_src[slot] = g0 + tn[q]; eid_src[slot] = (int)(e0 + s); }
     }
+    BLK_CLK(1);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
