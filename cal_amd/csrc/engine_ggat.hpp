@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     __shared__ int ptr_s[T + 4];
     __shared__ signed char en[GGB_E], er[GGB_E];        // source / destination node of a CSR slot, local to the graph
     __shared__ int ee[GGB_E];
-    __shared__ float al_s[GGB_E + T], ak_s[GGB_E + T], dk_s[GGB_E + T], S_s[T];     // per slot (edges, then self loops), current head
+    __shared__ float al_s[GGB_E + T], ak_s[GGB_E + T], dk_s[GGB_E + T], dr_s[GGB_E + T];     // per slot (edges, then self loops), current head
     __shared__ float att_s[2 * GC_N];
     __shared__ float ad_s[2][T], as_s[2][T], mx_s[2][T], dn_s[2][T], dad_s[2][T], das_s[2][T];
     BLK_CLK(0);
@@ -546,31 +546,29 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
             al_s[s] = al; ak_s[s] = al * kp; dk_s[s] = dk;
         }
         __syncthreads();
-        // (b2) one lane per destination row: S_i = sum over its slots of alpha * dalpha (plain LDS sums, fixed order)
-        if (t < rows) {
-            float S = al_s[ne + t] * dk_s[ne + t];
-            const int s1 = ptr_s[t + 1];
-            for (int s = ptr_s[t]; s < s1; s += 8) {         // 16 independent LDS reads per round (a plain loop exposes every latency)
-                float x[8], y[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { const int sq = min(s + q, s1 - 1); x[q] = al_s[sq]; y[q] = dk_s[sq]; }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) S = fmaf(s + q < s1 ? x[q] : 0.f, y[q], S);
-            }
-            S_s[t] = S;
-        }
-        __syncthreads();
-        // (b3) one lane per slot: d(raw logit) (over dk_s), alpha~ into the block (atomic: duplicate edges share an entry)
+        // (b2 + b3) one lane per slot: S_i = sum over the slots of its destination row of alpha * dalpha, computed by the lane
+        //      itself in slot order (8 independent LDS reads per round; the row sums used to be a phase of their own -- one
+        //      lane per row, a barrier, the other 450 lanes idle), then d(raw logit) into dr_s and alpha~ into the block
+        //      (atomic: duplicate edges share an entry)
         for (int s = t; s < ne + rows; s += GB_NT) {
             const bool self = s >= ne;
             const int i = self ? s - ne : er[s], j = self ? s - ne : en[s];
             float dr = 0.f;
             if (j >= 0) {
+                float S = al_s[ne + i] * dk_s[ne + i];
+                const int s1 = ptr_s[i + 1];
+                for (int q0 = ptr_s[i]; q0 < s1; q0 += 8) {
+                    float x[8], y[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { const int sq = min(q0 + q, s1 - 1); x[q] = al_s[sq]; y[q] = dk_s[sq]; }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) S = fmaf(q0 + q < s1 ? x[q] : 0.f, y[q], S);
+                }
                 const float raw = ad_s[h][i] + as_s[h][j];
-                dr = al_s[s] * (dk_s[s] - S_s[i]) * (raw > 0.f ? 1.f : a.slope);
+                dr = al_s[s] * (dk_s[s] - S) * (raw > 0.f ? 1.f : a.slope);
                 atomicAdd(&Bk[i * GB_LDJ + j], ak_s[s]);
             }
-            dk_s[s] = dr;
+            dr_s[s] = dr;
         }
         __syncthreads();
         // (c) waves 0-3: dz tile (rows j, 32 columns of this head) = alpha~^T G_h; waves 4-5: d a_dst_i (row sums of dr);
@@ -580,12 +578,12 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
         } else if (w < 6) {
             const int i = t - 256;
             if (i < rows) {
-                float sd = dk_s[ne + i];
+                float sd = dr_s[ne + i];
                 const int s1 = ptr_s[i + 1];
                 for (int s = ptr_s[i]; s < s1; s += 8) {
                     float y[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) y[q] = dk_s[min(s + q, s1 - 1)];
+                    for (int q = 0; q < 8; ++q) y[q] = dr_s[min(s + q, s1 - 1)];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) sd += s + q < s1 ? y[q] : 0.f;
                 }
@@ -601,13 +599,13 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
                     int e8[8];
                     float y[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { const int sq = min(q0 + q, qe - 1); e8[q] = en[sq]; y[q] = dk_s[sq]; }
+                    for (int q = 0; q < 8; ++q) { const int sq = min(q0 + q, qe - 1); e8[q] = en[sq]; y[q] = dr_s[sq]; }
 #pragma unroll
                     for (int q = 0; q < 8; ++q) sj += (q0 + q < qe && e8[q] == j) ? y[q] : 0.f;
                 }
             }
             const float other = __shfl_xor(sj, 1, 64);
-            if (j < rows && half == 0) das_s[h][j] = dk_s[ne + j] + sj + other;
+            if (j < rows && half == 0) das_s[h][j] = dr_s[ne + j] + sj + other;
         }
         __syncthreads();
     }
