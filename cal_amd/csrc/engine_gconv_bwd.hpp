@@ -127,14 +127,39 @@ __device__ __forceinline__ void gb_mma_rowk(const float* a_row, const float* b_r
     }
 }
 
+// the same with two row tiles of A against one tile of B (acc0: rows of a0_row, acc1: rows of a1_row); TWO = false: only acc0
+template <bool TWO>
+__device__ __forceinline__ void gb_mma_rowk2(const float* a0_row, const float* a1_row, const float* b_row, int kred, int lk,
+                                             gc_f32x16& acc0, gc_f32x16& acc1) {
+    for (int k0 = 0; k0 < kred; k0 += 32) {
+        float4 av[4], aw[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + 8 * i + 4 * lk;
+            av[i] = *reinterpret_cast<const float4*>(a0_row + k);
+            if (TWO) aw[i] = *reinterpret_cast<const float4*>(a1_row + k);
+            bv[i] = *reinterpret_cast<const float4*>(b_row + k);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a[4] = {av[i].x, av[i].y, av[i].z, av[i].w}, b[4] = {bv[i].x, bv[i].y, bv[i].z, bv[i].w};
+            const float a2[4] = {TWO ? aw[i].x : 0.f, TWO ? aw[i].y : 0.f, TWO ? aw[i].z : 0.f, TWO ? aw[i].w : 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[j], acc0, 0, 0, 0);
+                if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], b[j], acc1, 0, 0, 0);
+            }
+        }
+    }
+}
+
 template <bool RS, int MODE>      // MODE 0: dOut given; 1: UP (from the upper layer's partials); 2: POOL (+ gn / gself)
 __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBwdBranch b0, const GconvBwdBranch b1, float loop_w, int N, int H,
                                                    int K, int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) float Ab[GB_T * GB_LDJ];       // adjacency block Ab[j][i]: dz_i += Ab[j][i] dOut_j
     __shared__ __attribute__((aligned(16))) float Ds[GB_T * GB_LDD];       // dOut slice [j][n]; later dz [i][n]
-    __shared__ __attribute__((aligned(16))) float Zt[GC_N * GB_LDJ];       // dz^T [n][i]
-    __shared__ __attribute__((aligned(16))) float Wt[GC_N * GB_LDW];       // W[:, ns]^T: Wt[n][k_in]
+    __shared__ __attribute__((aligned(16))) float Ws[GC_K * GB_LDD];       // W[:, ns] as loaded: Ws[k_in][n] (row-major in n, 16 B operand reads)
     __shared__ __attribute__((aligned(16))) float Xs[GB_T * GB_LDX];       // x_hat rows [i][k_in] (normalised, no affine)
     __shared__ float mean_s[GC_K], rstd_s[GC_K], gam_s[GC_K], bet_s[GC_K];
     __shared__ int ptr_s[GB_T + 4];
@@ -271,10 +296,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     }
     if (POOL && t < GC_N) gv_s[t] = gv;
     if (MODE == 0) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
-    ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) {
-        float* d = Wt + (4 * n4) * GB_LDW + k;
-        d[0] = v.x; d[GB_LDW] = v.y; d[2 * GB_LDW] = v.z; d[3 * GB_LDW] = v.w;
-    });
+    ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) { *reinterpret_cast<float4*>(Ws + k * GB_LDD + 4 * n4) = v; });
     __syncthreads();                                     // per-column BN constants, row scales, zeroed Ab, CSR
     ro_commit<GB_NT>(bx, rows, K4, [&](int i, int k4, float4 v) {
         const float s = RS ? rs_s[i] : 1.f;
@@ -398,7 +420,6 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                Zt[(ct * 32 + li) * GB_LDJ + row] = acc[0][r];
                 Ds[row * GB_LDD + ct * 32 + li] = acc[0][r];           // dz row-major over the dOut stage
             }
         }
@@ -408,8 +429,10 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     if (w < 4 && w * 32 < K) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-        if (R == 2) gb_mma<2, 1, GB_LDJ, GB_LDW>(Zt + li, Zt + 32 + li, Wt + w * 32 + li, nullptr, GC_N, lk, ident, acc);
-        else gb_mma<1, 1, GB_LDJ, GB_LDW>(Zt + li, nullptr, Wt + w * 32 + li, nullptr, GC_N, lk, ident, acc);
+        // both operands row-major in the reduction index n (dz rows in Ds, W rows in Ws, stride 68 = 4 mod 32): 16 B reads,
+        // four MFMA steps per read; W is staged as loaded (no transposing scatter) and dz needs no transposed copy
+        if (R == 2) gb_mma_rowk2<true>(Ds + li * GB_LDD, Ds + (32 + li) * GB_LDD, Ws + (w * 32 + li) * GB_LDD, GC_N, lk, acc[0], acc[1]);
+        else gb_mma_rowk2<false>(Ds + li * GB_LDD, nullptr, Ws + (w * 32 + li) * GB_LDD, GC_N, lk, acc[0], acc[1]);
         const int k = w * 32 + li;
         float* dxp = sl ? br.dxp1 : br.dxp0;
         // x_hat of all rows first, as ONE batch of unconditional LDS reads (rows rows .. rowsP are zero, as are their dz;
