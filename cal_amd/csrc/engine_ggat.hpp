@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     __shared__ __attribute__((aligned(16))) float Bk[T * GB_LDJ];          // alpha~ of the current head: Bk[i][j] (edge j -> i)
     __shared__ __attribute__((aligned(16))) float Ds[T * GB_LDD];          // dOut slice [j][n]; later dz [i][n]
     __shared__ __attribute__((aligned(16))) float Zt[GC_N * GB_LDJ];       // dalpha of the current head [i][j]; later dz^T [n][i]
-    __shared__ __attribute__((aligned(16))) float Wt[GC_N * GB_LDW];       // W[:, ns]^T: Wt[n][k_in]
+    __shared__ __attribute__((aligned(16))) float Ws[GC_K * GB_LDD];       // W[:, ns] as loaded: Ws[k_in][n] (16 B operand reads, see k_gconv_bwd)
     __shared__ __attribute__((aligned(16))) float Xs[T * GB_LDX];          // x_hat rows [i][k_in]
     __shared__ __attribute__((aligned(16))) float Zr[T * GB_LDD];          // z slice [j][n]
     __shared__ float mean_s[GC_K], rstd_s[GC_K], gam_s[GC_K], bet_s[GC_K];
@@ -451,10 +451,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     }
     if (!UP) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
     ro_commit<GB_NT>(bz, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Zr + j * GB_LDD + 4 * n4) = v; });
-    ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) {
-        float* d = Wt + (4 * n4) * GB_LDW + k;
-        d[0] = v.x; d[GB_LDW] = v.y; d[2 * GB_LDW] = v.z; d[3 * GB_LDW] = v.w;
-    });
+    ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) { *reinterpret_cast<float4*>(Ws + k * GB_LDD + 4 * n4) = v; });
     __syncthreads();                                     // BN constants
     ro_commit<GB_NT>(bx, rows, K4, [&](int i, int k4, float4 v) {
         const int k = 4 * k4;
@@ -618,7 +615,6 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
         for (int r = 0; r < 16; ++r) {
             const int j = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             const float v = dzacc[0][r] + dad_s[hh][j] * a_dst + das_s[hh][j] * a_src;
-            Zt[n * GB_LDJ + j] = v;
             Ds[j * GB_LDD + n] = v;
         }
     } else if (w >= 4 && t - 256 < 2 * GC_N) {
@@ -642,8 +638,8 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     if (w < 4 && w * 32 < K) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-        if (R == 2) gb_mma<2, 1, GB_LDJ, GB_LDW>(Zt + li, Zt + 32 + li, Wt + w * 32 + li, nullptr, GC_N, lk, ident, acc);
-        else gb_mma<1, 1, GB_LDJ, GB_LDW>(Zt + li, nullptr, Wt + w * 32 + li, nullptr, GC_N, lk, ident, acc);
+        if (R == 2) gb_mma_rowk2<true>(Ds + li * GB_LDD, Ds + (32 + li) * GB_LDD, Ws + (w * 32 + li) * GB_LDD, GC_N, lk, acc[0], acc[1]);
+        else gb_mma_rowk2<false>(Ds + li * GB_LDD, nullptr, Ws + (w * 32 + li) * GB_LDD, GC_N, lk, acc[0], acc[1]);
         const int k = w * 32 + li;
         float* dxp = sl ? a.dxp1 : a.dxp0;
         // x_hat of all rows as ONE batch of unconditional LDS reads, masked afterwards, and a lane's 32 terms summed in
