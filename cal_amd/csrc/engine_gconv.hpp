@@ -98,17 +98,68 @@ __device__ __forceinline__ void gconv_mma(const float* As, const float* Bs, int 
     }
 }
 
+// z = x' W with the A operand ROW-MAJOR in k (x' rows as loaded: Xr[row * GC_LDX + k], stride 132 = 4 mod 32: conflict-free
+// 16 B reads) and B k-major (the W slice as loaded).  Lane (li, lk) takes the four consecutive k of every eight from its
+// row with one ds_read_b128 and the matching four B values with 4 B reads -- any bijection of k onto (MFMA step, lk) is a
+// valid reduction order when both operands share it.  Against the k-major x stage: no transposing scalar stores while
+// staging (8 float4 stores per lane instead of 32 scalar ones) and a third fewer LDS reads in the product.
+constexpr int GC_LDX = GC_K + 4;
+template <bool TWO, int LDB>
+__device__ __forceinline__ void gconv_mma_arow(const float* Xr, const float* Bs, int kred, int r0, int ct, int li, int lk,
+                                               gc_f32x16& acc0, gc_f32x16& acc1) {
+    const float* a0p = Xr + (r0 * 32 + li) * GC_LDX + 4 * lk;
+    const float* a1p = Xr + ((r0 + 2) * 32 + li) * GC_LDX + 4 * lk;
+    const float* bp = Bs + ct * 32 + li + 4 * lk * LDB;
+    float4 a0[2][4], a1[2][4];
+    float bv[2][16];
+    auto read_ops = [&](int kb, int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a0[s][i] = *reinterpret_cast<const float4*>(a0p + kb * 32 + 8 * i);
+            if (TWO) a1[s][i] = *reinterpret_cast<const float4*>(a1p + kb * 32 + 8 * i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[s][4 * i + j] = bp[(kb * 32 + 8 * i + j) * LDB];
+        }
+    };
+    auto mul = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x[4] = {a0[s][i].x, a0[s][i].y, a0[s][i].z, a0[s][i].w};
+            const float y[4] = {TWO ? a1[s][i].x : 0.f, TWO ? a1[s][i].y : 0.f, TWO ? a1[s][i].z : 0.f, TWO ? a1[s][i].w : 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], bv[s][4 * i + j], acc0, 0, 0, 0);
+                if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y[j], bv[s][4 * i + j], acc1, 0, 0, 0);
+            }
+        }
+    };
+    const int nkb = kred / 32;
+    read_ops(0, 0);
+    for (int kb = 0; kb < nkb; kb += 2) {
+        if (kb + 1 < nkb) read_ops(kb + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mul(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 1 < nkb) {
+            if (kb + 2 < nkb) read_ops(kb + 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 template <bool RS, int T>
 __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBranch b0, const GconvBranch b1, int relu, float loop_w, int H,
                                                    int K, int* __restrict__ status) {
     constexpr int LDA = T + 1, ECAP = gc_edge_cap(T);
-    __shared__ __attribute__((aligned(16))) float As[GC_K * LDA];          // x stage [k][row]; later the adjacency block [j][i]
+    __shared__ __attribute__((aligned(16))) float As[(GC_K * LDA > T * GC_LDX) ? GC_K * LDA : T * GC_LDX];   // x' rows [row][k] (stride GC_LDX); later the adjacency block [j][i] (stride LDA)
     __shared__ __attribute__((aligned(16))) float Bs[GC_K * GC_LDB];       // W slice [k][col]; later the z tile [row][col]
     __shared__ float sc_s[GC_K], sh_s[GC_K];
     __shared__ int ptr_s[T + 4];
     __shared__ float dis_s[T];
-    __shared__ int en[ECAP];
+    __shared__ short en[ECAP];                          // (local node index < T: 2 bytes keep the T = 64 instantiation at two workgroups per CU)
     __shared__ float ec[ECAP];
     __shared__ signed char er[ECAP];
     __shared__ double red[4][2][32];
@@ -227,7 +278,7 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
         if (s < ne) {
             const int loc = nv[u] - g0;
             const bool inb = loc >= 0 && loc < rows;        // an edge that leaves its graph is not a mini-batch: flag it
-            en[s] = inb ? loc : 0; ec[s] = inb ? cv[u] : 0.f;
+            en[s] = (short)(inb ? loc : 0); ec[s] = inb ? cv[u] : 0.f;
             if (br.coef_out && blockIdx.y == 0) { br.coef_out[e0 + s] = cv[u]; if (br.w_out) br.w_out[e0 + s] = wv[u]; }
             if (!inb) atomicOr(status, 16);
         }
@@ -254,11 +305,9 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
                     const float s = rr == 0 ? rsv[0] : (rr == 1 ? rsv[1] : (rr == 2 ? rsv[2] : rsv[3]));
                     x0 *= s; x1 *= s; x2 *= s; x3 *= s;
                 }
-                float* d = As + k * LDA + r;
-                d[0] = fmaf(x0, sc_s[k], sh_s[k]);
-                d[LDA] = fmaf(x1, sc_s[k + 1], sh_s[k + 1]);
-                d[2 * LDA] = fmaf(x2, sc_s[k + 2], sh_s[k + 2]);
-                d[3 * LDA] = fmaf(x3, sc_s[k + 3], sh_s[k + 3]);
+                *reinterpret_cast<float4*>(As + r * GC_LDX + k) =
+                    make_float4(fmaf(x0, sc_s[k], sh_s[k]), fmaf(x1, sc_s[k + 1], sh_s[k + 1]), fmaf(x2, sc_s[k + 2], sh_s[k + 2]),
+                                fmaf(x3, sc_s[k + 3], sh_s[k + 3]));
             }
             if (++rr == R) { rr = 0; ++kc; }
         }
@@ -271,8 +320,8 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     if (r0 < R) {
-        if (r0 + 2 < R) gconv_mma<true, LDA, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
-        else gconv_mma<false, LDA, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
+        if (r0 + 2 < R) gconv_mma_arow<true, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
+        else gconv_mma_arow<false, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
     }
     RO_CLK(36);
     __syncthreads();                                     // every wave is done reading both stages
