@@ -46,7 +46,7 @@ __device__ __forceinline__ float gg_lrelu(float v, float slope) { return v > 0.f
 __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                   const GgatArgs a, int H, int K, int* __restrict__ status) {
     constexpr int T = GG_T, LDA = T + 1;
-    __shared__ __attribute__((aligned(16))) float As[GC_K * LDA];          // x stage [k][row]; later two attention blocks [j][i]
+    __shared__ __attribute__((aligned(16))) float As[(GC_K * LDA > T * GC_LDX) ? GC_K * LDA : T * GC_LDX];   // x' rows [row][k] (stride GC_LDX, as k_gconv_fwd); later two attention blocks [j][i]
     __shared__ __attribute__((aligned(16))) float Bs[GC_K * GC_LDB];       // W slice [k][col]; later the z tile [row][col]
     __shared__ float sc_s[GC_K], sh_s[GC_K];
     __shared__ int ptr_s[T + 4];
@@ -154,11 +154,9 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
         for (int u = 0; u < UA; ++u) {
             if (kc < nkc) {
                 const int r = (rr << 5) + (t >> 3), k = (kc << 5) + ((t & 7) << 2);
-                float* d = As + k * LDA + r;
-                d[0] = fmaf(va[u].x, sc_s[k], sh_s[k]);
-                d[LDA] = fmaf(va[u].y, sc_s[k + 1], sh_s[k + 1]);
-                d[2 * LDA] = fmaf(va[u].z, sc_s[k + 2], sh_s[k + 2]);
-                d[3 * LDA] = fmaf(va[u].w, sc_s[k + 3], sh_s[k + 3]);
+                *reinterpret_cast<float4*>(As + r * GC_LDX + k) =
+                    make_float4(fmaf(va[u].x, sc_s[k], sh_s[k]), fmaf(va[u].y, sc_s[k + 1], sh_s[k + 1]),
+                                fmaf(va[u].z, sc_s[k + 2], sh_s[k + 2]), fmaf(va[u].w, sc_s[k + 3], sh_s[k + 3]));
             }
             if (++rr == R) { rr = 0; ++kc; }
         }
@@ -168,7 +166,7 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
     gc_f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    if (r0 < R) gconv_mma<false, LDA, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
+    if (r0 < R) gconv_mma_arow<false, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
     __syncthreads();                                     // every wave is done reading both stages
     float* Zs = Bs;
     float* At = As;                                      // At[(h * T + j) * LDA + i] = alpha of edge j -> i, head h0 + h
