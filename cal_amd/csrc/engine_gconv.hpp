@@ -149,6 +149,35 @@ __device__ __forceinline__ void gconv_mma_arow(const float* Xr, const float* Bs,
     }
 }
 
+// out = A z with BOTH operands row-major in the reduction index j (the adjacency block as At[i * LD + j], the z tile
+// transposed as Zt[col * LD + j], LD = 4 mod 32): 16 B reads, four MFMA steps per read (same k mapping as above)
+template <bool TWO, int LD>
+__device__ __forceinline__ void gconv_mma_rowk(const float* At, const float* Zt, int kred, int r0, int ct, int li, int lk,
+                                               gc_f32x16& acc0, gc_f32x16& acc1) {
+    const float* a0p = At + (r0 * 32 + li) * LD + 4 * lk;
+    const float* a1p = At + ((r0 + 2) * 32 + li) * LD + 4 * lk;
+    const float* bp = Zt + (ct * 32 + li) * LD + 4 * lk;
+    for (int k0 = 0; k0 < kred; k0 += 32) {
+        float4 a0[4], a1[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a0[i] = *reinterpret_cast<const float4*>(a0p + k0 + 8 * i);
+            if (TWO) a1[i] = *reinterpret_cast<const float4*>(a1p + k0 + 8 * i);
+            bv[i] = *reinterpret_cast<const float4*>(bp + k0 + 8 * i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x[4] = {a0[i].x, a0[i].y, a0[i].z, a0[i].w}, b[4] = {bv[i].x, bv[i].y, bv[i].z, bv[i].w};
+            const float y[4] = {TWO ? a1[i].x : 0.f, TWO ? a1[i].y : 0.f, TWO ? a1[i].z : 0.f, TWO ? a1[i].w : 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x[j], b[j], acc0, 0, 0, 0);
+                if (TWO) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y[j], b[j], acc1, 0, 0, 0);
+            }
+        }
+    }
+}
+
 template <bool RS, int T>
 __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBranch b0, const GconvBranch b1, int relu, float loop_w, int H,
@@ -326,26 +355,40 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     RO_CLK(36);
     __syncthreads();                                     // every wave is done reading both stages
     // ---- z tile -> LDS (over the W stage); zero the adjacency block (over the x stage) ------------------------
-    float* Zs = Bs;
-    float* At = As;                                      // At[j * LDA + i] = weight of edge j -> i, times dis_i
+    constexpr int LDT = T + 4;                           // row stride of the two j-major tiles below (4 mod 32)
+    float* Zt = Bs;                                      // Zt[col * LDT + j] = z[j][col]   (over the W stage)
+    float* At = As;                                      // At[i * LDT + j] = weight of edge j -> i, times dis_i   (over the x stage)
     if (r0 < R) {
+        // an accumulator holds rows 8 g + 4 lk .. + 3 of its tile in elements 4 g .. 4 g + 3: four consecutive j of one column
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            Zs[row * GC_LDZ + ct * 32 + li] = acc0[r];
-            if (br.z && row < rows) br.z[(size_t)(g0 + row) * H + n0 + ct * 32 + li] = acc0[r];
+        for (int gq = 0; gq < 4; ++gq) {
+            const int row = r0 * 32 + 8 * gq + 4 * lk;
+            *reinterpret_cast<float4*>(Zt + (ct * 32 + li) * LDT + row) = make_float4(acc0[4 * gq], acc0[4 * gq + 1], acc0[4 * gq + 2], acc0[4 * gq + 3]);
+        }
+        if (br.z) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < rows) br.z[(size_t)(g0 + row) * H + n0 + ct * 32 + li] = acc0[r];
+            }
         }
         if (r0 + 2 < R) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r0 + 2) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                Zs[row * GC_LDZ + ct * 32 + li] = acc1[r];
-                if (br.z && row < rows) br.z[(size_t)(g0 + row) * H + n0 + ct * 32 + li] = acc1[r];
+            for (int gq = 0; gq < 4; ++gq) {
+                const int row = (r0 + 2) * 32 + 8 * gq + 4 * lk;
+                *reinterpret_cast<float4*>(Zt + (ct * 32 + li) * LDT + row) = make_float4(acc1[4 * gq], acc1[4 * gq + 1], acc1[4 * gq + 2], acc1[4 * gq + 3]);
+            }
+            if (br.z) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r0 + 2) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (row < rows) br.z[(size_t)(g0 + row) * H + n0 + ct * 32 + li] = acc1[r];
+                }
             }
         }
     }
     {
-        const int nz4 = (rowsP * LDA + 3) >> 2;       // rows j < rowsP of the block (contiguous), as float4s
+        const int nz4 = (rowsP * LDT) >> 2;           // rows i < rowsP of the block (contiguous), as float4s
         float4* z4 = reinterpret_cast<float4*>(At);
         for (int idx = t; idx < nz4; idx += 256) z4[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -355,17 +398,17 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     // read-modify-write the block) while the other lanes idled -- the slowest row was the phase.
     for (int s = t; s < ne; s += 256) {
         const int i = er[s];
-        atomicAdd(&At[en[s] * LDA + i], dis_s[i] * ec[s]);
+        atomicAdd(&At[i * LDT + en[s]], dis_s[i] * ec[s]);
     }
-    if (t < rows) atomicAdd(&At[t * LDA + t], dis_s[t] * dis_s[t] * loop_w);
+    if (t < rows) atomicAdd(&At[t * LDT + t], dis_s[t] * dis_s[t] * loop_w);
     __syncthreads();
     RO_CLK(37);
     // ---- out tile = A z on the matrix cores (reduction over the graph's rowsP nodes) ---------------------------
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     if (r0 < R) {
-        if (r0 + 2 < R) gconv_mma<true, LDA, GC_LDZ>(At, Zs, rowsP, r0, ct, li, lk, acc0, acc1);
-        else gconv_mma<false, LDA, GC_LDZ>(At, Zs, rowsP, r0, ct, li, lk, acc0, acc1);
+        if (r0 + 2 < R) gconv_mma_rowk<true, LDT>(At, Zt, rowsP, r0, ct, li, lk, acc0, acc1);
+        else gconv_mma_rowk<false, LDT>(At, Zt, rowsP, r0, ct, li, lk, acc0, acc1);
     }
     RO_CLK(38);
     // ---- epilogue: bias, ReLU, store, column sums of this graph ---------------------------------------------------
