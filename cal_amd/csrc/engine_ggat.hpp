@@ -46,7 +46,8 @@ __device__ __forceinline__ float gg_lrelu(float v, float slope) { return v > 0.f
 __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                   const GgatArgs a, int H, int K, int* __restrict__ status) {
     constexpr int T = GG_T, LDA = T + 1;
-    __shared__ __attribute__((aligned(16))) float As[(GC_K * LDA > T * GC_LDX) ? GC_K * LDA : T * GC_LDX];   // x' rows [row][k] (stride GC_LDX, as k_gconv_fwd); later two attention blocks [j][i]
+    constexpr int LDT = T + 4;                           // row stride of the j-major tiles of the second product (4 mod 32)
+    __shared__ __attribute__((aligned(16))) float As[2 * T * LDT];          // x' rows [row][k] (stride GC_LDX, as k_gconv_fwd); later two attention blocks [h][i][j]
     __shared__ __attribute__((aligned(16))) float Bs[GC_K * GC_LDB];       // W slice [k][col]; later the z tile [row][col]
     __shared__ float sc_s[GC_K], sh_s[GC_K];
     __shared__ int ptr_s[T + 4];
@@ -168,19 +169,23 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     if (r0 < R) gconv_mma_arow<false, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
     __syncthreads();                                     // every wave is done reading both stages
-    float* Zs = Bs;
-    float* At = As;                                      // At[(h * T + j) * LDA + i] = alpha of edge j -> i, head h0 + h
+    float* Zt = Bs;                                      // Zt[col * LDT + j] = z[j][col]: the z tile transposed (as k_gconv_fwd)
+    float* At = As;                                      // At[(h * T + i) * LDT + j] = alpha of edge j -> i, head h0 + h
     if (r0 < R) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int row = r0 * 32 + 8 * gq + 4 * lk;
+            *reinterpret_cast<float4*>(Zt + (ct * 32 + li) * LDT + row) = make_float4(acc0[4 * gq], acc0[4 * gq + 1], acc0[4 * gq + 2], acc0[4 * gq + 3]);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            Zs[row * GC_LDZ + ct * 32 + li] = acc0[r];
             if (row < rows) a.z[(size_t)(g0 + row) * H + n0 + ct * 32 + li] = acc0[r];
         }
     }
     {
         float4* z4 = reinterpret_cast<float4*>(At);
-        for (int idx = t; idx < (GC_K * LDA) / 4; idx += 256) z4[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int idx = t; idx < (2 * T * LDT) / 4; idx += 256) z4[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     // ---- scores: one lane per (node, head of the slice) ----------------------------------------------------------
@@ -188,12 +193,12 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
     const bool pair = ph < hs && pi < rows;
     float my_ad = 0.f, my_as = 0.f;
     if (pair) {
-        const float* zr = Zs + pi * GC_LDZ + ph * D;
+        const float* zr = Zt + (ph * D) * LDT + pi;          // column ph * D + d of node pi: lanes = consecutive nodes
         const float* av = att_s + ph * 2 * D;
         for (int d0 = 0; d0 < D; d0 += 8) {                  // 24 independent LDS reads per round (D is 32 or 64)
             float zz[8], a1[8], a2[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { zz[u] = zr[d0 + u]; a1[u] = av[d0 + u]; a2[u] = av[D + d0 + u]; }
+            for (int u = 0; u < 8; ++u) { zz[u] = zr[(d0 + u) * LDT]; a1[u] = av[d0 + u]; a2[u] = av[D + d0 + u]; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) { my_ad = fmaf(zz[u], a1[u], my_ad); my_as = fmaf(zz[u], a2[u], my_as); }
         }
@@ -237,7 +242,7 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
         if (j >= 0) {
             pe = expf(le_s[h][s] - m_s[h][i]);
             const float kp = keep_scale(seed, self ? a.E + g0 + i : (int64_t)ee[s], h0 + h, a.heads, a.p, inv_keep);
-            atomicAdd(&At[(size_t)h * T * LDA + j * LDA + i], pe * kp);
+            atomicAdd(&At[((size_t)h * T + i) * LDT + j], pe * kp);
         }
         le_s[h][s] = pe;
     }
@@ -261,7 +266,7 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
     // ---- out tile = alpha_h z on the matrix cores: the 32-column tile ct lies in head (ct * 32) / D of the slice ----
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc0[i] = 0.f;
-    if (r0 < R) gconv_mma<false, LDA, GC_LDZ>(At + (size_t)((ct * 32) / D) * T * LDA, Zs, rowsP, r0, ct, li, lk, acc0, acc1);
+    if (r0 < R) gconv_mma_rowk<false, LDT>(At + (size_t)((ct * 32) / D) * T * LDT, Zt, rowsP, r0, ct, li, lk, acc0, acc1);
     // ---- epilogue: bias, ReLU, store, column sums of this graph ---------------------------------------------------
     // (a lane's 16 terms of the column sums in fp32, masked and unguarded, as in k_gconv_fwd; the denominators in one batch)
     float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
