@@ -12,7 +12,7 @@
 // dz never goes to HBM and neither product re-reads it.
 //
 //   grid (B graphs, H / 64 slices, branches), 512 threads; graphs of at most 64 nodes / 1024 stored edges
-//   (cal_engine_set_graph_bounds), K = H in {64, 128}.  LDS ~129 KB: one workgroup per CU, so it brings its
+//   (cal_engine_set_graph_bounds), K = H in {64, 128}.  LDS ~115-135 KB: one workgroup per CU, so it brings its
 //   own latency hiding: 8 waves -- waves 0-3 run the dX' product and its epilogue while waves 4-7 run the
 //   dW product (both only need dz), and twice as many loads are in flight while staging.
 #pragma once
