@@ -48,6 +48,55 @@ __device__ __forceinline__ void ro_step_barrier(int* ctr, int n) {
     ro_step_arrive(ctr);
     ro_step_wait(ctr, n);
 }
+// 16 x 16 output tiles (wave w owns tiles w, w + 4, ..) of a product whose operands are both ROW-MAJOR in k in LDS:
+// A[row][k] = X[min(row, nrow - 1) * ld + k] (optionally x * sc[k] + sh[k]), B[k][col] = Wr[col * ld + k].  Lane
+// (lr = l & 15, lk = l >> 4) takes the four consecutive k  k0 + 4 lk .. + 3  of every sixteen with one 16 B read per
+// operand and feeds element j to MFMA step j -- the four lane groups of a step then hold four distinct k, every k once per
+// sixteen: a valid reduction order.  One read per four MFMAs and operand instead of one (three with the BatchNorm) per MFMA.
+template <int NT, bool BN>
+__device__ __forceinline__ void ro_mfma_rowk_nt(int kred, const float* X, int ld, int nrow, const float* Wr, const float* sc,
+                                                const float* sh, ro_f32x4 (&acc)[4]) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6, lr = l & 15, lk = l >> 4;
+    const float* ar[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ar[t] = X + min((w + 4 * t) * 16 + lr, nrow - 1) * ld + 4 * lk;
+    const float* br = Wr + lr * ld + 4 * lk;
+    // operands of the next sixteen k are requested before the current ones are multiplied (one LDS latency per product)
+    float4 a4[NT], b4, s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int k0, float4 (&a)[NT], float4& b, float4& s, float4& h) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = *reinterpret_cast<const float4*>(ar[t] + k0);
+        b = *reinterpret_cast<const float4*>(br + k0);
+        if (BN) { s = *reinterpret_cast<const float4*>(sc + k0 + 4 * lk); h = *reinterpret_cast<const float4*>(sh + k0 + 4 * lk); }
+    };
+    fetch(0, a4, b4, s4, h4);
+    for (int k0 = 0; k0 < kred; k0 += 16) {
+        float4 an[NT], bn, sn = s4, hn = h4;
+        fetch(min(k0 + 16, kred - 16), an, bn, sn, hn);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, hh[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float aa[4] = {a4[t].x, a4[t].y, a4[t].z, a4[t].w};
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(BN ? fmaf(aa[j], ss[j], hh[j]) : aa[j], bb[j], acc[t], 0, 0, 0);
+            }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a4[t] = an[t];
+        b4 = bn; s4 = sn; h4 = hn;
+    }
+}
+template <bool BN>
+__device__ __forceinline__ void ro_mfma_rowk(int ntiles, int kred, const float* X, int ld, int nrow, const float* Wr, const float* sc,
+                                             const float* sh, ro_f32x4 (&acc)[4]) {
+    switch ((ntiles + 3) / 4) {
+        case 1: ro_mfma_rowk_nt<1, BN>(kred, X, ld, nrow, Wr, sc, sh, acc); break;
+        case 2: ro_mfma_rowk_nt<2, BN>(kred, X, ld, nrow, Wr, sc, sh, acc); break;
+        case 3: ro_mfma_rowk_nt<3, BN>(kred, X, ld, nrow, Wr, sc, sh, acc); break;
+        default: ro_mfma_rowk_nt<4, BN>(kred, X, ld, nrow, Wr, sc, sh, acc); break;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     const RoArgs& a = sa.a;
     __shared__ __attribute__((aligned(16))) float Xs[RS_B * RS_LD];         // raw input rows; phase C: dy1 rows
@@ -58,7 +107,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     __shared__ __attribute__((aligned(16))) float y1c[RS_B * RO_CW];        // relu(fc1) chunk [B][16] (raw)
     __shared__ __attribute__((aligned(16))) float zs[2048];                 // logits -> dz, [B][C]
     __shared__ __attribute__((aligned(16))) float W2c[64 * RO_CW];          // W2[c][j0 + j]
-    __shared__ float sc_s[RS_K], sh_s[RS_K], mean1_s[RS_K], rstd1_s[RS_K];
+    __shared__ __attribute__((aligned(16))) float sc_s[RS_K], sh_s[RS_K], mean1_s[RS_K], rstd1_s[RS_K];     // (sc / sh are read 16 B at a time)
     __shared__ int perm_s[256];
     __shared__ double red[2][256];
     __shared__ float c2[6][RO_CW];             // BN2 of the chunk: mean, rstd, gamma, beta; m1, m2 of a BatchNorm backward
@@ -170,8 +219,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     }
     // y1[:, chunk] = relu(BN1(x) W1[chunk]^T + b1) on MFMA
     ro_f32x4 acc[4] = {};
-    ro_mfma_tiles(ntiles, K, [&](int row, int k) { return fmaf(Xs[min(row, B - 1) * ld + k], sc_s[k], sh_s[k]); },
-                  [&](int k, int col) { return Ws[col * ld + k]; }, acc);
+    ro_mfma_rowk<true>(ntiles, K, Xs, ld, B, Ws, sc_s, sh_s, acc);
     float s1 = 0.f, s2 = 0.f;                  // (16 terms per lane in fp32, see add_stats)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -409,8 +457,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     const int i = j, i0 = j0;
     const float mean1 = mean1_s[i0 + i], rstd1 = rstd1_s[i0 + i], gs1 = sc_s[i0 + i], sh1 = sh_s[i0 + i];
     ro_f32x4 dacc[4] = {};
-    ro_mfma_tiles(ntiles, K, [&](int row, int k) { return Ds[min(row, B - 1) * ld + k]; },
-                  [&](int k, int col) { return W1t[col * ld + k]; }, dacc);
+    ro_mfma_rowk<false>(ntiles, K, Ds, ld, B, W1t, nullptr, nullptr, dacc);
     float u1 = 0.f, u2 = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
