@@ -669,9 +669,9 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
         final_task(c, p + H, B * nsl, 2 * H, H, dprod[k]);
     }
     const dim3 grid(B, nsl, nb);
-    if (rs) PROF_LAUNCH((k_gconv_bwd<true, 2>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
-    else if (gb[0].dout) PROF_LAUNCH((k_gconv_bwd<false, 0>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
-    else PROF_LAUNCH((k_gconv_bwd<false, 1>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, gb[0], gb[nb - 1], e->loop_w, c.N, H, H, e->status);
+    if (rs) PROF_LAUNCH((k_gconv_bwd<true, 2>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
+    else if (gb[0].dout) PROF_LAUNCH((k_gconv_bwd<false, 0>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
+    else PROF_LAUNCH((k_gconv_bwd<false, 1>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
     CAL_CHECK_LAUNCH("k_gconv_bwd");
     return 0;
 }
@@ -796,7 +796,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
                 SpmmBranch br{hin, agg, nullptr, nullptr, e->ones, Acc(), Acc()};
                 RC(with_g(H, [&](auto g) {
                     constexpr int G = decltype(g)::value;
-                    hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gd, br, br, 0, 1.0f, N, H, spmm_rpb(H, false));
+                    hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gd, SpmmBranch2{{br, br}}, 0, 1.0f, N, H, spmm_rpb(H, false));
                     return 0;
                 }));
                 CAL_CHECK_LAUNCH("k_espmm(gin)"); STAGE();
@@ -874,9 +874,9 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H); }
             {
                 ProfScope ps(st, 2, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
-                if (gc_small(c)) PROF_LAUNCH((k_gconv_fwd<false, 64>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, gb, gb, 1,
+                if (gc_small(c)) PROF_LAUNCH((k_gconv_fwd<false, 64>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1,
                                                     e->loop_w, H, H, e->status);
-                else PROF_LAUNCH((k_gconv_fwd<false, GC_T>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, gb, gb, 1,
+                else PROF_LAUNCH((k_gconv_fwd<false, GC_T>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1,
                                         e->loop_w, H, H, e->status);
             }
             CAL_CHECK_LAUNCH("k_gconv_fwd"); STAGE();
@@ -895,7 +895,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0, true);
             RC(with_g(H, [&](auto g) {
                 constexpr int G = decltype(g)::value;
-                PROF_LAUNCH((k_espmm<4, G>), dim3(cdiv(N, rpb), 1), dim3(256), 0, st, gd, br, br, 1, e->loop_w, N, H, rpb);
+                PROF_LAUNCH((k_espmm<4, G>), dim3(cdiv(N, rpb), 1), dim3(256), 0, st, gd, SpmmBranch2{{br, br}}, 1, e->loop_w, N, H, rpb);
                 return 0;
             }));
         }
@@ -949,9 +949,9 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             gb[k].coef_out = e->coef + (size_t)(1 + k) * E;
             gb[k].w_out = e->wslot + (size_t)k * E;
         }
-        if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<true, 64>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, gb[0], gb[1], 1,
+        if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<true, 64>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1,
                                             e->loop_w, H, H, e->status);
-        else hipLaunchKernelGGL((k_gconv_fwd<true, GC_T>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, gb[0], gb[1], 1,
+        else hipLaunchKernelGGL((k_gconv_fwd<true, GC_T>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1,
                                 e->loop_w, H, H, e->status);
         CAL_CHECK_LAUNCH("k_gconv_fwd(co)"); STAGE();
     }
@@ -971,7 +971,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         SpmmBranch b1{e->zco + NH, e->hco + NH, e->P + e->o_ob, e->att + E, e->dis_co + N, Acc(), Acc()};
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 2), dim3(256), 0, st, gd, b0, b1, 1, e->loop_w, N, H, spmm_rpb(H, false));
+            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 2), dim3(256), 0, st, gd, SpmmBranch2{{b0, b1}}, 1, e->loop_w, N, H, spmm_rpb(H, false));
             return 0;
         }));
         CAL_CHECK_LAUNCH("k_espmm(co)"); STAGE();
@@ -1219,7 +1219,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         SpmmBranch b1{e->dZco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, Acc(), Acc()};
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 2), dim3(256), 0, st, gs, b0, b1, 0, e->loop_w, N, H, spmm_rpb(H, false));
+            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 2), dim3(256), 0, st, gs, SpmmBranch2{{b0, b1}}, 0, e->loop_w, N, H, spmm_rpb(H, false));
             return 0;
         }));
         CAL_CHECK_LAUNCH("k_espmm(co,T)"); STAGE();
@@ -1377,7 +1377,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                 SpmmBranch br{e->dXh, e->z, nullptr, nullptr, e->ones, Acc(), Acc()};                // d h_{i-1}
                 RC(with_g(H, [&](auto g) {
                     constexpr int G = decltype(g)::value;
-                    hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, br, br, 0, 1.0f, N, H, spmm_rpb(H, false));
+                    hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, SpmmBranch2{{br, br}}, 0, 1.0f, N, H, spmm_rpb(H, false));
                     return 0;
                 }));
                 CAL_CHECK_LAUNCH("k_espmm(gin,T)"); STAGE();
@@ -1545,7 +1545,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0, true);
             RC(with_g(H, [&](auto g) {
                 constexpr int G = decltype(g)::value;
-                PROF_LAUNCH((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, br, br, 0, e->loop_w, N, H, spmm_rpb(H, false));
+                PROF_LAUNCH((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, SpmmBranch2{{br, br}}, 0, e->loop_w, N, H, spmm_rpb(H, false));
                 return 0;
             }));
             CAL_CHECK_LAUNCH("k_espmm(T)");

@@ -54,6 +54,8 @@ struct GconvBranch {
     float* w_out;            // with coef_out: the raw edge weights w_e in CSR-slot order (read by the per-graph attention backward), or null
 };
 
+struct GconvBranch2 { GconvBranch b[2]; };
+
 typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
 
 // kred/32 blocks of 16 MFMA steps over k-major LDS operands A[k][row] (stride LDA) and B[k][col]
@@ -180,7 +182,7 @@ __device__ __forceinline__ void gconv_mma_rowk(const float* At, const float* Zt,
 
 template <bool RS, int T>
 __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
-                                                   const GconvBranch b0, const GconvBranch b1, int relu, float loop_w, int H,
+                                                   const GconvBranch2 bb, int relu, float loop_w, int H,
                                                    int K, int* __restrict__ status) {
     constexpr int LDA = T + 1, ECAP = gc_edge_cap(T);
     __shared__ __attribute__((aligned(16))) float As[(GC_K * LDA > T * GC_LDX) ? GC_K * LDA : T * GC_LDX];   // x' rows [row][k] (stride GC_LDX); later the adjacency block [j][i] (stride LDA)
@@ -194,8 +196,15 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     __shared__ double red[4][2][32];
     __shared__ float pool_s[4][32];
     BLK_CLK(0);
-    const GconvBranch& br = blockIdx.z ? b1 : b0;
+    const GconvBranch& br = bb.b[blockIdx.z];           // indexed in the kernel-argument segment: one set of scalar loads (b0 / b1 as two parameters were loaded both and selected field by field)
     const int b = blockIdx.x, n0 = blockIdx.y * GC_N, t = threadIdx.x;
+    // the W slice does not depend on the graph: requested before the graph's extents (a scalar round trip) are known
+    float4 vb[8];                                        // W[k][n0 + 4 j4 ..]: 16 lanes per k row
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int idx = t + u * 256, k = min(idx >> 4, K - 1), j4 = idx & 15;
+        vb[u] = *reinterpret_cast<const float4*>(br.W + (size_t)k * H + n0 + 4 * j4);
+    }
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
     const bool want = br.st_sum.on();
     if (rows <= 0) {                                     // empty graph: its partial rows still have to exist
@@ -228,12 +237,6 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
             va[u] = *reinterpret_cast<const float4*>(br.x + (size_t)(g0 + r) * K + k);
             if (++rr == R) { rr = 0; ++kc; }
         }
-    }
-    float4 vb[8];                                        // W[k][n0 + 4 j4 ..]: 16 lanes per k row
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int idx = t + u * 256, k = min(idx >> 4, K - 1), j4 = idx & 15;
-        vb[u] = *reinterpret_cast<const float4*>(br.W + (size_t)k * H + n0 + 4 * j4);
     }
     const int pv = g.ptr[g0 + min(t, rows)];
     const float dv = br.dis[g0 + min(t, rows - 1)];

@@ -62,6 +62,8 @@ struct GconvBwdBranch {
     int gn_slot;             // gn is written in CSR-slot order (gn[eptr[b] + s], for the per-graph attention backward) instead of edge-id order
 };
 
+struct GconvBwdBranch2 { GconvBwdBranch b[2]; };
+
 // acc[0] (+acc[1]) += A B over kred (multiple of 32) with k-major LDS operands A[k*LDA + row], B[k*LDB + col];
 // NA == 2: two row tiles (a0, a1) against b0; NB == 2: a0 against two column tiles (b0, b1).
 // ax(v, kstep) transforms an A element (identity or the BatchNorm affine of the lane's row).
@@ -155,7 +157,7 @@ __device__ __forceinline__ void gb_mma_rowk2(const float* a0_row, const float* a
 
 template <bool RS, int MODE>      // MODE 0: dOut given; 1: UP (from the upper layer's partials); 2: POOL (+ gn / gself)
 __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
-                                                   const GconvBwdBranch b0, const GconvBwdBranch b1, float loop_w, int N, int H,
+                                                   const GconvBwdBranch2 bb, float loop_w, int N, int H,
                                                    int K, int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) float Ab[GB_T * GB_LDJ];       // adjacency block Ab[j][i]: dz_i += Ab[j][i] dOut_j
     __shared__ __attribute__((aligned(16))) float Ds[GB_T * GB_LDD];       // dOut slice [j][n]; later dz [i][n]
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     __shared__ short er[GB_E];                           // destination row of CSR slot s
     constexpr bool UP = MODE == 1, POOL = MODE == 2;
     BLK_CLK(0);
-    const GconvBwdBranch& br = blockIdx.z ? b1 : b0;
+    const GconvBwdBranch& br = bb.b[blockIdx.z];         // indexed in the kernel-argument segment (see k_gconv_fwd)
     const int b = blockIdx.x, sl = blockIdx.y, ns0 = sl * GC_N, t = threadIdx.x;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
     const int pb = (MODE == 2 && br.iperm) ? br.iperm[b] : b;         // row of the second pooled-gradient partial (scalar load, with the extents)

@@ -197,12 +197,14 @@ struct SpmmBranch {
     Acc st_sq;
 };
 
+struct SpmmBranch2 { SpmmBranch b[2]; };
+
 template <int VEC, int G>
-__global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch b0, const SpmmBranch b1, int relu,
+__global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch2 bb, int relu,
                                                float loop_w, int N, int H, int rows_per_block) {
     __shared__ double lds[2][256 * (VEC == 4 ? 4 : 1)];
     constexpr int RPB = 256 / G;
-    const SpmmBranch& br = blockIdx.y ? b1 : b0;
+    const SpmmBranch& br = bb.b[blockIdx.y];            // indexed in the kernel-argument segment: one set of scalar loads
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
     // XCD-contiguous row blocks: workgroups are dealt to the 8 XCDs round-robin, and a row's neighbours live in its
     // own graph (block-diagonal batch).  Workgroup w therefore takes row block (w % 8) * (blocks / 8) + w / 8 -- each
