@@ -1129,7 +1129,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                               bn_dsum(c, bn_fc2 + 2 * hd), bn_dprod(c, bn_fc2 + 2 * hd), e->arena + e->a_db1 + hd * H};
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(B, c.rpb_b), 3), dim3(256), 0, st, p[0], p[1], p[2], 1, B, H, c.rpb_b);
+            hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(B, c.rpb_b), 3), dim3(256), 0, st, BnBwdProb3{{p[0], p[1], p[2]}}, 1, B, H, c.rpb_b);
             return 0;
         }));
         CAL_CHECK_LAUNCH("k_bn_bwd(readout)"); STAGE();
@@ -1462,7 +1462,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                 BnBwdProb p{p0, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i), Acc(), H > GC_N ? dzi : nullptr};
                 RC(with_g(H, [&](auto g) {
                     constexpr int G = decltype(g)::value;
-                    hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
+                    hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, BnBwdProb3{{p, p, p}}, 1, N, H, c.rpb_n);
                     return 0;
                 }));
                 CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();
@@ -1517,7 +1517,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                 BnBwdProb p{p0, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i), Acc(), H > GC_N ? dzi : nullptr};
                 RC(with_g(H, [&](auto g) {
                     constexpr int G = decltype(g)::value;
-                    hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
+                    hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, BnBwdProb3{{p, p, p}}, 1, N, H, c.rpb_n);
                     return 0;
                 }));
                 CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();
@@ -1570,7 +1570,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                         i >= 2 ? deferred(H, d_convb[i - 2]) : Acc()};
             RC(with_g(H, [&](auto g) {
                 constexpr int G = decltype(g)::value;
-                hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, p, p, p, 1, N, H, c.rpb_n);
+                hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, BnBwdProb3{{p, p, p}}, 1, N, H, c.rpb_n);
                 return 0;
             }));
             CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();

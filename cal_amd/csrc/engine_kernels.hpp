@@ -653,12 +653,14 @@ struct BnBwdProb {
     const float* dyh2;   // second partial of dyh (per-graph fused backward: one per output-column slice) or null
 };
 
+struct BnBwdProb3 { BnBwdProb p[3]; };
+
 template <int VEC, int G>
-__global__ void __launch_bounds__(256) k_bn_bwd(const BnBwdProb p0, const BnBwdProb p1, const BnBwdProb p2, int relu,
+__global__ void __launch_bounds__(256) k_bn_bwd(const BnBwdProb3 pp, int relu,
                                                 int N, int W, int rows_per_block) {
     __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
     constexpr int RPB = 256 / G;
-    const BnBwdProb& p = blockIdx.y == 0 ? p0 : (blockIdx.y == 1 ? p1 : p2);
+    const BnBwdProb& p = pp.p[blockIdx.y];              // indexed in the kernel-argument segment (see k_gconv_fwd)
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
     using V = Vec<VEC>;
