@@ -146,6 +146,23 @@ __device__ __forceinline__ void randperm_block(int64_t* __restrict__ perm, int B
     if (threadIdx.x == 0) *counter = cnt + 1;
 }
 
+// Touch every 64 B line of the kernel-argument segment in ONE round of scalar loads at the top of a kernel: hipcc sinks
+// argument loads into the blocks that use them, and each first touch of another line is a scalar-cache miss (a few
+// hundred ns) in its own dependent round; after this every later argument load is a hit.
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned* ka = (const unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int NL = (BYTES + 63) / 64;
+    static_assert(NL <= 16, "argument segment larger than 1 KB");
+    unsigned v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = ka[16 * (i < NL ? i : 0)];
+    asm volatile("" :: "s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]), "s"(v[8]), "s"(v[9]),
+                 "s"(v[10]), "s"(v[11]), "s"(v[12]), "s"(v[13]), "s"(v[14]), "s"(v[15]));
+#endif
+}
+
 }  // namespace cal
 
 namespace cal { inline const char* g_last_launch = ""; }     // name of the latest launch site (profiling aid)

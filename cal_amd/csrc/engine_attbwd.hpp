@@ -45,6 +45,7 @@ constexpr int AG_LD = AG_T + 1;
 template <int VEC, int G>
 __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga, int relu, int H, int nsplit) {
     constexpr int RPB = 512 / G, UR = 2, HALF = AG_T / 2;
+    warm_kernargs<sizeof(AttBwdGraphArgs) + 16>();
     const AttBwdArgs& a = ga.a;
     // dense per-graph blocks, [source r][destination c]: Tc / To = sum over the edges r -> c of g_k w_k (d deg terms),
     // D = sum of dl.  Duplicate edges accumulate through the LDS atomic (commutative for the usual <= 2 copies).

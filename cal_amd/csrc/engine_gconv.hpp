@@ -196,6 +196,7 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     __shared__ double red[4][2][32];
     __shared__ float pool_s[4][32];
     BLK_CLK(0);
+    warm_kernargs<sizeof(CSR) + 2 * sizeof(void*) + sizeof(GconvBranch2) + 32>();
     const GconvBranch& br = bb.b[blockIdx.z];           // indexed in the kernel-argument segment: one set of scalar loads (b0 / b1 as two parameters were loaded both and selected field by field)
     const int b = blockIdx.x, n0 = blockIdx.y * GC_N, t = threadIdx.x;
     // the W slice does not depend on the graph: requested before the graph's extents (a scalar round trip) are known

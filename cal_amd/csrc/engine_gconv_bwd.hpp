@@ -176,6 +176,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     __shared__ short er[GB_E];                           // destination row of CSR slot s
     constexpr bool UP = MODE == 1, POOL = MODE == 2;
     BLK_CLK(0);
+    warm_kernargs<sizeof(CSR) + 2 * sizeof(void*) + sizeof(GconvBwdBranch2) + 32>();
     const GconvBwdBranch& br = bb.b[blockIdx.z];         // indexed in the kernel-argument segment (see k_gconv_fwd)
     const int b = blockIdx.x, sl = blockIdx.y, ns0 = sl * GC_N, t = threadIdx.x;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
@@ -518,6 +519,7 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
     __shared__ float m0_s[FB_F], r0_s[FB_F], g0_s[FB_F], b0_s[FB_F];
     __shared__ float dX0[FB_T * FB_F];
     BLK_CLK(0);
+    warm_kernargs<sizeof(FeatBwdArgs) + 32>();
     const int b = blockIdx.x, t = threadIdx.x, LDZ = FB_H + 4;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0;
     float* slab = a.slab + (size_t)b * F * H;

@@ -189,6 +189,7 @@ __global__ void __launch_bounds__(512) k_att_fwd_graph(const int* __restrict__ g
     constexpr int RPB = 512 / G, MAXR = 4 * RPB;
     __shared__ double lds[4 * 512 * (VEC == 4 ? 4 : 1)];
     __shared__ float4 pq_s[MAXR];
+    warm_kernargs<320>();
     const int b = blockIdx.x, t = threadIdx.x, grp = t / G, l = t % G;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0;
     // the graph's by-source CSR rows for the edge phase: requested NOW, with the row loads (its slot range is its edge range,

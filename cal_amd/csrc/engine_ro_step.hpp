@@ -98,6 +98,7 @@ __device__ __forceinline__ void ro_mfma_rowk(int ntiles, int kred, const float* 
 }
 
 __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
+    warm_kernargs<(sizeof(RoStepArgs) < 1024 ? sizeof(RoStepArgs) : 1024)>();
     const RoArgs& a = sa.a;
     __shared__ __attribute__((aligned(16))) float Xs[RS_B * RS_LD];         // raw input rows; phase C: dy1 rows
     __shared__ __attribute__((aligned(16))) float Ws[RO_CW * RS_LD];        // W1[j0 + j][:]
