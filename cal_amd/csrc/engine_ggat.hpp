@@ -46,6 +46,7 @@ __device__ __forceinline__ float gg_lrelu(float v, float slope) { return v > 0.f
 __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                   const GgatArgs a, int H, int K, int* __restrict__ status) {
     constexpr int T = GG_T, LDA = T + 1;
+    warm_kernargs<(sizeof(GgatArgs) + 64 < 1024 ? sizeof(GgatArgs) + 64 : 1024)>();
     constexpr int LDT = T + 4;                           // row stride of the j-major tiles of the second product (4 mod 32)
     __shared__ __attribute__((aligned(16))) float As[2 * T * LDT];          // x' rows [row][k] (stride GC_LDX, as k_gconv_fwd); later two attention blocks [h][i][j]
     __shared__ __attribute__((aligned(16))) float Bs[GC_K * GC_LDB];       // W slice [k][col]; later the z tile [row][col]
@@ -356,6 +357,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     __shared__ float att_s[2 * GC_N];
     __shared__ float ad_s[2][T], as_s[2][T], mx_s[2][T], dn_s[2][T], dad_s[2][T], das_s[2][T];
     BLK_CLK(0);
+    warm_kernargs<(sizeof(GgatBwdArgs) + 64 < 1024 ? sizeof(GgatBwdArgs) + 64 : 1024)>();
     const int b = blockIdx.x, sl = blockIdx.y, ns0 = sl * GC_N, t = threadIdx.x;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
     const int lane = t & 63, li = lane & 31, lk = lane >> 5;
