@@ -153,13 +153,15 @@ template <int BYTES>
 __device__ __forceinline__ void warm_kernargs() {
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned* ka = (const unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
-    constexpr int NL = (BYTES + 63) / 64;
-    static_assert(NL <= 16, "argument segment larger than 1 KB");
-    unsigned v[16];
+    constexpr int NL = (BYTES + 63) / 64 < 32 ? (BYTES + 63) / 64 : 32;      // at most 2 KB
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = ka[16 * (i < NL ? i : 0)];
-    asm volatile("" :: "s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]), "s"(v[8]), "s"(v[9]),
-                 "s"(v[10]), "s"(v[11]), "s"(v[12]), "s"(v[13]), "s"(v[14]), "s"(v[15]));
+    for (int g = 0; g < NL; g += 16) {
+        unsigned v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = ka[16 * (g + i < NL ? g + i : 0)];
+        asm volatile("" :: "s"(v[0]), "s"(v[1]), "s"(v[2]), "s"(v[3]), "s"(v[4]), "s"(v[5]), "s"(v[6]), "s"(v[7]), "s"(v[8]), "s"(v[9]),
+                     "s"(v[10]), "s"(v[11]), "s"(v[12]), "s"(v[13]), "s"(v[14]), "s"(v[15]));
+    }
 #endif
 }
 

@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch2 bb
                                                float loop_w, int N, int H, int rows_per_block) {
     __shared__ double lds[2][256 * (VEC == 4 ? 4 : 1)];
     constexpr int RPB = 256 / G;
+    warm_kernargs<sizeof(CSR) + sizeof(SpmmBranch2) + 32>();
     const SpmmBranch& br = bb.b[blockIdx.y];            // indexed in the kernel-argument segment: one set of scalar loads
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
     // XCD-contiguous row blocks: workgroups are dealt to the 8 XCDs round-robin, and a row's neighbours live in its
@@ -660,6 +661,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd(const BnBwdProb3 pp, int relu,
                                                 int N, int W, int rows_per_block) {
     __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
     constexpr int RPB = 256 / G;
+    warm_kernargs<sizeof(BnBwdProb3) + 32>();
     const BnBwdProb& p = pp.p[blockIdx.y];              // indexed in the kernel-argument segment (see k_gconv_fwd)
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
@@ -892,6 +894,7 @@ struct AttBwdArgs {
 
 template <int VEC, int G>
 __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, int N, int H, int rows_per_block) {
+    warm_kernargs<sizeof(AttBwdArgs) + 16>();
     __shared__ double lds[4 * 256 * (VEC == 4 ? 4 : 1)];
     __shared__ double sc_lds[2][256 / G];
     constexpr int RPB = 256 / G;

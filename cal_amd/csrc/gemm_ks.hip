@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(256) k_gemm_ks(const GemmArgs a) {
     // operand slices; the reduction buffer Rs[4][32*32] aliases the A slices once the MFMAs are done
     __shared__ __attribute__((aligned(16))) float smem[4 * TK * LA + 4 * TK * LB];
     static_assert(4 * TM * TN <= 4 * TK * LA, "reduction buffer must fit in the A slices");
+    warm_kernargs<sizeof(GemmArgs)>();
     __shared__ float xsc[XA > 0 ? KS_XMAX : 4], xsh[XA > 0 ? KS_XMAX : 4];
     __shared__ double cred[4][2][TN];
 
