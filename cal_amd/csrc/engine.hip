@@ -874,7 +874,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H); }
             {
                 ProfScope ps(st, 2, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
-                if (gc_small(c)) PROF_LAUNCH((k_gconv_fwd<false, 64>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1,
+                if (gc_small(c)) PROF_LAUNCH((k_gconv_fwd<false, 64, 512>), dim3(B, H / GC_N, 1), dim3(512), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1,
                                                     e->loop_w, H, H, e->status);
                 else PROF_LAUNCH((k_gconv_fwd<false, GC_T>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1,
                                         e->loop_w, H, H, e->status);
@@ -949,7 +949,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             gb[k].coef_out = e->coef + (size_t)(1 + k) * E;
             gb[k].w_out = e->wslot + (size_t)k * E;
         }
-        if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<true, 64>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1,
+        if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<true, 64, 512>), dim3(B, H / GC_N, 2), dim3(512), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1,
                                             e->loop_w, H, H, e->status);
         else hipLaunchKernelGGL((k_gconv_fwd<true, GC_T>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1,
                                 e->loop_w, H, H, e->status);

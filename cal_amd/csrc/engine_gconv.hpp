@@ -180,11 +180,16 @@ __device__ __forceinline__ void gconv_mma_rowk(const float* At, const float* Zt,
     }
 }
 
-template <bool RS, int T>
-__global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
+template <bool RS, int T, int NT = 256>
+__global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBranch2 bb, int relu, float loop_w, int H,
                                                    int K, int* __restrict__ status) {
+    // NT = 256: one 32 x 32 tile pair per wave.  NT = 512 (T = 64): eight waves -- the first product's reduction range is
+    // split over two waves per tile (partial z tiles combined through LDS), twice the lanes stage the operands, and waves
+    // 4-7 are free for the adjacency block while waves 0-3 finish the z tile
     constexpr int LDA = T + 1, ECAP = gc_edge_cap(T);
+    constexpr int WU = 2048 / NT, CU = (ECAP + NT - 1) / NT, RPP = NT / 8, NRS = T / RPP > 0 ? T / RPP : 1;
+    static_assert(NT == 256 || (NT == 512 && T == 64), "512 threads: 64-node variant only");
     __shared__ __attribute__((aligned(16))) float As[(GC_K * LDA > T * GC_LDX) ? GC_K * LDA : T * GC_LDX];   // x' rows [row][k] (stride GC_LDX); later the adjacency block [j][i] (stride LDA)
     __shared__ __attribute__((aligned(16))) float Bs[GC_K * GC_LDB];       // W slice [k][col]; later the z tile [row][col]
     __shared__ float sc_s[GC_K], sh_s[GC_K];
@@ -200,10 +205,10 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     const GconvBranch& br = bb.b[blockIdx.z];           // indexed in the kernel-argument segment: one set of scalar loads (b0 / b1 as two parameters were loaded both and selected field by field)
     const int b = blockIdx.x, n0 = blockIdx.y * GC_N, t = threadIdx.x;
     // the W slice does not depend on the graph: requested before the graph's extents (a scalar round trip) are known
-    float4 vb[8];                                        // W[k][n0 + 4 j4 ..]: 16 lanes per k row
+    float4 vb[WU];                                       // W[k][n0 + 4 j4 ..]: 16 lanes per k row
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int idx = t + u * 256, k = min(idx >> 4, K - 1), j4 = idx & 15;
+    for (int u = 0; u < WU; ++u) {
+        const int idx = t + u * NT, k = min(idx >> 4, K - 1), j4 = idx & 15;
         vb[u] = *reinterpret_cast<const float4*>(br.W + (size_t)k * H + n0 + 4 * j4);
     }
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
@@ -223,78 +228,78 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     RO_CLK(32);
     BLK_CLK(2);
     const bool hasw = br.ew != nullptr;
-    const int rowsP = (rows + 31) & ~31, R = rowsP >> 5, nkc = K >> 5;
+    const int rowsP = (rows + 31) & ~31, R = rowsP >> 5, nkc = K >> 5, RB = (rowsP + RPP - 1) / RPP;
     // ---- every global load of the kernel, issued before the first wait -------------------------------------
     // x rows: item (u, t) -> 32-wide k chunk kc, row block rr, row (t >> 3), float4 (t & 7) of the chunk:
     // 8 lanes x 16 B per row (coalesced), and the transposing LDS stores below see only 2-way bank conflicts
-    constexpr int UA = T / 8;                          // x float4s per lane: T rows x GC_K / 4 over 256 lanes
+    constexpr int UA = T * 32 / NT;                    // x float4s per lane: T rows x GC_K / 4 over NT lanes
     float4 va[UA];
     {
         int kc = 0, rr = 0;
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
             const bool ok = kc < nkc;
-            const int r = min(((ok ? rr : 0) << 5) + (t >> 3), rows - 1), k = ((ok ? kc : 0) << 5) + ((t & 7) << 2);
+            const int r = min((ok ? rr : 0) * RPP + (t >> 3), rows - 1), k = ((ok ? kc : 0) << 5) + ((t & 7) << 2);
             va[u] = *reinterpret_cast<const float4*>(br.x + (size_t)(g0 + r) * K + k);
-            if (++rr == R) { rr = 0; ++kc; }
+            if (++rr == RB) { rr = 0; ++kc; }
         }
     }
     const int pv = g.ptr[g0 + min(t, rows)];
     const float dv = br.dis[g0 + min(t, rows - 1)];
-    float rsv[4] = {1.f, 1.f, 1.f, 1.f};                 // row scale of this lane's x row in each 32-row block
+    float rsv[4] = {1.f, 1.f, 1.f, 1.f};                 // row scale of this lane's x row in each RPP-row block
     if (RS) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rsv[q] = br.rs[(size_t)(g0 + min((q << 5) + (t >> 3), rows - 1)) * br.rs_stride];
+        for (int q = 0; q < NRS; ++q) rsv[q] = br.rs[(size_t)(g0 + min(q * RPP + (t >> 3), rows - 1)) * br.rs_stride];
     }
     // CSR slots, BatchNorm constants, bias, coefficients: all unconditional on clamped indices / substituted pointers
     // (see BNRaw in engine.hpp: guarded loads here cost four serial round trips behind the tile loads)
-    int nv[8], ev[8];
+    int nv[CU], ev[CU];
     const int slot_hi = max(g.nnz - 1, 0);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int s = min(e0 + max(min(t + u * 256, ne - 1), 0), slot_hi);
+    for (int u = 0; u < CU; ++u) {
+        const int s = min(e0 + max(min(t + u * NT, ne - 1), 0), slot_hi);
         nv[u] = g.nbr[s];
         ev[u] = g.eid[s];
     }
     const int lane = t & 63, li = lane & 31, lk = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int ct = w & 1, r0 = w >> 1;
+    const int kh = w >> 2, ct = w & 1, r0 = (w & 3) >> 1;     // kh: half of the first product's reduction range (NT = 512)
     const float* biasp = br.bias ? br.bias : br.W;       // W: any valid [>= H] float array; the value is masked below
     float bias = biasp[n0 + ct * 32 + li];
     BNRaw braw = bn_raw_load(br.bn, min(t, K - 1));
     const float* coefp = br.coef_in ? br.coef_in : br.dis;
     const int coef_hi = br.coef_in ? slot_hi : 0;
-    float cin[8];                                        // coefficients of an earlier kernel of this step, if any
+    float cin[CU];                                       // coefficients of an earlier kernel of this step, if any
 #pragma unroll
-    for (int u = 0; u < 8; ++u) cin[u] = coefp[min(e0 + max(min(t + u * 256, ne - 1), 0), coef_hi)];
+    for (int u = 0; u < CU; ++u) cin[u] = coefp[min(e0 + max(min(t + u * NT, ne - 1), 0), coef_hi)];
     // all of the above stay in flight together: without the pins hipcc pairs every W load with its LDS store
     // ("load, s_waitcnt vmcnt(0), ds_write" x 8: eight serial round trips, 5-30 us under 256-way contention)
 #pragma unroll
     for (int u = 0; u < UA; ++u) ro_pin(va[u]);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) ro_pin(vb[u]);
+    for (int u = 0; u < WU; ++u) ro_pin(vb[u]);
     bn_raw_pin(braw);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]), "+v"(cin[u]));
+    for (int u = 0; u < CU; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]), "+v"(cin[u]));
     asm volatile("" : "+v"(bias));
     if (!br.bias) bias = 0.f;
     if (ne <= 0) {                                       // no slot of this graph exists: what the clamped loads fetched is not an index
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { nv[u] = g0; ev[u] = 0; }
+        for (int u = 0; u < CU; ++u) { nv[u] = g0; ev[u] = 0; }
     }
     if (t < K) {
         bn_raw_scale_shift(br.bn, braw, sc_s[t], sh_s[t]);
         if (br.bn.update && blockIdx.x == 0 && blockIdx.y == 0) bn_raw_update_running(br.bn, braw, t);
     }
     // second round: edge coefficients dis_j * w_e (needs the neighbour / edge ids)
-    float cv[8], wv[8];
+    float cv[CU], wv[CU];
     if (br.coef_in) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { cv[u] = cin[u]; wv[u] = 1.f; }
+        for (int u = 0; u < CU; ++u) { cv[u] = cin[u]; wv[u] = 1.f; }
     } else {
         const float* ewp = hasw ? br.ew : br.dis;        // (masked when there are no edge weights)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < CU; ++u) {
             const float c = br.dis[nv[u]];
             const float wl = ewp[hasw ? ev[u] : 0];
             wv[u] = hasw ? wl : 1.f;
@@ -306,8 +311,8 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     if (t <= rows) ptr_s[t] = pv - e0;
     if (t < rows) dis_s[t] = dv;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int s = t + u * 256;
+    for (int u = 0; u < CU; ++u) {
+        const int s = t + u * NT;
         if (s < ne) {
             const int loc = nv[u] - g0;
             const bool inb = loc >= 0 && loc < rows;        // an edge that leaves its graph is not a mini-batch: flag it
@@ -317,8 +322,8 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
         }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int idx = t + u * 256, k = idx >> 4, j4 = idx & 15;
+    for (int u = 0; u < WU; ++u) {
+        const int idx = t + u * NT, k = idx >> 4, j4 = idx & 15;
         if (k < K) *reinterpret_cast<float4*>(Bs + k * GC_LDB + 4 * j4) = vb[u];
     }
     RO_CLK(34);
@@ -332,17 +337,17 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
 #pragma unroll
         for (int u = 0; u < UA; ++u) {
             if (kc < nkc) {
-                const int r = (rr << 5) + (t >> 3), k = (kc << 5) + ((t & 7) << 2);
+                const int r = rr * RPP + (t >> 3), k = (kc << 5) + ((t & 7) << 2);
                 float x0 = va[u].x, x1 = va[u].y, x2 = va[u].z, x3 = va[u].w;
                 if (RS) {
-                    const float s = rr == 0 ? rsv[0] : (rr == 1 ? rsv[1] : (rr == 2 ? rsv[2] : rsv[3]));
+                    const float s = (NRS == 1 || rr == 0) ? rsv[0] : ((NRS == 2 || rr == 1) ? rsv[1] : (rr == 2 ? rsv[2] : rsv[3]));
                     x0 *= s; x1 *= s; x2 *= s; x3 *= s;
                 }
                 *reinterpret_cast<float4*>(As + r * GC_LDX + k) =
                     make_float4(fmaf(x0, sc_s[k], sh_s[k]), fmaf(x1, sc_s[k + 1], sh_s[k + 1]), fmaf(x2, sc_s[k + 2], sh_s[k + 2]),
                                 fmaf(x3, sc_s[k + 3], sh_s[k + 3]));
             }
-            if (++rr == R) { rr = 0; ++kc; }
+            if (++rr == RB) { rr = 0; ++kc; }
         }
     }
     __syncthreads();
@@ -353,7 +358,10 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
     if (r0 < R) {
-        if (r0 + 2 < R) gconv_mma_arow<true, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
+        if (NT == 512) {                                 // this wave's half of the reduction range
+            const int kofs = kh * (K >> 1);
+            gconv_mma_arow<false, GC_LDB>(As + kofs, Bs + kofs * GC_LDB, K >> 1, r0, ct, li, lk, acc0, acc1);
+        } else if (r0 + 2 < R) gconv_mma_arow<true, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
         else gconv_mma_arow<false, GC_LDB>(As, Bs, K, r0, ct, li, lk, acc0, acc1);
     }
     RO_CLK(36);
@@ -362,21 +370,22 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     constexpr int LDT = T + 4;                           // row stride of the two j-major tiles below (4 mod 32)
     float* Zt = Bs;                                      // Zt[col * LDT + j] = z[j][col]   (over the W stage)
     float* At = As;                                      // At[i * LDT + j] = weight of edge j -> i, times dis_i   (over the x stage)
-    if (r0 < R) {
+    const bool own = NT == 256 || kh == 0;               // the wave that finishes its tile (NT = 512: adds its partner's partial below)
+    if (r0 < R && (NT == 256 || kh == 1)) {
         // an accumulator holds rows 8 g + 4 lk .. + 3 of its tile in elements 4 g .. 4 g + 3: four consecutive j of one column
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int row = r0 * 32 + 8 * gq + 4 * lk;
             *reinterpret_cast<float4*>(Zt + (ct * 32 + li) * LDT + row) = make_float4(acc0[4 * gq], acc0[4 * gq + 1], acc0[4 * gq + 2], acc0[4 * gq + 3]);
         }
-        if (br.z) {
+        if (NT == 256 && br.z) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (row < rows) br.z[(size_t)(g0 + row) * H + n0 + ct * 32 + li] = acc0[r];
             }
         }
-        if (r0 + 2 < R) {
+        if (NT == 256 && r0 + 2 < R) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int row = (r0 + 2) * 32 + 8 * gq + 4 * lk;
@@ -394,13 +403,29 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     {
         const int nz4 = (rowsP * LDT) >> 2;           // rows i < rowsP of the block (contiguous), as float4s
         float4* z4 = reinterpret_cast<float4*>(At);
-        for (int idx = t; idx < nz4; idx += 256) z4[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int idx = t; idx < nz4; idx += NT) z4[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
+    if (NT == 512 && kh == 0 && r0 < R) {                // z tile = this wave's half + the partner's (already in Zt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float4* zp = reinterpret_cast<float4*>(Zt + (ct * 32 + li) * LDT + r0 * 32 + 8 * gq + 4 * lk);
+            const float4 p = *zp;
+            acc0[4 * gq] += p.x; acc0[4 * gq + 1] += p.y; acc0[4 * gq + 2] += p.z; acc0[4 * gq + 3] += p.w;
+            *zp = make_float4(acc0[4 * gq], acc0[4 * gq + 1], acc0[4 * gq + 2], acc0[4 * gq + 3]);
+        }
+        if (br.z) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < rows) br.z[(size_t)(g0 + row) * H + n0 + ct * 32 + li] = acc0[r];
+            }
+        }
+    }
     // one lane per CSR slot (then one per self loop): duplicate edges accumulate through the LDS atomic.  One lane per
     // destination ROW walked a hub's 30 slots as 30 dependent LDS round trips (read source, read coefficient,
     // read-modify-write the block) while the other lanes idled -- the slowest row was the phase.
-    for (int s = t; s < ne; s += 256) {
+    for (int s = t; s < ne; s += NT) {
         const int i = er[s];
         atomicAdd(&At[i * LDT + en[s]], dis_s[i] * ec[s]);
     }
@@ -410,7 +435,7 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     // ---- out tile = A z on the matrix cores (reduction over the graph's rowsP nodes) ---------------------------
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
-    if (r0 < R) {
+    if (own && r0 < R) {
         if (r0 + 2 < R) gconv_mma_rowk<true, LDT>(At, Zt, rowsP, r0, ct, li, lk, acc0, acc1);
         else gconv_mma_rowk<false, LDT>(At, Zt, rowsP, r0, ct, li, lk, acc0, acc1);
     }
@@ -422,7 +447,7 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     float psum = 0.f;
     const int col = n0 + ct * 32 + li;
     asm volatile("" :: "v"(bias));                       // consume the bias load before the guarded stores (see gemm.hip)
-    if (r0 < R) {
+    if (own && r0 < R) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
@@ -451,7 +476,7 @@ __global__ void __launch_bounds__(256) k_gconv_fwd(const CSR g, const int* __res
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     psum += __shfl_xor(psum, 32, 64);
-    if (lk == 0) { red[w][0][li] = s1; red[w][1][li] = s2; pool_s[w][li] = psum; }
+    if (own && lk == 0) { red[w & 3][0][li] = s1; red[w & 3][1][li] = s2; pool_s[w & 3][li] = psum; }
     __syncthreads();
     if (w < 2 && lk == 0) {
         if (want) {
