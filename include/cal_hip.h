@@ -144,7 +144,7 @@ CAL_API int cal_engine_set_gat(void* engine, int64_t heads, float p, float slope
 
 /* ---- native CausalGCN step engine ------------------------------------------------
  * The whole train step of train_causal.py:173-192 on model.py:85-164 (forward, 3-term loss,
- * backward, Adam) as one call enqueuing a few dozen fused kernels (25 at BASELINE config 2); see cal_amd/csrc/engine.hip for the
+ * backward, Adam) as one call enqueuing a few dozen fused kernels (24 at BASELINE config 2); see cal_amd/csrc/engine.hip for the
  * slot order of `offs` / `bn_ptrs`.  mode bits: 1 = training-mode forward, 2 = loss gradient +
  * backward into the flat gradient buffer, 4 = Adam (applied inside the step's last kernel; the step counter is advanced by
  * its first one), 8 = Adam follows separately (cal_engine_adam_ticked),
