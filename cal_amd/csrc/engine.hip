@@ -769,10 +769,16 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     (void)gs;
     // 2. bn_feat statistics (model.py:90)
     if (c.training && !plan_stats) {
+        // wide feature matrices (one-hot degrees: F = 139 at the NCI1-like shape): many short blocks whose column sums go to
+        // partial rows (k_stats_final) -- F fp64 atomics per block on the same 2 F addresses cost more than the reads
         int tc = std::min(256, pow2ceil(F));
-        int rpb = std::max(128, cdiv(N, 256));
-        hipLaunchKernelGGL(k_colstats, dim3(cdiv(N, rpb)), dim3(256), 0, st, x0, N, F, tc, rpb, Acc(bn_stsum(c, 0)), Acc(bn_stsq(c, 0)));
+        const bool wide = (size_t)cdiv(N, 32) * F > 16384;
+        int rpb = wide ? std::max(32, cdiv(N, 1024)) : std::max(128, cdiv(N, 256));
+        const Acc a0 = wide ? spmm_acc(c, bn_stsum(c, 0), F, rpb) : Acc(bn_stsum(c, 0));
+        const Acc a1 = wide ? spmm_acc(c, bn_stsq(c, 0), F, rpb) : Acc(bn_stsq(c, 0));
+        hipLaunchKernelGGL(k_colstats, dim3(cdiv(N, rpb)), dim3(256), 0, st, x0, N, F, tc, rpb, a0, a1);
         CAL_CHECK_LAUNCH("k_colstats"); STAGE();
+        if (wide) { RC(flush_finals(c)); STAGE(); }
     }
     // 3. h0 = relu(BN(x0) @ W_feat)   (model.py:90-91, gcn_conv.py:75-77)
     {
@@ -1048,8 +1054,10 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         }
         RC(fwd_gemm(c, true, a, 3)); STAGE();
     }
-    hipLaunchKernelGGL(k_loss, dim3(1), dim3(256), 0, st, e->zl, y, e->logp, e->dzl, e->stats, e->arena + e->a_db2, B, C, wc, wo,
-                       wco, want_grad);
+    if (B > 256) hipLaunchKernelGGL(k_loss<1024>, dim3(1), dim3(1024), 0, st, e->zl, y, e->logp, e->dzl, e->stats, e->arena + e->a_db2, B, C, wc, wo,
+                                    wco, want_grad);
+    else hipLaunchKernelGGL(k_loss<256>, dim3(1), dim3(256), 0, st, e->zl, y, e->logp, e->dzl, e->stats, e->arena + e->a_db2, B, C, wc, wo,
+                            wco, want_grad);
     CAL_CHECK_LAUNCH("k_loss"); STAGE();
     return 0;
 }

@@ -151,11 +151,21 @@ __global__ void __launch_bounds__(256) k_colstats(const float* __restrict__ x, i
     const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
     for (int cc = c; cc - c < W; cc += tc) {
         const bool ok = cc < W;
+        // eight rows in flight per lane (clamped, masked when added): as a loop of single dependent-latency loads this kernel
+        // took 52 us over a [15k, 139] matrix
         double s = 0.0, q = 0.0;
-        if (ok)
-            for (int r = r0 + rl; r < r1; r += nrl) {
-                double v = x[(size_t)r * W + cc];
-                s += v; q += v * v;
+        if (ok && r0 + rl < r1)
+            for (int r = r0 + rl; r < r1; r += 8 * nrl) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = x[(size_t)min(r + u * nrl, r1 - 1) * W + cc];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double d = r + u * nrl < r1 ? (double)v[u] : 0.0;
+                    s += d; q += d * d;
+                }
             }
         block_col_atomic(s, c, rl, nrl, tc, ok, sum, cc, lds);
         block_col_atomic(q, c, rl, nrl, tc, ok, sq, cc, lds);
@@ -539,19 +549,20 @@ __global__ void __launch_bounds__(256) k_readout_prep(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // log_softmax + 3-term loss (train_causal.py:176-183) + gradient w.r.t. the pre-softmax scores.
-// One workgroup.  z, logp, dz: [3,B,C] (heads c, o, co).  stats: [loss, c, o, co, correct_o].
+// One workgroup (NT = 256 threads, 1024 for B > 256: 19.7 -> us at B = 512).  z, logp, dz: [3,B,C] (heads c, o, co).  stats: [loss, c, o, co, correct_o].
 // db2[h*C + k] = column sums of dz (fc2 bias gradients), written to the fp64 arena.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_loss(const float* __restrict__ z, const int64_t* __restrict__ y,
+template <int NT>
+__global__ void __launch_bounds__(NT) k_loss(const float* __restrict__ z, const int64_t* __restrict__ y,
                                               float* __restrict__ logp, float* __restrict__ dz,
                                               float* __restrict__ stats, double* __restrict__ db2, int B, int C,
                                               float wc, float wo, float wco, int want_grad) {
-    __shared__ double red[256];
+    __shared__ double red[NT];
     __shared__ double tot[4];
     const float w[3] = {wc, wo, wco};
     double part[4] = {0.0, 0.0, 0.0, 0.0};   // c, o, co, correct
     const float u = 1.0f / (float)C, invB = 1.0f / (float)B;
-    for (int t = threadIdx.x; t < 3 * B; t += 256) {
+    for (int t = threadIdx.x; t < 3 * B; t += NT) {
         const int hd = t / B, b = t % B;
         const float* zr = z + (size_t)t * C;
         float m = -INFINITY;
@@ -578,7 +589,7 @@ __global__ void __launch_bounds__(256) k_loss(const float* __restrict__ z, const
     for (int q = 0; q < 4; ++q) {
         red[threadIdx.x] = part[q];
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
+        for (int o = NT / 2; o > 0; o >>= 1) {
             if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
             __syncthreads();
         }
@@ -592,8 +603,8 @@ __global__ void __launch_bounds__(256) k_loss(const float* __restrict__ z, const
     }
     if (want_grad) {
         __syncthreads();
-        // column sums of dz: (3C columns) x (256 / 3C row lanes), then a serial LDS tail per column
-        const int nc = 3 * C, nl = 256 / nc;
+        // column sums of dz: (3C columns) x (NT / 3C row lanes), then a serial LDS tail per column
+        const int nc = 3 * C, nl = NT / nc;
         const int cidx = threadIdx.x % nc, pl = threadIdx.x / nc;
         double sacc = 0.0;
         if (pl < nl) {

@@ -232,6 +232,9 @@ def _ragged_batch(seed, nfeat, sizes):
     (48, 1, 5, 3, [4, 2, 7] * 12 + [5]),
     (80, 2, 4, 40, [3, 5] * 50),
     (16, 1, 6, 2, [2, 3] * 100),
+    # NCI1-like: B > 256 (1024-thread loss kernel, GEMM readout) and a wide one-hot-style feature matrix (bn_feat statistics
+    # through partial rows: k_colstats + k_stats_final)
+    (128, 2, 139, 2, [20 + (i * 7) % 21 for i in range(300)]),
 ])
 def test_ragged_and_odd_shapes(hidden, layers, nfeat, ncls, sizes):
     torch.manual_seed(hidden + layers)
