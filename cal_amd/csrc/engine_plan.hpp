@@ -249,12 +249,39 @@ __global__ void __launch_bounds__(512) k_att_fwd_graph(const int* __restrict__ g
             }
         }
     }
+    // Column sums over the row groups: every lane parks its 4 x VEC partials, ONE barrier (it also publishes pq_s), then one
+    // lane per (statistic, column) adds the RPB partials in group order -- as VEC rounds of "groups park, the G lanes of
+    // group 0 add RPB x 4 values each" this was 8 barriers and 256 serial fp64 LDS adds on 32 lanes with 480 lanes idle
+    {
+        constexpr int NC = G * VEC;                      // columns covered by one row group (>= H)
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {                      // (also the barrier that publishes pq_s)
-        const double v4[4] = {sc1[j], sc2[j], so1[j], so2[j]};
-        double o4[4];
-        block_col_sums<4>(v4, l * VEC + j, grp, RPB, G * VEC, cok, lds, o4);
-        if (grp == 0 && cok) { stc_sum.add(c + j, o4[0]); stc_sq.add(c + j, o4[1]); sto_sum.add(c + j, o4[2]); sto_sq.add(c + j, o4[3]); }
+        for (int j = 0; j < VEC; ++j) {
+            const int cs = l * VEC + j;
+            lds[(0 * RPB + grp) * NC + cs] = cok ? sc1[j] : 0.0;
+            lds[(1 * RPB + grp) * NC + cs] = cok ? sc2[j] : 0.0;
+            lds[(2 * RPB + grp) * NC + cs] = cok ? so1[j] : 0.0;
+            lds[(3 * RPB + grp) * NC + cs] = cok ? so2[j] : 0.0;
+        }
+        __syncthreads();
+        for (int o = t; o < 4 * NC; o += 512) {
+            const int q = o / NC, col = o % NC;
+            constexpr int CH = RPB < 16 ? RPB : 16;
+            double tot = 0.0;
+#pragma unroll
+            for (int k0 = 0; k0 < RPB; k0 += CH) {
+                double v[CH];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) v[k] = lds[(q * RPB + k0 + k) * NC + col];
+#pragma unroll
+                for (int k = 0; k < CH; ++k) tot += v[k];
+            }
+            if (col < H) {
+                if (q == 0) stc_sum.add(col, tot);
+                else if (q == 1) stc_sq.add(col, tot);
+                else if (q == 2) sto_sum.add(col, tot);
+                else sto_sq.add(col, tot);
+            }
+        }
     }
     if (rows <= 0 || rows > MAXR) return;
     // edge softmax (model.py:102-104) + weighted degrees.  The graph's by-source CSR rows (pointers, targets, edge ids) are
