@@ -130,10 +130,21 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     const bool colfix = 256 % K4 == 0;
     // a lane's <= 16 terms per column are summed in fp32 (fp64 conversions and adds issue at a fraction of the fp32 rate:
     // 192 of them per lane were most of this phase), everything across lanes in fp64
-    float sf[4] = {0.f, 0.f, 0.f, 0.f}, qf[4] = {0.f, 0.f, 0.f, 0.f};
+    // The fp32 part is SHIFTED by the lane's first value of the column (pivot): sum (v - p), sum (v - p)^2, un-shifted in fp64
+    // when the lane hands its partial over.  Plain fp32 sums of v^2 lose (mean / sigma)^2 ulps of the variance -- nothing at
+    // B = 128, but a batch of 2-3 graphs (the last batch of an epoch) has sigma << mean in most columns and its gradients
+    // came out 10-100 % off (tests/tools/fuzz_engine.py against the fp64 oracle).
+    float sf[4] = {0.f, 0.f, 0.f, 0.f}, qf[4] = {0.f, 0.f, 0.f, 0.f}, pvt[4] = {0.f, 0.f, 0.f, 0.f};
+    int nst = 0;
     auto add_stats = [&](const float4 v) {
-        sf[0] += v.x; qf[0] = fmaf(v.x, v.x, qf[0]); sf[1] += v.y; qf[1] = fmaf(v.y, v.y, qf[1]);
-        sf[2] += v.z; qf[2] = fmaf(v.z, v.z, qf[2]); sf[3] += v.w; qf[3] = fmaf(v.w, v.w, qf[3]);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            pvt[c] = nst == 0 ? vv[c] : pvt[c];
+            const float d = vv[c] - pvt[c];
+            sf[c] += d; qf[c] = fmaf(d, d, qf[c]);
+        }
+        ++nst;
     };
     // Loads of the kernel's first round.  The co head gathers xc[perm]: its perm entry is requested FIRST (loads return in
     // order: asked for behind the tiles it arrived after all of them, and the gather was a second full round, 6.9 us to
@@ -192,7 +203,11 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
             for (int b = part; b < B; b += np) add_stats(*reinterpret_cast<const float4*>(Xs + b * ld + 4 * cg));
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { red8[c][threadIdx.x] = (double)sf[c]; red8[4 + c][threadIdx.x] = (double)qf[c]; }
+        for (int c = 0; c < 4; ++c) {
+            const double P = (double)pvt[c], S0 = (double)sf[c], n0 = (double)nst;
+            red8[c][threadIdx.x] = S0 + n0 * P;
+            red8[4 + c][threadIdx.x] = (double)qf[c] + 2.0 * P * S0 + n0 * P * P;
+        }
         __syncthreads();
         if ((int)threadIdx.x < K) {
             const int k = threadIdx.x, g = k >> 2, c = k & 3;
@@ -221,7 +236,8 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     // y1[:, chunk] = relu(BN1(x) W1[chunk]^T + b1) on MFMA
     ro_f32x4 acc[4] = {};
     ro_mfma_rowk<true>(ntiles, K, Xs, ld, B, Ws, sc_s, sh_s, acc);
-    float s1 = 0.f, s2 = 0.f;                  // (16 terms per lane in fp32, see add_stats)
+    float s1 = 0.f, s2 = 0.f, pv2 = 0.f;       // (16 terms per lane in fp32, shifted by the lane's first value: see add_stats)
+    int n2 = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -229,10 +245,16 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
             const int b = (w + 4 * t) * 16 + lk * 4 + r;
             const float v = b < B ? fmaxf(acc[t][r] + bias1, 0.f) : 0.f;
             if (b < B) y1c[b * RO_CW + j] = v;
-            s1 += v; s2 = fmaf(v, v, s2);
+            pv2 = (b < B && n2 == 0) ? v : pv2;
+            const float d = b < B ? v - pv2 : 0.f;
+            n2 += b < B ? 1 : 0;
+            s1 += d; s2 = fmaf(d, d, s2);
         }
     RO_CLK(43);
-    red[0][threadIdx.x] = (double)s1; red[1][threadIdx.x] = (double)s2;
+    {
+        const double P = (double)pv2, S0 = (double)s1, n0 = (double)n2;
+        red[0][threadIdx.x] = S0 + n0 * P; red[1][threadIdx.x] = (double)s2 + 2.0 * P * S0 + n0 * P * P;
+    }
     __syncthreads();
     if (threadIdx.x < RO_CW) {                 // BN2 of the chunk (column-local: final values)
         double S = 0.0, Q = 0.0;
