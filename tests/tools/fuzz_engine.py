@@ -3,7 +3,8 @@
     python tests/tools/fuzz_engine.py [seconds] [seed]
 
 Draws (hidden, layers, features, classes, graph sizes) at random -- including sizes around the per-graph kernels' tile
-edges (1, 2, 31..33, 63..65, 127..129) -- runs one CausalGCN training step through
+edges (1, 2, 31..33, 63..65, 127..129) -- and a model variant (GCN / GAT / GIN backbone, add / cat readout, the two
+ablation flags), runs one training step through
 cal_engine_step and through oracle.cal_oracle.CpuTrainer and reports every case whose logits / losses / gradients differ
 farther from the same step in fp64 than 8x the fp32 oracle's own distance (floor 1e-4 of the tensor's scale).
 
@@ -42,31 +43,56 @@ def one_case(rng):
         if not big:
             n = min(n, 64)
         sizes.append(n)
-    if sum(sizes) > 12000:                       # keep the oracle in seconds
-        sizes = sizes[: max(1, 12000 // max(sizes))]
+    if sum(sizes) > 6000:                        # keep the oracle (fp32 + fp64 step) in seconds
+        sizes = sizes[: max(2, 6000 // max(sizes))]
     return hidden, layers, nfeat, ncls, sizes
 
 
-def run(case, seed):
+def one_variant(rng, hidden):
+    """(model, oracle / args keywords): every variant opts.get_model can build."""
+    name = rng.choice(["CausalGCN", "CausalGCN", "CausalGAT", "CausalGIN"])
+    if name == "CausalGAT" and hidden % 4:
+        name = "CausalGCN"
+    kw = {}
+    if rng.random() < 0.3:
+        kw["cat_or_add"] = "cat"
+    if rng.random() < 0.15:
+        kw["without_node_attention"] = True
+    if rng.random() < 0.15:
+        kw["without_edge_attention"] = True
+    return name, kw
+
+
+def run(case, seed, name="CausalGCN", kw=None):
+    from cal_amd import model as M
+    from cal_amd.engine import StepEngine
+    kw = dict(kw or {})
     hidden, layers, nfeat, ncls, sizes = case
     torch.manual_seed(seed)
     b = T._ragged_batch(seed, nfeat, sizes)
     bd = T._ragged_batch(seed, nfeat, sizes).to(T.DEV)
     b.y = b.y % ncls
     bd.y = bd.y % ncls
-    sd = O.init_state("CausalGCN", nfeat, ncls, hidden=hidden, layers=layers)
+    sd = O.init_state(name, nfeat, ncls, hidden=hidden, layers=layers, heads=4, cat_or_add=kw.get("cat_or_add", "add"))
     g = torch.Generator().manual_seed(7)
     for k in list(sd):
-        if k.endswith(".bias") or ("bn" in k and k.endswith(".weight")):
+        if k.endswith(".bias") or ("bn" in k and k.endswith(".weight")) or k.endswith(".nn.1.weight"):
             sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=g)
-    m, eng = T._engine({k: v.clone() for k, v in sd.items()}, T._args(hidden=hidden, layers=layers), nfeat, ncls)
+    m = getattr(M, name)(nfeat, ncls, T._args(hidden=hidden, layers=layers, **kw))
+    m.load_state_dict({k: v.clone() for k, v in sd.items()}, strict=name != "CausalGIN")
+    m = m.to(T.DEV).train()
+    if name == "CausalGAT":
+        for c in m.convs:
+            c.dropout = 0.0
+    eng = StepEngine(m, lr=1e-3)
+    okw = dict(layers=layers, heads=4, gat_dropout=0.0, **kw)
     B = len(sizes)
     perm = torch.randperm(B)
-    tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, ncls, lr=1e-3, layers=layers)
+    tr = O.CpuTrainer(name, {k: v.clone() for k, v in sd.items()}, ncls, lr=1e-3, **okw)
     loss, lc, lo, lco, logits = tr.step(b.x, b.edge_index, b.batch, b.y, perm=perm)
     # the same step in fp64: what separates a defect from the conditioning of the case (BatchNorm over 2 graphs, ...)
     sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    tr64 = O.CpuTrainer("CausalGCN", sd64, ncls, lr=1e-3, layers=layers)
+    tr64 = O.CpuTrainer(name, sd64, ncls, lr=1e-3, **okw)
     loss64, _, _, _, logits64 = tr64.step(b.x.double(), b.edge_index, b.batch, b.y, perm=perm)
     stats = eng.train_step(bd, perm.to(T.DEV), adam=False).cpu().numpy()
     eng.check_status()
@@ -87,6 +113,8 @@ def run(case, seed):
         gref = tr.sd[k].grad
         if gref is not None:
             judge("grad " + k, p.grad.cpu(), gref, tr64.sd[k].grad, 1e-4)
+        elif float(p.grad.abs().max()) != 0.0:       # switched-off attention MLP / conv_feat.bias: no gradient in the reference
+            bad.append("grad %s: %.3g where the reference has none" % (k, float(p.grad.abs().max())))
     return bad
 
 
@@ -98,16 +126,17 @@ def main():
     n = nbad = 0
     while time.time() - t0 < budget:
         case = one_case(rng)
+        name, kw = one_variant(rng, case[0])
         n += 1
         try:
-            bad = run(case, seed * 1000 + n)
+            bad = run(case, seed * 1000 + n, name, kw)
         except Exception as ex:                  # noqa: BLE001
             bad = ["exception: %r" % (ex,)]
         if bad:
             nbad += 1
             h, l, f, c, sizes = case
-            print("MISMATCH hidden=%d layers=%d nfeat=%d ncls=%d B=%d sizes[:12]=%s seed=%d: %s"
-                  % (h, l, f, c, len(sizes), sizes[:12], seed * 1000 + n, "; ".join(bad[:4])), flush=True)
+            print("MISMATCH %s %s hidden=%d layers=%d nfeat=%d ncls=%d B=%d sizes[:12]=%s seed=%d: %s"
+                  % (name, kw, h, l, f, c, len(sizes), sizes[:12], seed * 1000 + n, "; ".join(bad[:4])), flush=True)
     print("fuzz: %d cases, %d mismatching, %.0f s" % (n, nbad, time.time() - t0))
 
 
