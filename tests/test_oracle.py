@@ -228,3 +228,18 @@ def test_oracle_matches_committed_fixture(model, fname):
     assert tr.sd["conv_feat.bias"].grad is None          # gfn bias never gets a grad
     for k in tr.names:
         assert np.allclose(tr.sd[k].detach().numpy(), fx[f"post.{k}"], atol=1e-5), k
+
+
+@pytest.mark.parametrize("model", ["CausalGCN", "CausalGIN", "CausalGAT"])
+def test_ablation_flags_only_act_in_causalgcn(model):
+    """model.py:99-107 -- only CausalGCN.forward replaces the attentions by constant 0.5 masks when
+    --without_node_attention / --without_edge_attention are given; CausalGIN.forward (model.py:236-264) and
+    CausalGAT.forward (model.py:380-409) have no such branch, so the flags change nothing there."""
+    b = random_graph_batch(num_graphs=6, feat=5, seed=3)
+    sd = O.init_state(model, 5, 3, hidden=16, layers=2, heads=4, seed=1)
+    kw = dict(layers=2, heads=4, gat_dropout=0.0, training=False)
+    base = O.causal_forward(model, sd, b.x, b.edge_index, b.batch, **kw)
+    flagged = O.causal_forward(model, sd, b.x, b.edge_index, b.batch, without_node_attention=True,
+                               without_edge_attention=True, **kw)
+    same = all(torch.equal(a, c) for a, c in zip(base, flagged))
+    assert same == (model != "CausalGCN")
