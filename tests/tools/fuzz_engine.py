@@ -94,7 +94,7 @@ def run(case, seed, name="CausalGCN", kw=None):
     sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     tr64 = O.CpuTrainer(name, sd64, ncls, lr=1e-3, **okw)
     loss64, _, _, _, logits64 = tr64.step(b.x.double(), b.edge_index, b.batch, b.y, perm=perm)
-    stats = eng.train_step(bd, perm.to(T.DEV), adam=False).cpu().numpy()
+    stats = eng.train_step(bd, perm.to(T.DEV), adam=True).cpu().numpy()       # Adam inside k_finish (or k_adam behind it)
     eng.check_status()
     lp = eng.buffer("logp", 3 * B * ncls).view(3, B, ncls).cpu()
     bad = []
@@ -115,6 +115,12 @@ def run(case, seed, name="CausalGCN", kw=None):
             judge("grad " + k, p.grad.cpu(), gref, tr64.sd[k].grad, 1e-4)
         elif float(p.grad.abs().max()) != 0.0:       # switched-off attention MLP / conv_feat.bias: no gradient in the reference
             bad.append("grad %s: %.3g where the reference has none" % (k, float(p.grad.abs().max())))
+        if gref is not None:
+            # the Adam update, where the gradient is not numerically zero (lr * sign(g) of a 1e-9 gradient is rounding noise)
+            # and the engine's gradient agrees with the oracle's to begin with
+            mask = (gref.abs() > 1e-5) & ((p.grad.cpu() - gref).abs() <= 1e-5 + 1e-2 * gref.abs())
+            if mask.any() and not torch.allclose(p.detach().cpu()[mask], tr.sd[k].detach()[mask], atol=5e-5, rtol=1e-3):
+                bad.append("param %s after Adam: %.3g" % (k, (p.detach().cpu()[mask] - tr.sd[k].detach()[mask]).abs().max().item()))
     return bad
 
 
