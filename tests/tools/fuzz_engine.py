@@ -63,7 +63,9 @@ def one_variant(rng, hidden):
     return name, kw
 
 
-def run(case, seed, name="CausalGCN", kw=None):
+def run(case, seed, name="CausalGCN", kw=None, autograd=False):
+    """autograd: through the nn.Module surface (forward by the engine, the loss by torch, cal_engine_backward_from) instead
+    of the one-call training step."""
     from cal_amd import model as M
     from cal_amd.engine import StepEngine
     kw = dict(kw or {})
@@ -94,9 +96,17 @@ def run(case, seed, name="CausalGCN", kw=None):
     sd64 = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     tr64 = O.CpuTrainer(name, sd64, ncls, lr=1e-3, **okw)
     loss64, _, _, _, logits64 = tr64.step(b.x.double(), b.edge_index, b.batch, b.y, perm=perm)
-    stats = eng.train_step(bd, perm.to(T.DEV), adam=True).cpu().numpy()       # Adam inside k_finish (or k_adam behind it)
-    eng.check_status()
-    lp = eng.buffer("logp", 3 * B * ncls).view(3, B, ncls).cpu()
+    if autograd:
+        m.zero_grad()
+        out = m(bd, perm=perm.to(T.DEV))
+        loss_t = O.causal_loss(*out, bd.y, ncls)[0]
+        loss_t.backward()
+        stats = np.array([loss_t.detach().item()])
+        lp = torch.stack([o.detach().cpu() for o in out])
+    else:
+        stats = eng.train_step(bd, perm.to(T.DEV), adam=True).cpu().numpy()       # Adam inside k_finish (or k_adam behind it)
+        eng.check_status()
+        lp = eng.buffer("logp", 3 * B * ncls).view(3, B, ncls).cpu()
     bad = []
 
     def judge(name, mine, ref32, ref64, floor):
@@ -115,7 +125,7 @@ def run(case, seed, name="CausalGCN", kw=None):
             judge("grad " + k, p.grad.cpu(), gref, tr64.sd[k].grad, 1e-4)
         elif float(p.grad.abs().max()) != 0.0:       # switched-off attention MLP / conv_feat.bias: no gradient in the reference
             bad.append("grad %s: %.3g where the reference has none" % (k, float(p.grad.abs().max())))
-        if gref is not None:
+        if gref is not None and not autograd:
             # the Adam update, where the gradient is not numerically zero (lr * sign(g) of a 1e-9 gradient is rounding noise)
             # and the engine's gradient agrees with the oracle's to begin with
             mask = (gref.abs() > 1e-5) & ((p.grad.cpu() - gref).abs() <= 1e-5 + 1e-2 * gref.abs())
@@ -133,16 +143,17 @@ def main():
     while time.time() - t0 < budget:
         case = one_case(rng)
         name, kw = one_variant(rng, case[0])
+        ag = rng.random() < 0.4
         n += 1
         try:
-            bad = run(case, seed * 1000 + n, name, kw)
+            bad = run(case, seed * 1000 + n, name, kw, autograd=ag)
         except Exception as ex:                  # noqa: BLE001
             bad = ["exception: %r" % (ex,)]
         if bad:
             nbad += 1
             h, l, f, c, sizes = case
-            print("MISMATCH %s %s hidden=%d layers=%d nfeat=%d ncls=%d B=%d sizes[:12]=%s seed=%d: %s"
-                  % (name, kw, h, l, f, c, len(sizes), sizes[:12], seed * 1000 + n, "; ".join(bad[:4])), flush=True)
+            print("MISMATCH %s%s %s hidden=%d layers=%d nfeat=%d ncls=%d B=%d sizes[:12]=%s seed=%d: %s"
+                  % (name, " (module surface)" if ag else "", kw, h, l, f, c, len(sizes), sizes[:12], seed * 1000 + n, "; ".join(bad[:4])), flush=True)
     print("fuzz: %d cases, %d mismatching, %.0f s" % (n, nbad, time.time() - t0))
 
 
