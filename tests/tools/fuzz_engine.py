@@ -131,6 +131,17 @@ def run(case, seed, name="CausalGCN", kw=None, autograd=False):
             mask = (gref.abs() > 1e-5) & ((p.grad.cpu() - gref).abs() <= 1e-5 + 1e-2 * gref.abs())
             if mask.any() and not torch.allclose(p.detach().cpu()[mask], tr.sd[k].detach()[mask], atol=5e-5, rtol=1e-3):
                 bad.append("param %s after Adam: %.3g" % (k, (p.detach().cpu()[mask] - tr.sd[k].detach()[mask]).abs().max().item()))
+    if not autograd:
+        # eval-mode forward of the stepped model (running statistics, post-Adam parameters) against the oracle on the same state
+        m.eval()
+        sde = {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if not k.endswith(".eps")}
+        fkw = {k: v for k, v in okw.items() if k != "gat_dropout"}
+        ref = O.causal_forward(name, sde, b.x, b.edge_index, b.batch, perm=perm, training=False, **fkw)
+        out = eng.forward(bd, perm.to(T.DEV), training=False)
+        for hd, (r, t) in enumerate(zip(ref, out)):
+            d = (r.detach() - t.cpu()).abs().max().item()
+            if not d <= 2e-4 * max(1.0, r.abs().max().item()):
+                bad.append("eval logits head %d: %.3g (scale %.3g)" % (hd, d, r.abs().max().item()))
     return bad
 
 
