@@ -285,6 +285,11 @@ class StepEngine:
         N, E, B = x.size(0), ei.size(1), int(batch.num_graphs)
         if x.dtype != torch.float32 or x.size(1) != self.F:
             raise ValueError("features must be float32 [N, %d]" % self.F)
+        if (mode & 1) and (B == 1 or N == 1):
+            # the reference's error behaviour: torch.nn.BatchNorm1d in training mode refuses a single row (bn_feat over one
+            # node, model.py:90; the readout BatchNorms over one graph, model.py:127-131) -- same exception, same text
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                             % (torch.Size([1, self.F if N == 1 else self.H]),))
         if self.heads:
             self._sync_gat()
         self.reserve(N, E, B)

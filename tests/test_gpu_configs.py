@@ -296,3 +296,24 @@ def test_graph_cache_survives_id_reuse():
     b.ptr, b.edge_ptr, b.max_nodes, b.max_edges = b2.ptr, b2.edge_ptr, b2.max_nodes, b2.max_edges
     l1 = float(trn.step(b, perm=perm)[0].item())
     assert abs(l0 - losses[0][0]) < 1e-6 and abs(l1 - losses[1][0]) < 1e-6
+
+
+def test_single_graph_batch_in_training_raises_like_the_reference():
+    """torch.nn.BatchNorm1d refuses one row in training mode, so the reference's step on a batch of ONE graph raises
+    ValueError from the readout (model.py:127-131; the oracle does the same); the engine mirrors the error instead of
+    normalising a single value to beta.  Eval mode (running statistics) accepts the same batch."""
+    from cal_amd.data import Batch
+    gs = ref_graphs([3])
+    b, bd = Batch.from_data_list(gs), Batch.from_data_list(gs).to(DEV)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=2)
+    m, eng = _engine("CausalGCN", {k: v.clone() for k, v in sd.items()}, _args(hidden=64, layers=2))
+    perm = torch.zeros(1, dtype=torch.long)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=2).step(
+            b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel when training"):
+        eng.train_step(bd, perm.to(DEV))
+    ref = O.causal_forward("CausalGCN", sd, b.feat, b.edge_index, b.batch, perm=perm, training=False, layers=2)
+    out = eng.forward(bd, perm.to(DEV), training=False)
+    for r, t in zip(ref, out):
+        assert (r - t.cpu()).abs().max().item() < LOGIT_TOL
