@@ -118,30 +118,29 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
 template <int NT>
 __device__ __forceinline__ void randperm_block(int64_t* __restrict__ perm, int B, unsigned long long seed,
                                                unsigned long long* __restrict__ counter, unsigned long long* key, int* idx) {
-    int n = 1;
-    while (n < B) n <<= 1;
+    // perm = argsort of B hashed 63-bit keys, ties (probability ~B^2 / 2^64) by index so the result is always a permutation.
+    // Rank sort: element i goes to position #{j : key_j < key_i or (key_j == key_i and j < i)} -- B broadcast LDS reads and
+    // compares per element and ONE barrier, against log2(B)^2 / 2 barrier-separated exchange stages of a bitonic network
+    // (28 stages at B = 128, 45 at 512: the step's first kernel waited 5-19 us for this one workgroup).
     const unsigned long long cnt = *counter;
-    for (int i = threadIdx.x; i < n; i += NT) {
-        // padding keys sort to the end; real keys keep 63 random bits
-        key[i] = i < B ? (splitmix64(splitmix64(seed ^ (cnt * 0xD1342543DE82EF95ull)) + (unsigned long long)i) >> 1)
-                       : 0xFFFFFFFFFFFFFFFFull;
-        idx[i] = i;
+    for (int i = threadIdx.x; i < B; i += NT)
+        key[i] = splitmix64(splitmix64(seed ^ (cnt * 0xD1342543DE82EF95ull)) + (unsigned long long)i) >> 1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += NT) {
+        const unsigned long long k = key[i];
+        int r = 0;
+        int j = 0;
+        for (; j + 8 <= B; j += 8) {
+            unsigned long long kj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kj[u] = key[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r += (kj[u] < k || (kj[u] == k && j + u < i)) ? 1 : 0;
+        }
+        for (; j < B; ++j) { const unsigned long long kk = key[j]; r += (kk < k || (kk == k && j < i)) ? 1 : 0; }
+        idx[r] = i;
     }
     __syncthreads();
-    for (int k = 2; k <= n; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n; i += NT) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const bool up = (i & k) == 0;
-                    const unsigned long long a = key[i], b = key[p];
-                    // ties (probability ~B^2 / 2^64) broken by index so the result is always a permutation
-                    const bool gt = a > b || (a == b && idx[i] > idx[p]);
-                    if (gt == up) { key[i] = b; key[p] = a; const int t = idx[i]; idx[i] = idx[p]; idx[p] = t; }
-                }
-            }
-            __syncthreads();
-        }
     for (int i = threadIdx.x; i < B; i += NT) perm[i] = idx[i];
     if (threadIdx.x == 0) *counter = cnt + 1;
 }
