@@ -106,7 +106,7 @@ template <> struct Vec<1> {
 };
 
 // Random-intervention permutation (model.py:147-152, `random.shuffle(range(num))`) drawn on the device: graph b gets
-// the key splitmix64(seed, *counter, b), the permutation is the argsort of the keys (bitonic network in LDS, one
+// the key splitmix64(seed, *counter, b), the permutation is the argsort of the keys (rank sort in LDS, one
 // workgroup of NT threads, B <= CAP); *counter is advanced, so a replayed hipGraph draws a fresh permutation every
 // step.  Shared by cal_randperm (collate.hip, stand-alone) and the step engine's first kernel.
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
