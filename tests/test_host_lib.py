@@ -170,3 +170,31 @@ def test_config0_cpu_plumbing_train_causal_syn():
     h = history[0]
     assert all(np.isfinite(h[k]) for k in ("loss", "loss_c", "loss_o", "loss_co", "train_acc_o", "val_acc_o", "test_acc_o"))
     assert abs(h["loss"] - (0.5 * h["loss_c"] + h["loss_o"] + 0.5 * h["loss_co"])) < 1e-5
+
+
+_SWEEP = [
+    (99001, "CausalGCN", {}, (128, 3, 10, 10, [3, 99, 23, 126, 129])),
+    (99010, "CausalGCN", {"cat_or_add": "cat"}, (16, 3, 64, 10, [50, 64, 1, 2, 15])),
+    (99012, "CausalGAT", {"cat_or_add": "cat"}, (80, 4, 1, 2, [44, 37, 64, 32, 64, 64, 51, 48, 51, 64, 1, 15, 29, 11, 1, 15])),
+    (99022, "CausalGCN", {}, (48, 1, 139, 3, [25, 64, 58, 7, 29, 15, 50, 1, 32, 38, 20, 3, 15, 42, 38, 25])),
+    (99041, "CausalGCN", {}, (32, 2, 139, 4, [11, 38, 53, 10, 62])),
+    (99043, "CausalGIN", {}, (48, 0, 1, 3, [36, 32, 31, 57, 8, 39, 7, 45, 47, 3, 19, 15, 56, 2, 1, 47, 52])),
+    (99047, "CausalGCN", {"without_edge_attention": True},
+     (64, 3, 64, 4, [2, 26, 13, 10, 39, 35, 42, 64, 46, 63, 11, 21, 54, 36, 40, 47, 63])),
+    (99049, "CausalGAT", {}, (64, 2, 10, 10, [7, 32, 29, 63, 18])),
+    (99054, "CausalGIN", {}, (80, 3, 10, 3, [10, 64, 44, 53, 1, 1, 15, 34, 12, 64, 33, 32, 42, 2, 36, 29])),
+    (99055, "CausalGAT", {"without_node_attention": True}, (128, 3, 37, 2, [32, 23, 3, 43, 21])),
+]
+
+
+@pytest.mark.parametrize("seed,name,kw,case", _SWEEP, ids=[str(s[0]) for s in _SWEEP])
+def test_random_shape_sweep_cases_on_the_host_library(seed, name, kw, case):
+    """Ten draws of tests/tools/fuzz_host.py kept as fixed cases: (hidden, layers, features, classes, ragged graph sizes
+    with single nodes / edgeless graphs / stars / self loops) x model variant, one forward + external loss + backward
+    through libcalhost.so, judged against the oracle's fp64 step (8x the fp32 oracle's own distance, floor 1e-4 of scale).
+    The ablation flags on a GAT / GIN model change nothing, as in the reference (model.py:236-264,380-409)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import fuzz_host
+    assert fuzz_host.run(case, seed, name, kw) == []
