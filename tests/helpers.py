@@ -43,3 +43,20 @@ def random_graph_batch(num_graphs=5, n_lo=3, n_hi=12, p=0.3, feat=6, seed=0,
         ds.append(Data(x=torch.randn(n, feat, generator=g, dtype=dtype), edge_index=ei,
                        y=torch.randint(0, 4, (1,), generator=g)))
     return Batch.from_data_list(ds)
+
+
+# Ten draws of tests/tools/fuzz_host.py / fuzz_engine.py kept as fixed cases: (seed, model, variant keywords,
+# (hidden, layers, features, classes, graph sizes))
+SWEEP_CASES = [
+    (99001, "CausalGCN", {}, (128, 3, 10, 10, [3, 99, 23, 126, 129])),
+    (99010, "CausalGCN", {"cat_or_add": "cat"}, (16, 3, 64, 10, [50, 64, 1, 2, 15])),
+    (99012, "CausalGAT", {"cat_or_add": "cat"}, (80, 4, 1, 2, [44, 37, 64, 32, 64, 64, 51, 48, 51, 64, 1, 15, 29, 11, 1, 15])),
+    (99022, "CausalGCN", {}, (48, 1, 139, 3, [25, 64, 58, 7, 29, 15, 50, 1, 32, 38, 20, 3, 15, 42, 38, 25])),
+    (99041, "CausalGCN", {}, (32, 2, 139, 4, [11, 38, 53, 10, 62])),
+    (99043, "CausalGIN", {}, (48, 0, 1, 3, [36, 32, 31, 57, 8, 39, 7, 45, 47, 3, 19, 15, 56, 2, 1, 47, 52])),
+    (99047, "CausalGCN", {"without_edge_attention": True},
+     (64, 3, 64, 4, [2, 26, 13, 10, 39, 35, 42, 64, 46, 63, 11, 21, 54, 36, 40, 47, 63])),
+    (99049, "CausalGAT", {}, (64, 2, 10, 10, [7, 32, 29, 63, 18])),
+    (99054, "CausalGIN", {}, (80, 3, 10, 3, [10, 64, 44, 53, 1, 1, 15, 34, 12, 64, 33, 32, 42, 2, 36, 29])),
+    (99055, "CausalGAT", {"without_node_attention": True}, (128, 3, 37, 2, [32, 23, 3, 43, 21])),
+]

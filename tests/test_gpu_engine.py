@@ -629,3 +629,20 @@ def test_batches_of_two_or_three_graphs_track_the_fp64_step(seed, case):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import fuzz_engine
     assert fuzz_engine.run(case, seed) == []
+
+
+def _sweep_cases():
+    from tests.helpers import SWEEP_CASES
+    # (99012: a GAT backbone with head width 20 -- not an engine shape, StepEngine says so and the trainer takes the operator path)
+    return [c for c in SWEEP_CASES if c[0] != 99012]
+
+
+@pytest.mark.parametrize("seed,name,kw,case", _sweep_cases(), ids=[str(c[0]) for c in _sweep_cases()])
+def test_random_shape_sweep_cases_on_the_engine(seed, name, kw, case):
+    """The ten fixed draws of the random-shape sweep (tests/helpers.py: every backbone, add / cat readout, ablation flags,
+    ragged sizes up to 129 nodes) through cal_engine_step incl. the in-kernel Adam update and the eval-mode forward of the
+    stepped model, judged against the oracle's fp64 step (tests/tools/fuzz_engine.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import fuzz_engine
+    assert fuzz_engine.run(case, seed, name, kw) == []
