@@ -337,7 +337,77 @@ def end_to_end(wl, margs, steps=60):
         dt = time.perf_counter() - t0
         res[kind] = {"graphs_per_s": n_graphs / dt, "ms_per_step": 1e3 * dt / n_steps}
     res["note"] = "epochs over a 2048-graph dataset, shuffled, eager engine step; includes batch assembly"
+    try:
+        res["reference_loop"] = reference_loop(wl, margs, gs, max(steps, 160))
+    except Exception as exc:
+        res["reference_loop"] = {"error": repr(exc)}
     return res
+
+
+def reference_loop(wl, margs, gs, steps=60):
+    """The loop the reference's entry scripts run, through the reference-named surface: ``train_causal_epoch(model, optimizer,
+    loader, device, args)`` (train_causal.py:162-200) with an ``Adam`` object and a cosine schedule stepped once per epoch
+    (train_causal.py:21-29), shuffled epochs over the same 2048-graph dataset.  Three feeds:
+      fused_device_loader  what ``train_causal_syn`` builds on a GPU: device-resident dataset + one-call fused step
+      fused_host_loader    a caller's own host DataLoader (Python collate + H2D per batch) in front of the fused step
+      module_surface       ``--no_fused_step``: model(data) -> torch loss -> backward -> optimizer.step(), statement by
+                           statement on the nn.Module surface (what a foreign loop gets), with a host read-back of the
+                           loss every iteration like train_causal.py:186-191"""
+    import copy
+    from torch.optim.lr_scheduler import CosineAnnealingLR
+    from cal_amd import model as M
+    from cal_amd.data import DataLoader
+    from cal_amd.device_data import DeviceDataset, DeviceLoader
+    from cal_amd.optim import EngineAdam
+    from cal_amd.train_causal import causal_loss, train_causal_epoch
+    dev = torch.device("cuda")
+    out = {}
+    for kind in ("fused_device_loader", "fused_host_loader", "module_surface"):
+        args = copy.copy(margs)
+        args.no_fused_step = kind == "module_surface"
+        torch.manual_seed(1)
+        random.seed(1)
+        model = getattr(M, wl["model"])(wl["nfeat"], wl["ncls"], args).cuda()
+        opt = EngineAdam(model.parameters(), lr=1e-3)
+        sched = CosineAnnealingLR(opt, T_max=100, eta_min=1e-6)
+        if kind == "fused_device_loader":
+            loader = DeviceLoader(DeviceDataset(gs), wl["batch"], shuffle=True)
+        else:
+            loader = DataLoader(gs, wl["batch"], shuffle=True)
+        per_epoch = len(loader)
+        n_epochs = max(1, -(-steps // per_epoch)) if kind != "module_surface" else max(1, steps // (2 * per_epoch))
+        if kind == "module_surface":
+            def epoch():
+                model.train()
+                tot = 0.0
+                for data in loader:
+                    opt.zero_grad()
+                    data = data.to(dev)
+                    c, o, co = model(data, eval_random=args.with_random)
+                    loss, lc, lo, lco = causal_loss(c, o, co, data.y, model.num_classes, args)
+                    loss.backward()
+                    tot += loss.item() * data.num_graphs            # the reference's per-iteration host sync
+                    opt.step()
+                return tot / len(gs)
+        else:
+            def epoch():
+                return train_causal_epoch(model, opt, loader, dev, args)[0]
+        epoch()                                                   # warm-up epoch (workspace sizing, engine creation)
+        sched.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(n_epochs):
+            last = epoch()
+            sched.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_steps = n_epochs * per_epoch
+        out[kind] = {"graphs_per_s": n_epochs * len(gs) / dt, "ms_per_step": 1e3 * dt / n_steps, "steps": n_steps,
+                     "epoch_loss": float(last), "fused": bool(getattr(opt, "_cal_binding", None) is not None and kind != "module_surface")}
+    out["note"] = ("train_causal_epoch (train_causal.py:162-200) over shuffled epochs of a 2048-graph dataset, Adam object + "
+                   "cosine schedule; intervention permutation from Python's RNG on the host as in model.py:147-152")
+    return out
 
 
 def main():

@@ -1867,6 +1867,14 @@ CAL_EXPORT int cal_engine_set_perm_rng(void* h, uint64_t seed, uint64_t* counter
     e->perm_seed = seed; e->perm_ctr = (unsigned long long*)counter;
     return 0;
 }
+// Adam hyper-parameters after cal_engine_bind (an optimizer object's param group may change them between steps:
+// torch.optim.Adam(params, lr, betas, eps, weight_decay), train_causal.py:21,76); the learning rate is the bound device float
+CAL_EXPORT int cal_engine_set_adam(void* h, float beta1, float beta2, float eps, float weight_decay) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e != nullptr && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f && weight_decay >= 0.f, "bad arguments");
+    e->beta1 = beta1; e->beta2 = beta2; e->eps = eps; e->wd = weight_decay;
+    return 0;
+}
 // Factor applied to the bound gradient buffer inside the Adam update (1/world_size turns the all-reduced SUM of the
 // replicas' gradients into the mean, train_causal.py:187-192 semantics per replica); default 1
 CAL_EXPORT int cal_engine_set_grad_scale(void* h, float scale) {

@@ -189,6 +189,12 @@ class StepEngine:
         self._bounds = (0, 0)
         self._ptrs = (0, 0)
         self.wc, self.wo, self.wco = float(getattr(a, "c", 0.5)), float(getattr(a, "o", 1.0)), float(getattr(a, "co", 0.5))
+        from .optim import register_engine
+        register_engine(self)
+
+    def set_adam(self, beta1: float, beta2: float, eps: float, weight_decay: float):
+        """Adam hyper-parameters of an attached optimizer object (cal_amd/optim.py); the learning rate is ``self.lr``."""
+        _lib.call("cal_engine_set_adam", self._h, float(beta1), float(beta2), float(eps), float(weight_decay))
 
     def __del__(self):
         try:
@@ -324,6 +330,13 @@ class StepEngine:
         lp = self.buffer("logp", 3 * B * self.C).view(3, B, self.C)
         return lp[0], lp[1], lp[2]
 
+    def logp_copy(self):
+        """The latest forward's three [B, C] log-prob outputs as views of ONE private copy (the workspace buffer is
+        overwritten by the next step; a caller may keep what a forward returned)."""
+        B = self._last_B
+        lp = self.buffer("logp", 3 * B * self.C).clone().view(3, B, self.C)
+        return lp[0], lp[1], lp[2]
+
     def train_step(self, batch, perm=None, adam: bool = True, tick: bool = False, draw_perm: bool = False):
         """forward + loss + backward (+ Adam); returns the device stats tensor
         [loss, c_loss, o_loss, co_loss, correct_o] (a view into the workspace).  ``tick`` (with ``adam=False``):
@@ -361,11 +374,11 @@ class _EngineAutograd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng: "StepEngine", batch, perm, anchor):
-        c, o, co = eng.forward(batch, perm, training=True)
+        eng.forward(batch, perm, training=True)
         ctx.eng, ctx.batch = eng, batch
         eng._fwd_token = getattr(eng, "_fwd_token", 0) + 1
         ctx.token = eng._fwd_token
-        return c.clone(), o.clone(), co.clone()
+        return eng.logp_copy()
 
     @staticmethod
     def backward(ctx, gc, go, gco):

@@ -77,6 +77,12 @@ class _CausalBase(torch.nn.Module):
     #: behind this same nn.Module / autograd surface.  Set False for the operator-level path.
     use_engine = os.environ.get("CAL_AMD_ENGINE", "1") != "0"
 
+    def engine(self):
+        """The model's StepEngine (created on first use) when its parameters are on the GPU and the engine covers this
+        variant; else ``None``."""
+        p0 = next(self.parameters())
+        return self._engine_for(p0)
+
     def _engine_for(self, x):
         from . import engine as eng_mod
         if not (self.use_engine and x.is_cuda and isinstance(self, (CausalGCN, CausalGAT, CausalGIN)) and eng_mod.supported(self)):
@@ -102,7 +108,8 @@ class _CausalBase(torch.nn.Module):
             perm = perm.to(x.device)
             if self.training and torch.is_grad_enabled():
                 return engine_forward_autograd(eng, data, perm)
-            return tuple(t.clone() for t in eng.forward(data, perm, training=self.training))
+            eng.forward(data, perm, training=self.training)
+            return eng.logp_copy()
         edge_index = data.edge_index
         plan = plan_of(data)
         x = self.bn_feat(x)

@@ -6,6 +6,18 @@ Differences that do not change results: the five ``.item()`` host syncs per
 iteration (train_causal.py:186-191) are replaced by on-device accumulators read
 once per epoch, and ``CosineAnnealingLR`` is built without the ``verbose``
 keyword current torch rejects.
+
+On a GPU the loop body of ``train_causal_epoch`` -- forward, the 3-term loss,
+backward and the optimizer step (train_causal.py:173-192) -- is ONE
+``cal_engine_step`` call per mini-batch when the model is engine-backed and the
+optimizer is a plain Adam over its parameters (``cal_amd.optim.bind``): same
+signature, same returned tuple, the optimizer object and any LR scheduler keep
+working (its moments are views of the engine's, its ``step`` counters are kept in
+sync).  Anything else -- another optimizer, a ``grad_sync`` hook, a CPU model, a
+model variant the engine does not cover -- runs the statement-by-statement loop.
+``train_causal_syn`` / ``train_causal_real`` feed it from a device-resident
+dataset with on-GPU collate (``cal_amd.device_data``) instead of the per-graph
+Python collate.
 """
 from __future__ import annotations
 
@@ -51,26 +63,106 @@ def causal_loss(c_logs, o_logs, co_logs, y, num_classes, args):
     return loss, c_loss, o_loss, co_loss
 
 
+def _loader(dataset, batch_size, shuffle, device):
+    """``DataLoader(dataset, batch_size, shuffle)`` (train_causal.py:13-15,72-73): on a GPU the dataset is made
+    device-resident once and every mini-batch is assembled by one collate kernel (bit-identical batches); the host
+    ``DataLoader`` elsewhere."""
+    if device.type == "cuda" and len(dataset) > 0:
+        from .device_data import DeviceDataset, DeviceLoader
+        graphs = dataset if isinstance(dataset, (list, tuple)) else [dataset[i] for i in range(len(dataset))]
+        return DeviceLoader(DeviceDataset(graphs, device=device), batch_size, shuffle=shuffle)
+    return DataLoader(dataset, batch_size, shuffle=shuffle)
+
+
+class _PermStage:
+    """Pinned ring for the per-step intervention permutation (a pageable H2D copy would block the host on the GPU)."""
+
+    def __init__(self, device, n=1024, slots=8):
+        self.device = device
+        self.host = [torch.empty(n, dtype=torch.long).pin_memory() for _ in range(slots)]
+        self.dev = [torch.empty(n, dtype=torch.long, device=device) for _ in range(slots)]
+        self.ev = [None] * slots
+        self.i = 0
+
+    def put(self, perm):
+        n = perm.numel()
+        if n > self.host[0].numel():
+            return perm.to(self.device)
+        k, self.i = self.i, (self.i + 1) % len(self.host)
+        if self.ev[k] is not None:
+            self.ev[k].synchronize()
+        self.host[k][:n].copy_(perm)
+        d = self.dev[k][:n]
+        d.copy_(self.host[k][:n], non_blocking=True)
+        self.ev[k] = torch.cuda.Event()
+        self.ev[k].record()
+        return d
+
+
+def _fused_epoch(model, binding, loader, device, args):
+    """The loop of train_causal.py:171-192 with its body as one engine call per mini-batch (module docstring)."""
+    eng = binding.engine
+    eng.wc, eng.wo, eng.wco = float(args.c), float(args.o), float(args.co)
+    binding.resync()
+    acc = torch.zeros(5, dtype=torch.float64, device=device)      # loss, c, o, co (each x graphs), correct
+    weights = {}
+    device_perm = bool(getattr(args, "device_perm", False))       # not a reference flag: draw the permutation on the GPU
+    if device_perm and getattr(eng, "_perm_counter", None) is None:
+        import random
+        eng.set_perm_rng(random.getrandbits(63), torch.zeros(1, dtype=torch.int64, device=device))
+    stage = getattr(eng, "_perm_stage", None)
+    if stage is None:
+        stage = eng._perm_stage = _PermStage(device)
+    try:
+        for data in loader:
+            data = data.to(device)
+            n = num_graphs(data)
+            shuffles = bool(args.with_random and (model.with_random if model._gate_on_with_random else True))
+            if device_perm and shuffles and n <= 1024:
+                stats = eng.train_step(data, None, adam=True, draw_perm=True)
+            else:
+                # model.py:147-152: Python's RNG on the host, exactly the reference's stream
+                perm = stage.put(model.intervention_index(n, args.with_random))
+                stats = eng.train_step(data, perm, adam=True)
+            binding.stepped()
+            w = weights.get(n)
+            if w is None:
+                w = weights[n] = torch.tensor([n, n, n, n, 1], dtype=torch.float64, device=device)
+            acc.addcmul_(stats.to(torch.float64), w)
+    finally:
+        binding.flush()
+    return acc
+
+
 def train_causal_epoch(model, optimizer, loader, device, args, grad_sync=None):
     """train_causal.py:162-200.  ``grad_sync`` (optional callable) runs between
     backward and the optimizer step -- the data-parallel gradient all-reduce."""
     model.train()
-    acc = torch.zeros(5, dtype=torch.float64, device=device)   # loss, c, o, co, correct
-    for it, data in enumerate(loader):
-        optimizer.zero_grad()
-        data = data.to(device)
-        c_logs, o_logs, co_logs = model(data, eval_random=args.with_random)
-        loss, c_loss, o_loss, co_loss = causal_loss(c_logs, o_logs, co_logs, data.y, model.num_classes, args)
-        pred_o = o_logs.max(1)[1]
-        loss.backward()
-        if grad_sync is not None:
-            grad_sync()
-        n = num_graphs(data)
-        with torch.no_grad():
-            acc += torch.stack([loss.detach() * n, c_loss.detach() * n, o_loss.detach() * n,
-                                co_loss.detach() * n,
-                                pred_o.eq(data.y.view(-1)).sum().to(loss.dtype)]).to(torch.float64)
-        optimizer.step()
+    device = torch.device(device)
+    binding = None
+    if grad_sync is None and device.type == "cuda" and getattr(model, "use_engine", False) \
+            and not getattr(args, "no_fused_step", False):
+        from .optim import bind
+        binding = bind(optimizer, model)
+    if binding is not None:
+        acc = _fused_epoch(model, binding, loader, device, args)
+    else:
+        acc = torch.zeros(5, dtype=torch.float64, device=device)   # loss, c, o, co, correct
+        for it, data in enumerate(loader):
+            optimizer.zero_grad()
+            data = data.to(device)
+            c_logs, o_logs, co_logs = model(data, eval_random=args.with_random)
+            loss, c_loss, o_loss, co_loss = causal_loss(c_logs, o_logs, co_logs, data.y, model.num_classes, args)
+            pred_o = o_logs.max(1)[1]
+            loss.backward()
+            if grad_sync is not None:
+                grad_sync()
+            n = num_graphs(data)
+            with torch.no_grad():
+                acc += torch.stack([loss.detach() * n, c_loss.detach() * n, o_loss.detach() * n,
+                                    co_loss.detach() * n,
+                                    pred_o.eq(data.y.view(-1)).sum().to(loss.dtype)]).to(torch.float64)
+            optimizer.step()
     num = len(loader.dataset)
     total_loss, total_loss_c, total_loss_o, total_loss_co, correct_o = (acc / num).tolist()
     _check_engine(model)
@@ -95,41 +187,42 @@ def eval_acc_causal(model, loader, device, args):
     return acc_co, acc_c, acc_o
 
 
+_SYN_EPOCH_LINE = ("BIAS:[{:.2f}] | Model:[{}] Epoch:[{}/{}] Loss:[{:.4f}={:.4f}+{:.4f}+{:.4f}] Train:[{:.2f}] val:[{:.2f}] "
+                   "Test:[{:.2f}] | Update Test:[co:{:.2f},c:{:.2f},o:{:.2f}] at Epoch:[{}] | lr:{:.6f}")
+_SYN_FINAL_LINE = "syd: BIAS:[{:.2f}] | Val acc:[{:.2f}] Test acc:[co:{:.2f},c:{:.2f},o:{:.2f}] at epoch:[{}]"
+
+
 def train_causal_syn(train_set, val_set, test_set, model_func=None, args=None, log=print):
-    """train_causal.py:11-61."""
+    """train_causal.py:11-61: Adam + cosine schedule over ``args.epochs`` epochs of the SPMotif split, one training pass and
+    an evaluation of the validation and test sets per epoch; the reported test accuracies are those of the epoch with the
+    best ``val_acc_o`` so far (model selection on the validation set, train_causal.py:29-35).  The two log lines are the
+    reference's, character for character (they are what a user of main_syn.py greps).  Returns (model, per-epoch history)."""
+    from .optim import EngineAdam
     device = _device(args)
-    train_loader = DataLoader(train_set, args.batch_size, shuffle=True)
-    val_loader = DataLoader(val_set, args.batch_size, shuffle=False)
-    test_loader = DataLoader(test_set, args.batch_size, shuffle=False)
+    loaders = {name: _loader(ds, args.batch_size, name == "train", device)
+               for name, ds in (("train", train_set), ("val", val_set), ("test", test_set))}
     if args.feature_dim == -1:
-        args.feature_dim = args.max_degree
+        args.feature_dim = args.max_degree                                      # train_causal.py:17-18
     model = model_func(args.feature_dim, args.num_classes).to(device)
-    optimizer = Adam(model.parameters(), lr=args.lr)
-    lr_scheduler = CosineAnnealingLR(optimizer, T_max=args.epochs, eta_min=args.min_lr, last_epoch=-1)
-    best_val_acc, update_test_acc_co, update_test_acc_c, update_test_acc_o, update_epoch = 0, 0, 0, 0, 0
+    optimizer = EngineAdam(model.parameters(), lr=args.lr)
+    schedule = CosineAnnealingLR(optimizer, T_max=args.epochs, eta_min=args.min_lr, last_epoch=-1)
+    picked = dict(val=0.0, co=0.0, c=0.0, o=0.0, epoch=0)                        # test accuracies at the best validation epoch
     history = []
     for epoch in range(1, args.epochs + 1):
-        train_loss, loss_c, loss_o, loss_co, train_acc_o = train_causal_epoch(model, optimizer, train_loader, device, args)
-        val_acc_co, val_acc_c, val_acc_o = eval_acc_causal(model, val_loader, device, args)
-        test_acc_co, test_acc_c, test_acc_o = eval_acc_causal(model, test_loader, device, args)
-        lr_scheduler.step()
-        if val_acc_o > best_val_acc:
-            best_val_acc = val_acc_o
-            update_test_acc_co = test_acc_co
-            update_test_acc_c = test_acc_c
-            update_test_acc_o = test_acc_o
-            update_epoch = epoch
-        history.append(dict(epoch=epoch, loss=train_loss, loss_c=loss_c, loss_o=loss_o, loss_co=loss_co,
+        loss, loss_c, loss_o, loss_co, train_acc_o = train_causal_epoch(model, optimizer, loaders["train"], device, args)
+        _, _, val_acc_o = eval_acc_causal(model, loaders["val"], device, args)
+        test_acc_co, test_acc_c, test_acc_o = eval_acc_causal(model, loaders["test"], device, args)
+        schedule.step()
+        if val_acc_o > picked["val"]:
+            picked = dict(val=val_acc_o, co=test_acc_co, c=test_acc_c, o=test_acc_o, epoch=epoch)
+        history.append(dict(epoch=epoch, loss=loss, loss_c=loss_c, loss_o=loss_o, loss_co=loss_co,
                             train_acc_o=train_acc_o, val_acc_o=val_acc_o, test_acc_o=test_acc_o))
-        log("BIAS:[{:.2f}] | Model:[{}] Epoch:[{}/{}] Loss:[{:.4f}={:.4f}+{:.4f}+{:.4f}] Train:[{:.2f}] val:[{:.2f}] "
-            "Test:[{:.2f}] | Update Test:[co:{:.2f},c:{:.2f},o:{:.2f}] at Epoch:[{}] | lr:{:.6f}".format(
-                args.bias, args.model, epoch, args.epochs, train_loss, loss_c, loss_o, loss_co,
-                train_acc_o * 100, val_acc_o * 100, test_acc_o * 100, update_test_acc_co * 100,
-                update_test_acc_c * 100, update_test_acc_o * 100, update_epoch,
-                optimizer.param_groups[0]["lr"]))
-    log("syd: BIAS:[{:.2f}] | Val acc:[{:.2f}] Test acc:[co:{:.2f},c:{:.2f},o:{:.2f}] at epoch:[{}]".format(
-        args.bias, val_acc_o * 100, update_test_acc_co * 100, update_test_acc_c * 100,
-        update_test_acc_o * 100, update_epoch))
+        log(_SYN_EPOCH_LINE.format(args.bias, args.model, epoch, args.epochs, loss, loss_c, loss_o, loss_co,
+                                   train_acc_o * 100, val_acc_o * 100, test_acc_o * 100, picked["co"] * 100,
+                                   picked["c"] * 100, picked["o"] * 100, picked["epoch"],
+                                   optimizer.param_groups[0]["lr"]))
+    log(_SYN_FINAL_LINE.format(args.bias, picked["val"] * 100, picked["co"] * 100, picked["c"] * 100, picked["o"] * 100,
+                               picked["epoch"]))
     return model, history
 
 
@@ -139,16 +232,17 @@ def train_causal_real(dataset=None, model_func=None, args=None, log=print):
     accuracy is taken at the epoch whose fold-mean test accuracy is highest (``test_acc`` / ``test_acc_c``) and at the
     one whose fold-mean ``test_acc_o`` is highest (``test_acc_o``), mean and std over folds.
     Returns a dict with those figures and the per-fold / per-epoch tensors."""
+    from .optim import EngineAdam
     from .tu import k_fold
     device = _device(args)
     train_accs, test_accs, test_accs_c, test_accs_o = [], [], [], []
     random_guess = 1.0 / dataset.num_classes
     for fold, (train_idx, test_idx, val_idx) in enumerate(zip(*k_fold(dataset, args.folds, args.epoch_select))):
         best_test_acc, best_epoch, best_test_acc_c, best_test_acc_o = 0, 0, 0, 0
-        train_loader = DataLoader(dataset[train_idx], args.batch_size, shuffle=True)
-        test_loader = DataLoader(dataset[test_idx], args.batch_size, shuffle=False)
+        train_loader = _loader(dataset[train_idx], args.batch_size, True, device)
+        test_loader = _loader(dataset[test_idx], args.batch_size, False, device)
         model = model_func(dataset.num_features, dataset.num_classes).to(device)
-        optimizer = Adam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+        optimizer = EngineAdam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
         for epoch in range(1, args.epochs + 1):
             train_loss, loss_c, loss_o, loss_co, train_acc = train_causal_epoch(model, optimizer, train_loader, device, args)
             test_acc, test_acc_c, test_acc_o = eval_acc_causal(model, test_loader, device, args)

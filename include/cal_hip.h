@@ -174,6 +174,9 @@ CAL_API int cal_engine_step(void* engine, const float* x0, const int64_t* edge_i
                             int64_t E, int64_t B, float wc, float wo, float wco, int mode,
                             void* stream);
 CAL_API int cal_engine_adam(void* engine, void* stream);
+/* torch.optim.Adam's betas / eps / weight_decay (train_causal.py:21,76) after the bind, e.g. when an optimizer object that
+ * owns them is attached to an engine-backed model (cal_amd/optim.py); the learning rate is the bound device float `lr` */
+CAL_API int cal_engine_set_adam(void* engine, float beta1, float beta2, float eps, float weight_decay);
 /* model.py:147-152 on the device, inside the step (mode bit 16): permutation keyed by (seed, *counter), as cal_randperm draws it;
  * the device counter advances once per drawing step, so a replayed hipGraph draws a fresh permutation.  B <= 1024. */
 CAL_API int cal_engine_set_perm_rng(void* engine, uint64_t seed, uint64_t* counter);
