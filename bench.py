@@ -228,15 +228,24 @@ def engine_roofline(trainer, batches, workload, iters=20):
     roof = {}
     # HBM-side traffic per launch from the PMC passes (separate rocprofv3 --pmc runs of this command;
     # committed under profiles/): null when the summary is absent
-    pmc = {}
+    from cal_amd.build import kernel_source_sha
+    src_sha = kernel_source_sha()
+    pmc, pmc_file, pmc_stale = {}, None, None
     for cand in ("pmc_traffic_%s.json" % workload, "pmc_traffic.json"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
             if pmc.get("workload", HEADLINE) == workload:
+                pmc_file = "profiles/" + cand
                 break
             pmc = {}                                       # the counters were collected on another workload
         except Exception:
             pmc = {}
+    if pmc and pmc.get("kernel_source_sha") != src_sha:
+        # the PMC passes are separate rocprofv3 runs (scripts/profile_round.sh): a summary collected on other kernel
+        # sources says nothing about this run -- traffic is null until the passes are repeated
+        pmc_stale = pmc.get("kernel_source_sha", "unstamped")
+        pmc = {}
+    traffic_src = {"file": pmc_file, "kernel_source_sha": src_sha, "stale_summary_sha": pmc_stale}
     if workload == HEADLINE:
         note = ("config-2 working set (3.7 MB activations) is cache-resident and every launch is a few hundred "
                 "workgroups of one ~10 us dependent chain: the step is latency-bound by construction (SURVEY.md 8d); "
@@ -270,7 +279,7 @@ def engine_roofline(trainer, batches, workload, iters=20):
         d = dict(bound="mfma", kernel=mfma[key][1], achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3,
                  traffic=(pmc.get(mfma[key][2]) or pmc.get(mfma[key][2].replace("k_gemm_dual", "k_gemm_big_dual")) or {}).get("bytes_per_launch"),
                  avg_launch_us=dur * 1e6,
-                 algorithmic_flops_per_launch=work, timed_launches_per_step=per_step, note=note)
+                 algorithmic_flops_per_launch=work, timed_launches_per_step=per_step, note=note, traffic_source=traffic_src)
         roof["roofline" if key == best else "roofline_" + mfma[key][0]] = d
     if "spmm" in out:
         dur, work, per_step = out["spmm"]
@@ -494,7 +503,7 @@ def main():
     run(0, a.warmup)
     # --repeats timed regions of EXACTLY --steps steps each, every one bracketed by barrier + synchronize and reduced
     # with MAX over ranks; value / ms_per_step come from the MEDIAN region (median of 5 repeats)
-    regions = []
+    regions, local_regions = [], []
     first = a.warmup
     for _ in range(max(1, a.repeats)):
         barrier()
@@ -502,6 +511,7 @@ def main():
         stats = run(first, a.steps)
         barrier()
         dt = time.perf_counter() - t0
+        local_regions.append(dt)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -509,6 +519,29 @@ def main():
         regions.append(dt)
         first += a.steps
     dt = float(np.median(regions))
+    # N > 1 diagnostics (the driver's 8-GPU run is the only multi-GPU measurement there is): per-rank step time of the
+    # median region's policy, and the gradient exchange alone -- 20 eager all-reduces of the flat bucket between events
+    dp_diag = None
+    if world > 1:
+        local = torch.tensor([float(np.median(local_regions))], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(allr, local)
+        for _ in range(3):
+            dist.all_reduce(trainer.flat_g)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        saved = trainer.flat_g.clone()
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(trainer.flat_g)
+        e1.record()
+        torch.cuda.synchronize()
+        trainer.flat_g.copy_(saved)
+        dp_diag = {"exchange_in_graph": bool(trainer.exchange_in_graph), "fused_opt": bool(trainer.fused_opt),
+                   "sequence_graph": bool(seq), "backend": dist.get_backend(),
+                   "bucket_bytes": int(trainer.flat_g.numel() * 4),
+                   "allreduce_us_eager": 1e3 * e0.elapsed_time(e1) / 20,
+                   "ms_per_step_by_rank": [round(1e3 * float(t.item()) / a.steps, 5) for t in allr]}
     trainer.check_status()
     final = stats.tolist()
     graphs = wl["batch"] * a.steps * world
@@ -519,7 +552,7 @@ def main():
         "metric": "graphs/sec (train step) on SPMotif b=0.9 batch=128" if wl["data"] == "spmotif" else
                   "graphs/sec (train step) on %s batch=%d" % (a.workload, wl["batch"]),
         "value": graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * dt / a.steps, "timed_region_ms": 1e3 * dt, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": a.workload, "model": wl["model"], "batch_per_gpu": wl["batch"],
                    "global_batch": wl["batch"] * world, "hidden": wl["hidden"], "layers": wl["layers"],
@@ -528,6 +561,8 @@ def main():
                    "final_loss": final[0],
                    "repeats": {"n": len(regions), "ms_per_step": [round(1e3 * r / a.steps, 5) for r in regions], "pick": "median"}},
     }
+    if dp_diag is not None:
+        out["data_parallel"] = dp_diag
     if rank == 0 and world == 1:
         if not a.no_roofline:
             try:

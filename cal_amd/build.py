@@ -34,6 +34,19 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def kernel_source_sha() -> str:
+    """sha1 (16 hex digits) over every HIP source and header of libcalhip.so: identifies the kernel table a measurement
+    (a PMC summary under profiles/, a bench line) belongs to."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _needs(src: str, obj: str, deps) -> bool:
     if not os.path.exists(obj):
         return True

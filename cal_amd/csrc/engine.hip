@@ -226,6 +226,13 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     Engine* e = new Engine();
     memset(e, 0, sizeof(Engine));
     { const char* v = getenv("CAL_AMD_RO_STEP"); e->ro_step = !(v && v[0] == '0'); }
+    {
+        // k_ro_step's 3 * H / 16 workgroups (133 KB of LDS each: one per CU) meet at spin barriers: they must all be
+        // resident.  A device (or CU mask / partition) with fewer compute units than that takes the four-kernel readout.
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        if (cus < 3 * ((int)H / RO_CW) + 8) e->ro_step = 0;
+    }
     { const char* v = getenv("CAL_AMD_ADAM_FUSED"); e->adam_fused = !(v && v[0] == '0'); }
     e->F = (int)F; e->H = (int)H; e->C = (int)C; e->L = (int)L;
     e->loop_w = 1.f;

@@ -33,16 +33,20 @@ struct RoStepArgs {
     int* sync;                            // [3][2] barrier counters (zero at the start of the step)
 };
 
+// Fences by ONE lane, around the workgroup barriers: the L2 write-back of a release and the invalidate of an acquire are
+// cache-wide operations, so one wave's covers the workgroup once __syncthreads has drained every wave's stores
+// (s_waitcnt vmcnt(0) precedes the s_barrier) -- issued by all waves they queue up behind each other
+// (scripts/micro/gridbar.hip: 65 vs 20 us per barrier at 256 workgroups x 8 waves); the poll is a relaxed load.
 __device__ __forceinline__ void ro_step_arrive(int* ctr) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every wave: its global stores are written back past our L2
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void ro_step_wait(int* ctr, int n) {
-    if (threadIdx.x == 0)
-        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 __device__ __forceinline__ void ro_step_barrier(int* ctr, int n) {
     ro_step_arrive(ctr);

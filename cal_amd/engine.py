@@ -185,6 +185,7 @@ class StepEngine:
         #: (what a batch too large for the per-graph kernels runs anyway); tests compare the two paths with it
         self.fused = True
         self._ws: Optional[torch.Tensor] = None
+        self.ws_generation = 0          # bumped whenever the workspace is re-allocated (captured graphs check it)
         self._cap = (0, 0, 0)
         self._bounds = (0, 0)
         self._ptrs = (0, 0)
@@ -229,12 +230,21 @@ class StepEngine:
         if N <= cn and E <= ce and B <= cb and self._ws is not None:
             return
         N, E, B = max(N, cn), max(E, ce), max(B, cb)
+        # what the steps run so far flagged travels with us (the old status word dies with the old workspace; a
+        # synchronising read, but growth is rare), and captured graphs of the old workspace are stale from here on
+        sticky = 0
+        if self._ws is not None:
+            st = self.buffer("status", 4, torch.int32)
+            sticky = int((st[0] | st[1]).item())
+        self.ws_generation += 1
         nbytes = _lib.query("cal_engine_workspace_bytes", self._h, N, E, B)
         self._ws = torch.empty(nbytes // 4 + 64, dtype=torch.float32, device=self.device)
         assert self._ws.data_ptr() % 256 == 0
         _lib.call("cal_engine_set_workspace", self._h, _p(self._ws), nbytes, N, E, B)
         self._cap = (N, E, B)
         self.buffer("status", 4, torch.int32).zero_()       # [0] = latest step, [1] = sticky OR of the earlier steps
+        if sticky:
+            self.buffer("status", 4, torch.int32)[1] = sticky
         if self.gin:
             self.buffer("ones", N).fill_(1.0)                 # unit aggregation coefficients of the GINConv layers
 

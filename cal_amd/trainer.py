@@ -70,7 +70,7 @@ MAX_CAPTURED = 256
 class _Captured:
     """Captured step(s) of one resident batch: `graphs[True]` draws the intervention permutation on the
     device inside the graph (cal_randperm), `graphs[False]` reads it from `perm` (uploaded by the host)."""
-    __slots__ = ("graphs", "perm", "stats", "batch", "ptrs")
+    __slots__ = ("graphs", "perm", "stats", "batch", "ptrs", "ws_gen")
 
 
 class _PinnedRing:
@@ -269,9 +269,8 @@ class CausalTrainer:
             x = batch.x if getattr(batch, "x", None) is not None else batch.feat
             cn, ce, cb = self.engine._cap
             if x.size(0) > cn or batch.edge_index.size(1) > ce or nb > cb:
-                if any(c.graphs for c in self._graphs.values()):
-                    raise RuntimeError("engine workspace would be re-allocated under captured graphs: "
-                                       "call reserve_for(all batches) before the first prepare()")
+                # growth bumps the engine's workspace generation: graphs captured on the old workspace are evicted and
+                # re-captured when their batch comes up again (_captured); reserve_for(all batches) up front avoids that
                 self.engine.reserve(x.size(0), batch.edge_index.size(1), nb)
         # warm-up on a side stream (allocator / autograd state); everything it touched is restored
         snap = self._snapshot()
@@ -287,7 +286,7 @@ class CausalTrainer:
             with torch.cuda.graph(g, pool=self._pool):
                 cap.stats = self._fwd_bwd(batch, cap.perm, cap.stats, draw=draws)
         except Exception as exc:
-            if not (self.exchange_in_graph and not self._graphs):
+            if not self.exchange_in_graph:
                 raise
             # the collective refused stream capture: keep it between two graphs instead (every rank runs the same
             # software, so every rank takes this branch)
@@ -297,9 +296,14 @@ class CausalTrainer:
             self.fused_opt = False
             torch.cuda.synchronize()
             self._restore(snap)
+            # graphs captured earlier contain the collective + Adam: drop them, they are re-captured in the split form
+            self._graphs.clear()
+            self._seqs.clear()
+            cap.graphs = {}
             return self._capture(batch, dev_perm, cap)
         self._restore(snap)
         cap.graphs[dev_perm] = g
+        cap.ws_gen = self.engine.ws_generation if self.engine is not None else 0
         return cap
 
     def _reset_opt_state(self):
@@ -373,31 +377,52 @@ class CausalTrainer:
             for b in batches:
                 stats = self.step(b)
             return stats
+        if len(batches) > MAX_CAPTURED // 2:      # a sequence must not evict its own single-step captures: run it in chunks
+            stats = None
+            for s0 in range(0, len(batches), MAX_CAPTURED // 2):
+                stats = self.step_sequence(batches[s0:s0 + MAX_CAPTURED // 2])
+            return stats
         key = tuple(id(b) for b in batches)
         seq = self._seqs.get(key)
+        if seq is not None and len(seq) > 3 and seq[3] != self.engine.ws_generation:
+            del self._seqs[key]
+            seq = None
         if seq is None:
-            for b in batches:                     # per-batch state (perm buffers, warm-up) comes from the single-step capture
-                self.prepare(b)
-            caps = [self._graphs[id(b)] for b in batches]
+            # per-batch state (perm buffers, warm-up) comes from the single-step capture; the captures are taken from
+            # _captured()'s return value and pinned for the loop (an eviction while preparing a later batch of the same
+            # sequence used to leave `self._graphs[id(b)]` dangling)
+            self._pinned = set(key)
+            try:
+                caps = [self._captured(b, self._use_device_perm(b.num_graphs)) for b in batches]
+            finally:
+                self._pinned = set()
             snap = self._snapshot()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._pool):
                 for b, cap in zip(batches, caps):
                     stats = self._fwd_bwd(b, cap.perm, cap.stats, draw=self._shuffles())
             self._restore(snap)
-            seq = self._seqs[key] = (g, stats, list(batches))
+            seq = self._seqs[key] = (g, stats, list(batches), self.engine.ws_generation)
         seq[0].replay()
         return seq[1]
 
     def _captured(self, batch, dev_perm: bool) -> _Captured:
         cap = self._graphs.get(id(batch))
+        gen = self.engine.ws_generation if self.engine is not None else 0
+        if cap is not None and getattr(cap, "ws_gen", gen) != gen:
+            # the engine's workspace was re-allocated after this capture: its kernels have the old buffers baked in
+            self._evict(id(batch))
+            cap = None
         if cap is not None and (cap.batch is not batch or cap.ptrs != _batch_ptrs(batch)):
             # same id() but another object, or the batch's tensors were replaced: the baked-in pointers are stale
             self._evict(id(batch))
             cap = None
         if cap is None or dev_perm not in cap.graphs:
             if cap is None and len(self._graphs) >= MAX_CAPTURED:
-                self._evict(next(iter(self._graphs)))
+                pinned = getattr(self, "_pinned", ())
+                victim = next((k for k in self._graphs if k not in pinned), None)
+                if victim is not None:
+                    self._evict(victim)
             cap = self._capture(batch, dev_perm, cap)
             self._graphs[id(batch)] = cap
         return cap

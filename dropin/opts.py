@@ -65,13 +65,20 @@ def get_model(args):
     return lambda num_features, num_classes: cls(num_features, num_classes, args.hidden)
 
 
-def create_n_filter_triples(datasets, feat_strs=("deg+odeg100",), nets=("ResGCN",), **_):
-    """(dataset, feature string, net) triples; REDDIT datasets use the narrower one-hot degree, as the reference does."""
+_NARROW_DEGREE = {"REDDIT-BINARY", "REDDIT-MULTI-5K", "REDDIT-MULTI-12K", "DD"}      # opts.py:130-136
+
+
+def create_n_filter_triples(datasets, feat_strs=("deg+odeg100",), nets=("ResGCN",), reddit_odeg10=True, dd_odeg10_ak1=True, **_):
+    """(dataset, feature string, net) triples of opts.py:121-139: the three REDDIT datasets and DD take the narrower one-hot
+    degree ('odeg10'), DD also 'ak1' for 'ak3'."""
     out = []
     for d in datasets:
         for f in feat_strs:
+            narrow = (reddit_odeg10 and d in _NARROW_DEGREE and d != "DD") or (dd_odeg10_ak1 and d == "DD")
+            if narrow:
+                f = f.replace("odeg100", "odeg10")
+            if dd_odeg10_ak1 and d == "DD":
+                f = f.replace("ak3", "ak1")
             for n in nets:
-                if d.startswith("REDDIT"):
-                    f = f.replace("odeg100", "odeg10")
                 out.append((d, f, n))
     return out

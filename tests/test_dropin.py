@@ -56,6 +56,10 @@ CHILD = textwrap.dedent("""
     except NotImplementedError:
         pass
     assert opts.create_n_filter_triples(["MUTAG"])[0] == ("MUTAG", "deg+odeg100", "ResGCN")
+    # opts.py:130-136: DD and the three REDDIT sets (exact names) take the narrower one-hot degree, DD also ak3 -> ak1
+    assert opts.create_n_filter_triples(["DD"], feat_strs=["deg+odeg100+ak3"])[0] == ("DD", "deg+odeg10+ak1", "ResGCN")
+    assert opts.create_n_filter_triples(["REDDIT-BINARY"])[0][1] == "deg+odeg10"
+    assert opts.create_n_filter_triples(["REDDIT-FOO"])[0][1] == "deg+odeg100"
     try:
         get_dataset("MUTAG", sparse=True, feat_str="deg+odeg100", root="/nonexistent")
         raise SystemExit("expected FileNotFoundError")

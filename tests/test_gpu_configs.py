@@ -140,8 +140,13 @@ def test_config5_width_causalgat_engine_step_matches_oracle():
     for r32, r64, t in zip(logits, logits64, lp):
         e_gpu = (r64.detach() - t.double()).abs().max().item()
         e_cpu = (r64.detach() - r32.detach().double()).abs().max().item()
-        assert e_gpu < max(LOGIT_TOL, 4 * e_cpu), (e_gpu, e_cpu)
-    assert abs(stats[0] - loss64.item()) < max(1e-4, 4 * abs(loss.item() - loss64.item()))
+        # both bounds absolute, against the oracle evaluated in fp64.  Measured on MI355X (scripts history, round 3): the HIP
+        # path is 4e-6 away from it (fp64 accumulators behind every cross-row sum), the fp32 oracle 4.8e-5 (2e-5 with eight
+        # graphs): the unfused fp32 restatement is the noisier of the two, so it only has to stay inside the tolerance
+        # itself, and the HIP path is held to a quarter of north_star's 1e-4
+        assert e_gpu < 2.5e-5, (e_gpu, e_cpu)
+        assert e_cpu < LOGIT_TOL, e_cpu
+    assert abs(stats[0] - loss64.item()) < 1e-4
     eng.check_status()
     for k, p in m.named_parameters():
         g32, g64 = tr.sd[k].grad, tr64.sd[k].grad
@@ -317,3 +322,96 @@ def test_single_graph_batch_in_training_raises_like_the_reference():
     out = eng.forward(bd, perm.to(DEV), training=False)
     for r, t in zip(ref, out):
         assert (r - t.cpu()).abs().max().item() < LOGIT_TOL
+
+
+def test_workspace_growth_evicts_captured_graphs_and_keeps_the_status_word():
+    """growing the engine workspace under captured graphs used to leave graphs that write (and flag invalid
+    batches) into the OLD workspace.  Now the workspace generation is part of a capture: a stale graph is re-captured when
+    its batch comes up again, and what earlier steps flagged survives the re-allocation."""
+    from cal_amd import model as M
+    from cal_amd.data import Batch
+    from cal_amd.trainer import CausalTrainer
+    torch.manual_seed(6)
+    m = M.CausalGCN(10, 4, _args(layers=2, hidden=64)).to(DEV)
+    trn = CausalTrainer(m, _args(layers=2, hidden=64), lr=0.0, use_graph=True)
+    small = Batch.from_data_list(ref_graphs(list(range(8)))).to(DEV)
+    perm8 = torch.arange(8, device=DEV)
+    l0 = float(trn.step(small, perm=perm8)[0].item())
+    gen0 = trn.engine.ws_generation
+    trn.engine.buffer("status", 4, torch.int32)[1] = 8            # pretend an earlier step flagged a bad bound
+    big = Batch.from_data_list(ref_graphs(list(range(24)))).to(DEV)
+    trn.step(big, perm=torch.arange(24, device=DEV))              # grows the workspace
+    assert trn.engine.ws_generation > gen0
+    l1 = float(trn.step(small, perm=perm8)[0].item())             # stale capture -> re-captured on the new workspace
+    assert abs(l0 - l1) < 1e-6
+    assert trn._graphs[id(small)].ws_gen == trn.engine.ws_generation
+    with pytest.raises(Exception, match="status 0x8"):
+        trn.check_status()
+
+
+def test_sequence_longer_than_the_graph_cache(monkeypatch):
+    """step_sequence over more batches than MAX_CAPTURED used to evict its own single-step captures while
+    preparing the later ones (KeyError).  It now runs in chunks and pins what it is using."""
+    from cal_amd import model as M
+    from cal_amd import trainer as T
+    from cal_amd.data import Batch
+    monkeypatch.setattr(T, "MAX_CAPTURED", 4)
+    torch.manual_seed(6)
+    outs = []
+    batches = [Batch.from_data_list(ref_graphs(list(range(8 * (i % 3), 8 * (i % 3) + 8)))).to(DEV) for i in range(7)]
+    for seq in (True, False):
+        torch.manual_seed(6)
+        random_state = __import__("random").getstate()
+        m = M.CausalGCN(10, 4, _args(layers=2, hidden=64, with_random=False)).to(DEV)
+        trn = T.CausalTrainer(m, _args(layers=2, hidden=64, with_random=False), lr=1e-3, use_graph=True)
+        trn.reserve_for(batches)
+        if seq:
+            stats = trn.step_sequence(batches)
+        else:
+            for b in batches:
+                stats = trn.step(b)
+        outs.append((stats.clone(), trn.flat_p.clone()))
+        __import__("random").setstate(random_state)
+    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-6)
+    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-6)
+
+
+def test_config5_full_per_gpu_batch_step_properties():
+    """BASELINE.json configs[4] at its FULL per-GPU batch (32 BA graphs of 5000 nodes, hidden 256, 4 heads, 3 layers:
+    N = 160000, E' ~ 800k) -- too large for the CPU oracle in test time, so one CausalGAT train step is checked through the
+    size-independent properties the domain offers: status word clean, the two soft masks partition (w_c + w_o = 1 per edge,
+    a_c + a_o = 1 per node), log-probs normalise, the add-pool conserves the column sums of the two branch outputs, the
+    loss is the weighted sum of its terms, every gradient is finite and conv_feat.bias gets none, and a repeat
+    of the same step from the same state reproduces the statistics bit for bit (fixed-order reductions)."""
+    from cal_amd import synth
+    from cal_amd.data import Batch
+    gs = synth.ba_graphs(32, n=5000, seed=11)
+    bd = Batch.from_data_list(gs).to(DEV)
+    N, E, B, H = bd.feat.size(0), bd.edge_index.size(1), 32, 256
+    assert N == 160000
+    torch.manual_seed(23)
+    sd = O.init_state("CausalGAT", 10, 4, hidden=H, layers=3, heads=4)
+    m, eng = _engine("CausalGAT", {k: v.clone() for k, v in sd.items()}, _args(hidden=H), dropout=0.0, lr=0.0)
+    perm = torch.randperm(B, device=DEV)
+    stats1 = eng.train_step(bd, perm, adam=True).clone()
+    eng.check_status()
+    lp = eng.buffer("logp", 3 * B * 4).view(3, B, 4)
+    assert torch.allclose(lp.exp().sum(-1), torch.ones(3, B, device=DEV), atol=1e-5)
+    att = eng.buffer("att", 2 * E).view(2, E)
+    assert torch.allclose(att.sum(0), torch.ones(E, device=DEV), atol=1e-6)
+    an = eng.buffer("anode", 2 * N).view(N, 2)
+    assert torch.allclose(an.sum(1), torch.ones(N, device=DEV), atol=1e-6)
+    hco = eng.buffer("hco", 2 * N * H).view(2, N, H)
+    pooled = eng.buffer("pooled", 2 * B * H).view(2, B, H)
+    for k in range(2):
+        ref = torch.zeros(B, H, device=DEV, dtype=torch.float64).index_add_(0, bd.batch, hco[k].double())
+        assert torch.allclose(pooled[k].double(), ref, rtol=2e-5, atol=1e-3), k
+    s = stats1.tolist()
+    assert all(np.isfinite(s)) and abs(s[0] - (0.5 * s[1] + s[2] + 0.5 * s[3])) < 1e-5
+    g = eng.flat_g
+    assert bool(torch.isfinite(g).all().item()) and float(g.abs().max().item()) > 0.0
+    assert float(m.conv_feat.bias.grad.abs().max().item()) == 0.0
+    # lr = 0: the parameters did not move -> the same step again must give the same bits
+    m.load_state_dict(sd)                                           # running statistics back to their initial values
+    stats2 = eng.train_step(bd, perm, adam=True).clone()
+    assert torch.equal(stats1, stats2)

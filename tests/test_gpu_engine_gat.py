@@ -286,19 +286,23 @@ def test_big_batch_takes_the_throughput_gemm_and_matches_oracle(name):
     perm = torch.randperm(4)
     tr = O.CpuTrainer(name, {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=2, heads=4, gat_dropout=0.0)
     loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    tr64 = O.CpuTrainer(name, sd64, 4, lr=1e-3, layers=2, heads=4, gat_dropout=0.0)
+    tr64.step(b.feat.double(), b.edge_index, b.batch, b.y, perm=perm)
     stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
     lp = eng.buffer("logp", 3 * 4 * 4).view(3, 4, 4).cpu()
     for r, t in zip(logits, lp):
         assert (r.detach() - t).abs().max().item() < LOGIT_TOL
     assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
     for k, p in m.named_parameters():
-        gref = tr.sd[k].grad
-        if gref is not None:
-            # sums over 20000 nodes through a readout BatchNorm over only 4 graphs: fp32 summation-order noise is
-            # amplified, so the bound is relative to the gradient's largest entry
-            scale = max(1.0, gref.abs().max().item())
-            err = (p.grad.cpu() - gref).abs().max().item()
-            assert err <= 1e-3 * scale, (k, err, scale)
+        g32, g64 = tr.sd[k].grad, tr64.sd[k].grad
+        if g32 is not None:
+            # sums over 20000 nodes through a readout BatchNorm over only 4 graphs amplify fp32 summation-order noise, so the
+            # bound is stated against the oracle evaluated in fp64 (as tests/test_gpu_configs.py does at config-5 width): the
+            # HIP path must be as close to it as the fp32 oracle is (x4), plus 1e-5 of the gradient's largest entry
+            e_gpu = (p.grad.cpu().double() - g64).abs().max().item()
+            e_cpu = (g32.double() - g64).abs().max().item()
+            assert e_gpu <= 4 * e_cpu + 1e-5 * max(1.0, g64.abs().max().item()), (k, e_gpu, e_cpu)
 
 
 def test_fused_per_graph_gat_forward_with_dropout_matches_oracle():
