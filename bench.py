@@ -80,7 +80,8 @@ def make_graphs(wl, n, seed):
 def make_batches(wl, nb, seed):
     from cal_amd.data import Batch
     gs = make_graphs(wl, nb * wl["batch"], seed)
-    return [Batch.from_data_list(gs[i * wl["batch"]:(i + 1) * wl["batch"]]) for i in range(nb)]
+    # (batches of small graphs are ordered for the engine's 64-node tiles, as DeviceLoader orders them: a mini-batch is a set)
+    return [Batch.from_data_list(gs[i * wl["batch"]:(i + 1) * wl["batch"]], pack=True) for i in range(nb)]
 
 
 def cpu_baseline(wl, batches_cpu, seconds):

@@ -11,6 +11,9 @@
 // host from the (host-resident) size arrays.
 #include "common.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace cal {
 
 __global__ void __launch_bounds__(256) k_collate(const float* __restrict__ X, const int64_t* __restrict__ EI, int64_t sumE,
@@ -69,4 +72,41 @@ CAL_EXPORT int cal_randperm(int64_t* perm, int64_t B, uint64_t seed, uint64_t* c
                        (unsigned long long)seed, (unsigned long long*)counter);
     CAL_CHECK_LAUNCH("k_randperm");
     return 0;
+}
+
+
+// Host-side helper of the small-graph packing (cal_engine_set_tiles): order the B graphs of a mini-batch so that consecutive
+// runs of them fill 64-node tiles.  A mini-batch is a SET of graphs (the loss is a mean over it, the intervention permutation
+// random): their order inside the batch is the loader's to choose.  First-fit decreasing by node count under the three tile
+// bounds; graphs are emitted tile by tile.  order_out [B]: positions into the input arrays; first_out [T + 1]: first emitted
+// graph of every tile.  Returns T, or -1 when a graph exceeds a bound (the batch is not packed).  No device work.
+CAL_EXPORT int64_t cal_pack_order(const int64_t* node_sizes, const int64_t* edge_sizes, int64_t B, int64_t max_nodes,
+                                  int64_t max_edges, int64_t max_graphs, int64_t* order_out, int64_t* first_out) {
+    if (!node_sizes || !edge_sizes || !order_out || !first_out || B < 0 || max_graphs < 1) return -1;
+    std::vector<int64_t> idx((size_t)B);
+    for (int64_t i = 0; i < B; ++i) {
+        if (node_sizes[i] > max_nodes || edge_sizes[i] > max_edges || node_sizes[i] < 0 || edge_sizes[i] < 0) return -1;
+        idx[(size_t)i] = i;
+    }
+    std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) { return node_sizes[a] > node_sizes[b]; });
+    struct Bin { int64_t n, e, g; std::vector<int64_t> items; };
+    std::vector<Bin> bins;
+    size_t first_open = 0;                                   // bins before it are full in one of the three dimensions
+    for (int64_t k = 0; k < B; ++k) {
+        const int64_t i = idx[(size_t)k], n = node_sizes[i], e = edge_sizes[i];
+        size_t j = first_open;
+        for (; j < bins.size(); ++j)
+            if (bins[j].n + n <= max_nodes && bins[j].e + e <= max_edges && bins[j].g < max_graphs) break;
+        if (j == bins.size()) bins.push_back(Bin{0, 0, 0, {}});
+        bins[j].n += n; bins[j].e += e; bins[j].g += 1; bins[j].items.push_back(i);
+        while (first_open < bins.size() && (bins[first_open].n >= max_nodes || bins[first_open].g >= max_graphs)) ++first_open;
+    }
+    int64_t pos = 0, t = 0;
+    for (auto& b : bins) {
+        first_out[t++] = pos;
+        std::sort(b.items.begin(), b.items.end());           // inside a tile: the loader's order
+        for (int64_t i : b.items) order_out[pos++] = i;
+    }
+    first_out[t] = pos;
+    return t;
 }

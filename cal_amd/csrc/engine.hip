@@ -184,6 +184,9 @@ struct Engine {
     float* coef;                // [3][E] edge coefficients dis_j * w_e in CSR-by-destination slot order: unit, context, objects
     int max_nodes, max_edges;   // per-graph bounds of the coming batches (0 = unknown): cal_engine_set_graph_bounds
     const int64_t *node_ptr, *edge_ptr;   // [B+1] device arrays of the coming batch (null = unknown): cal_engine_set_graph_ptrs
+    // small-graph packing (cal_engine_set_tiles): the per-graph kernels run one workgroup per TILE = a run of consecutive
+    // graphs; node_ptr / edge_ptr and the bounds above then describe tiles, tile_gptr [ntiles + 1] = first graph of every tile
+    const int64_t* tile_gptr; int ntiles;
     // GATConv backbone (CausalGAT, model.py:340,390): K heads (0 = GCNConv backbone), attention dropout p with
     // per-layer seeds and an optional device step counter, att [K, 2D] parameter offsets
     int K; float gat_p, gat_slope;
@@ -429,6 +432,8 @@ struct Ctx {
     Engine* e;
     hipStream_t st;
     int N, B;
+    const int64_t* batch;   // [N] graph id of every node (the step's input)
+    int T;              // units of the per-graph kernels: tiles of consecutive graphs when the batch is packed, else graphs (= B)
     int64_t E;
     int training;
     int rpb_n, rpb_b;   // rows per block for node-level / graph-level row walkers
@@ -648,12 +653,12 @@ bool use_gc(const Ctx& c) {
 }
 bool gc_small(const Ctx& c) { return c.e->max_nodes <= 64 && c.e->max_edges <= gc_edge_cap(64); }
 // per-graph fused backward (engine_gconv_bwd.hpp): 64-node graphs only
-bool use_gcb(const Ctx& c) { return use_gc(c) && gc_small(c) && c.B <= 128 * 4; }
+bool use_gcb(const Ctx& c) { return use_gc(c) && gc_small(c) && c.T <= 128 * 4; }
 // partial-row statistics of a per-graph kernel: one row per graph
 Acc graph_acc(Ctx& c, double* dst, int cols) {
-    double* p = parts_alloc(c, (size_t)c.B * cols);
+    double* p = parts_alloc(c, (size_t)c.T * cols);
     if (!p) return Acc(dst);
-    final_task(c, p, c.B, cols, cols, dst);
+    final_task(c, p, c.T, cols, cols, dst);
     return Acc(dst, p, cols);
 }
 
@@ -662,8 +667,9 @@ Acc graph_acc(Ctx& c, double* dst, int cols) {
 int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, double** dsum, double** dprod,
               FinishArgs& fa, size_t& slab_off, bool rs) {
     Engine* e = c.e;
-    const int H = e->H, B = c.B, nsl = H / GC_N;
+    const int H = e->H, B = c.T, nsl = H / GC_N;         // (B: units of this launch -- tiles or graphs)
     for (int k = 0; k < nb; ++k) {
+        gb[k].batch = c.batch; gb[k].tile_gptr = e->ntiles > 0 ? e->tile_gptr : nullptr;
         const size_t need = (size_t)B * H * H;
         if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
         gb[k].slab = e->slabs + slab_off;
@@ -676,7 +682,8 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
         final_task(c, p + H, B * nsl, 2 * H, H, dprod[k]);
     }
     const dim3 grid(B, nsl, nb);
-    if (rs) PROF_LAUNCH((k_gconv_bwd<true, 2>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
+    if (rs && e->ntiles > 0) PROF_LAUNCH((k_gconv_bwd<true, 2, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
+    else if (rs) PROF_LAUNCH((k_gconv_bwd<true, 2>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
     else if (gb[0].dout) PROF_LAUNCH((k_gconv_bwd<false, 0>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
     else PROF_LAUNCH((k_gconv_bwd<false, 1>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
     CAL_CHECK_LAUNCH("k_gconv_bwd");
@@ -742,10 +749,11 @@ int gin_rows(Ctx& c, int mode, const GinRowArgs& ga) {
 int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int64_t* batch, const int64_t* y,
                    const int64_t* perm, float wc, float wo, float wco, int want_grad) {
     Engine* e = c.e;
-    const int N = c.N, B = c.B, H = e->H, F = e->F, C = e->C, L = e->L;
+    const int N = c.N, B = c.B, T = c.T, H = e->H, F = e->F, C = e->C, L = e->L;
     const int64_t E = c.E;
     hipStream_t st = c.st;
     const size_t NH = (size_t)N * H;
+    const int64_t* tgp = e->ntiles > 0 ? e->tile_gptr : nullptr;
     // per-graph plan (engine_plan.hpp) when the host vouches for the batch layout
     const bool fast_plan = e->node_ptr && e->edge_ptr && B > 0 && e->max_nodes > 0 && e->max_nodes <= GP_T2 && e->max_edges <= GP_E2;
     const bool wide_plan = fast_plan && (e->max_nodes > GP_T || e->max_edges > GP_E);
@@ -761,7 +769,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     // 1. GraphPlan
     if (fast_plan) {
         auto kern = wide_plan ? k_plan_graph<GP_T2, GP_E2> : k_plan_graph<GP_T, GP_E>;
-        hipLaunchKernelGGL(kern, dim3(B), dim3(256), 0, st, edge_index, E, N, B, e->node_ptr, e->edge_ptr, batch, e->loop_w,
+        hipLaunchKernelGGL(kern, dim3(T), dim3(256), 0, st, edge_index, E, N, T, e->node_ptr, e->edge_ptr, batch, tgp, B, e->loop_w,
                            e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src, e->row32, e->col32,
                            e->gptr, e->eptr, e->dis_unit, e->status, plan_stats ? x0 : nullptr, F, bn_stsum(c, 0), bn_stsq(c, 0));
         CAL_CHECK_LAUNCH("k_plan_graph"); STAGE();
@@ -852,7 +860,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
                 ga.seed = e->gat_seed[i - 1]; ga.ctr = (const uint64_t*)e->gat_ctr; ga.E = E;
                 {
                     ProfScope ps(st, 7, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
-                    PROF_LAUNCH(k_ggat_fwd, dim3(B, H / GC_N), dim3(256), 0, st, gd, e->gptr, e->eptr, ga, H, H, e->status);
+                    PROF_LAUNCH(k_ggat_fwd, dim3(T, H / GC_N), dim3(256), 0, st, gd, e->gptr, e->eptr, ga, H, H, e->status);
                 }
                 CAL_CHECK_LAUNCH("k_ggat_fwd"); STAGE();
                 RC(flush_finals(c)); STAGE();
@@ -887,9 +895,9 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H); }
             {
                 ProfScope ps(st, 2, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
-                if (gc_small(c)) PROF_LAUNCH((k_gconv_fwd<false, 64, 512>), dim3(B, H / GC_N, 1), dim3(512), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1,
+                if (gc_small(c)) PROF_LAUNCH((k_gconv_fwd<false, 64, 512>), dim3(T, H / GC_N, 1), dim3(512), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1,
                                                     e->loop_w, H, H, e->status);
-                else PROF_LAUNCH((k_gconv_fwd<false, GC_T>), dim3(B, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1,
+                else PROF_LAUNCH((k_gconv_fwd<false, GC_T>), dim3(T, H / GC_N, 1), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1,
                                         e->loop_w, H, H, e->status);
             }
             CAL_CHECK_LAUNCH("k_gconv_fwd"); STAGE();
@@ -923,7 +931,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         const Acc a2 = graph_acc(c, bn_stsum(c, L + 2), H), a3 = graph_acc(c, bn_stsq(c, L + 2), H);
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_att_fwd_graph<4, G>), dim3(B), dim3(512), 0, st, e->gptr, gs, x, e->P + e->o_natt_w, e->P + e->o_natt_b,
+            hipLaunchKernelGGL((k_att_fwd_graph<4, G>), dim3(T), dim3(512), 0, st, e->gptr, gs, x, e->P + e->o_natt_w, e->P + e->o_natt_b,
                                e->P + e->o_eatt_w, e->P + e->o_eatt_b, e->anode, e->pq, e->att, e->dis_co, e->dis_co + N, a0, a1, a2, a3,
                                e->loop_w, H, E, e->status, e->no_node_att ? 0.f : 1.f, e->no_edge_att ? 0.f : 1.f, e->eptr);
             return 0;
@@ -961,10 +969,13 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             gb[k].out = e->hco + (size_t)k * NH; gb[k].z = e->zco + (size_t)k * NH; gb[k].pooled = e->pooled + (size_t)k * B * H;
             gb[k].coef_out = e->coef + (size_t)(1 + k) * E;
             gb[k].w_out = e->wslot + (size_t)k * E;
+            gb[k].batch = batch; gb[k].tile_gptr = tgp;          // packed batch: the add-pool is per GRAPH inside the tile
         }
-        if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<true, 64, 512>), dim3(B, H / GC_N, 2), dim3(512), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1,
+        if (tgp) hipLaunchKernelGGL((k_gconv_fwd<true, 64, 512, true>), dim3(T, H / GC_N, 2), dim3(512), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1,
+                                    e->loop_w, H, H, e->status);
+        else if (gc_small(c)) hipLaunchKernelGGL((k_gconv_fwd<true, 64, 512>), dim3(T, H / GC_N, 2), dim3(512), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1,
                                             e->loop_w, H, H, e->status);
-        else hipLaunchKernelGGL((k_gconv_fwd<true, GC_T>), dim3(B, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1,
+        else hipLaunchKernelGGL((k_gconv_fwd<true, GC_T>), dim3(T, H / GC_N, 2), dim3(256), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1,
                                 e->loop_w, H, H, e->status);
         CAL_CHECK_LAUNCH("k_gconv_fwd(co)"); STAGE();
     }
@@ -1071,7 +1082,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
 
 int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     Engine* e = c.e;
-    const int N = c.N, B = c.B, H = e->H, F = e->F, C = e->C, L = e->L;
+    const int N = c.N, B = c.B, T = c.T, H = e->H, F = e->F, C = e->C, L = e->L;
     const int64_t E = c.E;
     hipStream_t st = c.st;
     const size_t NH = (size_t)N * H, BH = (size_t)B * H;
@@ -1096,7 +1107,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     };
     const int ag_split = 2;                                        // workgroups per graph of k_att_bwd_graph
     auto deferred_g = [&](int cols, Deferred& d) -> Acc {          // one partial row per workgroup of k_att_bwd_graph
-        d.p = parts_alloc(c, (size_t)ag_split * B * cols); d.P = ag_split * B; d.stride = cols;
+        d.p = parts_alloc(c, (size_t)ag_split * T * cols); d.P = ag_split * T; d.stride = cols;
         return d.p ? Acc(nullptr, d.p, cols) : Acc();
     };
     Deferred d_convb[MAX_LAYERS], d_cb, d_ob, d_dwn, d_dwe, d_bn0;
@@ -1192,7 +1203,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         CAL_CHECK_LAUNCH("k_readout_bwd_tail"); STAGE();
     }
     const bool gcb = use_gcb(c);
-    const bool agb = gcb && B <= 256;           // per-graph attention backward (two workgroups per graph: one wave of the chip)
+    const bool agb = gcb && T <= 256;           // per-graph attention backward (two workgroups per graph: one wave of the chip)
     // P1. add-pool backward + ReLU of the causal/trivial convs + their bias gradients
     // (per-graph fused backward: both are built while k_gconv_bwd stages dOut, and it emits gn / gself as well)
     if (!gcb) {
@@ -1254,7 +1265,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             gb[k].gn = e->gn + (size_t)k * E; gb[k].gself = e->gself + (size_t)k * N;
             gb[k].gn_stride = 2 * (size_t)E; gb[k].gself_stride = 2 * (size_t)N;
             Deferred& db = k ? d_ob : d_cb;
-            db.p = parts_alloc(c, (size_t)B * H); db.P = B; db.stride = H;
+            db.p = parts_alloc(c, (size_t)T * H); db.P = T; db.stride = H;
             if (!db.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
             gb[k].bias_parts = db.p;
             gb[k].ew = e->att + (size_t)k * E; gb[k].dis = e->dis_co + (size_t)k * N;
@@ -1317,7 +1328,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             ag.loop_w = e->loop_w; ag.E = E; ag.N = N; ag.status = e->status;
             RC(with_g(H, [&](auto g) {
                 constexpr int G = decltype(g)::value;
-                hipLaunchKernelGGL((k_att_bwd_graph<4, G>), dim3(ag_split * B), dim3(512), 0, st, ag, 1, H, ag_split);
+                hipLaunchKernelGGL((k_att_bwd_graph<4, G>), dim3(ag_split * T), dim3(512), 0, st, ag, 1, H, ag_split);
                 return 0;
             }));
             CAL_CHECK_LAUNCH("k_att_bwd_graph"); STAGE();
@@ -1431,27 +1442,27 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                 ga.y = e->h + (size_t)i * NH;
                 ga.ubn = bnref(c, i + 1, N, 0); ga.udot_sum = bn_dsum(c, i + 1); ga.udot_prod = bn_dprod(c, i + 1);
                 Deferred& db = d_convb[i - 1];
-                db.p = parts_alloc(c, (size_t)B * H); db.P = B; db.stride = H;
+                db.p = parts_alloc(c, (size_t)T * H); db.P = T; db.stride = H;
                 if (!db.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
                 ga.bias_parts = db.p;
             }
-            const size_t need_w = (size_t)B * H * H, need_a = (size_t)B * 2 * H;
+            const size_t need_w = (size_t)T * H * H, need_a = (size_t)T * 2 * H;
             if (slab_off + need_w + need_a > e->slab_floats || fa.nst + 2 > MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
             ga.slab = e->slabs + slab_off;
-            fa.st[fa.nst++] = SlabTask{ga.slab, e->G + e->o_conv_w[i - 1], H * H, B};
+            fa.st[fa.nst++] = SlabTask{ga.slab, e->G + e->o_conv_w[i - 1], H * H, T};
             slab_off += need_w;
             ga.att_slab = e->slabs + slab_off;
-            fa.st[fa.nst++] = SlabTask{ga.att_slab, e->G + e->o_conv_att[i - 1], 2 * H, B};
+            fa.st[fa.nst++] = SlabTask{ga.att_slab, e->G + e->o_conv_att[i - 1], 2 * H, T};
             slab_off += need_a;
-            double* pp = parts_alloc(c, (size_t)B * nsl * 2 * H);
+            double* pp = parts_alloc(c, (size_t)T * nsl * 2 * H);
             if (!pp) { set_error("engine: partial-row workspace exhausted"); return 2; }
             ga.dot_parts = pp;
-            final_task(c, pp, B * nsl, 2 * H, H, bn_dsum(c, i));
-            final_task(c, pp + H, B * nsl, 2 * H, H, bn_dprod(c, i));
+            final_task(c, pp, T * nsl, 2 * H, H, bn_dsum(c, i));
+            final_task(c, pp + H, T * nsl, 2 * H, H, bn_dprod(c, i));
             {
                 ProfScope ps(st, 8, 4.0 * N * H * H + 4.0 * (double)(c.E + N) * H, true);
-                if (i == L) PROF_LAUNCH((k_ggat_bwd<false>), dim3(B, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
-                else PROF_LAUNCH((k_ggat_bwd<true>), dim3(B, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+                if (i == L) PROF_LAUNCH((k_ggat_bwd<false>), dim3(T, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+                else PROF_LAUNCH((k_ggat_bwd<true>), dim3(T, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
             }
             CAL_CHECK_LAUNCH("k_ggat_bwd"); STAGE();
             RC(flush_finals(c)); STAGE();
@@ -1462,15 +1473,15 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                 fb.dy0 = p0; fb.dy1 = H > GC_N ? dzi : nullptr; fb.y = hin;
                 fb.ubn = bnref(c, 1, N, 0); fb.udot_sum = bn_dsum(c, 1); fb.udot_prod = bn_dprod(c, 1);
                 fb.x0 = x0; fb.W = e->P + e->o_feat_w; fb.bn0 = bnref(c, 0, N, 0);
-                const size_t need = (size_t)B * F * H;
+                const size_t need = (size_t)T * F * H;
                 if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
                 fb.slab = e->slabs + slab_off;
-                fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, B};
+                fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, T};
                 slab_off += need;
-                d_bn0.p = parts_alloc(c, (size_t)B * 2 * F); d_bn0.P = B; d_bn0.stride = 2 * F;
+                d_bn0.p = parts_alloc(c, (size_t)T * 2 * F); d_bn0.P = T; d_bn0.stride = 2 * F;
                 if (!d_bn0.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
                 fb.parts = d_bn0.p;
-                hipLaunchKernelGGL(k_feat_bwd, dim3(B), dim3(GB_NT), 0, st, e->gptr, fb, H, F, e->status);
+                hipLaunchKernelGGL(k_feat_bwd, dim3(T), dim3(GB_NT), 0, st, e->gptr, fb, H, F, e->status);
                 CAL_CHECK_LAUNCH("k_feat_bwd"); STAGE();
                 feat_done = true;
             } else if (i == 1) {       // the feature layer below is a plain GEMM: materialise dZ for it
@@ -1502,7 +1513,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                 gb.y = e->h + (size_t)i * NH;
                 gb.ubn = bnref(c, i + 1, N, 0); gb.udot_sum = bn_dsum(c, i + 1); gb.udot_prod = bn_dprod(c, i + 1);
                 Deferred& db = d_convb[i - 1];  // bias of conv i: column sums of dOut, one partial row per graph
-                db.p = parts_alloc(c, (size_t)B * H); db.P = B; db.stride = H;
+                db.p = parts_alloc(c, (size_t)T * H); db.P = T; db.stride = H;
                 if (!db.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
                 gb.bias_parts = db.p;
             }
@@ -1517,15 +1528,15 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                 fb.dy0 = p0; fb.dy1 = H > GC_N ? dzi : nullptr; fb.y = hin;
                 fb.ubn = bnref(c, 1, N, 0); fb.udot_sum = bn_dsum(c, 1); fb.udot_prod = bn_dprod(c, 1);
                 fb.x0 = x0; fb.W = e->P + e->o_feat_w; fb.bn0 = bnref(c, 0, N, 0);
-                const size_t need = (size_t)B * F * H;
+                const size_t need = (size_t)T * F * H;
                 if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
                 fb.slab = e->slabs + slab_off;
-                fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, B};
+                fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, T};
                 slab_off += need;
-                d_bn0.p = parts_alloc(c, (size_t)B * 2 * F); d_bn0.P = B; d_bn0.stride = 2 * F;
+                d_bn0.p = parts_alloc(c, (size_t)T * 2 * F); d_bn0.P = T; d_bn0.stride = 2 * F;
                 if (!d_bn0.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
                 fb.parts = d_bn0.p;
-                hipLaunchKernelGGL(k_feat_bwd, dim3(B), dim3(GB_NT), 0, st, e->gptr, fb, H, F, e->status);
+                hipLaunchKernelGGL(k_feat_bwd, dim3(T), dim3(GB_NT), 0, st, e->gptr, fb, H, F, e->status);
                 CAL_CHECK_LAUNCH("k_feat_bwd"); STAGE();
                 feat_done = true;
             } else if (i == 1) {       // the feature layer below is a plain GEMM: materialise dZ for it
@@ -1703,6 +1714,12 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     CAL_REQUIRE(N > 0 && B > 0, "empty batch");
     Ctx c;
     c.e = e; c.st = (hipStream_t)stream_; c.N = (int)N; c.B = (int)B; c.E = E;
+    CAL_REQUIRE(e->ntiles <= B, "more tiles than graphs (cal_engine_set_tiles belongs to another batch)");
+    c.T = e->ntiles > 0 ? e->ntiles : (int)B;
+    c.batch = batch;
+    CAL_REQUIRE(e->ntiles == 0 || (e->H % GC_N == 0 && e->H <= GC_K && e->node_ptr && e->edge_ptr && e->max_nodes > 0 && e->max_nodes <= 64 &&
+                                   e->max_edges <= gc_edge_cap(64)),
+                "cal_engine_set_tiles needs the per-graph kernels: hidden in {64, 128}, the tiles' offsets (cal_engine_set_graph_ptrs) and bounds <= 64 nodes / 1024 edges");
     c.training = (mode & 1) ? 1 : 0;
     c.rpb_n = std::max(32, cdiv(N, 1024));
     c.rpb_b = std::max(32, cdiv(B, 64));
@@ -1753,6 +1770,9 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
     CAL_REQUIRE(N <= e->capN && E <= e->capE && B <= e->capB && N > 0 && B > 0, "bad batch sizes");
     Ctx c;
     c.e = e; c.st = (hipStream_t)stream_; c.N = (int)N; c.B = (int)B; c.E = E;
+    CAL_REQUIRE(e->ntiles <= B, "more tiles than graphs (cal_engine_set_tiles belongs to another batch)");
+    c.T = e->ntiles > 0 ? e->ntiles : (int)B;
+    c.batch = batch;
     c.training = 1;
     c.rpb_n = std::max(32, cdiv(N, 1024));
     c.rpb_b = std::max(32, cdiv(B, 64));
@@ -1785,6 +1805,19 @@ CAL_EXPORT int cal_engine_set_graph_ptrs(void* h, const int64_t* node_ptr, const
     Engine* e = (Engine*)h;
     CAL_REQUIRE(e != nullptr, "bad arguments");
     e->node_ptr = node_ptr; e->edge_ptr = edge_ptr;
+    return 0;
+}
+// Small-graph packing.  The per-graph kernels give every workgroup a 64-row MFMA tile; a batch of ~30-node graphs (NCI1,
+// MUTAG: BASELINE.json configs[2..3]) leaves half of it empty and launches twice the workgroups.  A batch is a disjoint union,
+// so any run of CONSECUTIVE graphs is itself a block-diagonal graph: the caller groups consecutive graphs into tiles
+// (<= 64 nodes, <= 1024 edges, <= 8 graphs each), passes the TILES' node / edge offsets and bounds through
+// cal_engine_set_graph_ptrs / cal_engine_set_graph_bounds, and here the first graph of every tile: tile_gptr [ntiles + 1]
+// (device int64, tile_gptr[ntiles] = B; alive until the step has run).  Only the add-pool and its backward look at graphs
+// inside a tile (model.py:115-116).  ntiles = 0 / null: one graph per workgroup.
+CAL_EXPORT int cal_engine_set_tiles(void* h, const int64_t* tile_gptr, int64_t ntiles) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e != nullptr && ntiles >= 0 && (ntiles == 0 || tile_gptr != nullptr), "bad arguments");
+    e->tile_gptr = ntiles > 0 ? tile_gptr : nullptr; e->ntiles = (int)ntiles;
     return 0;
 }
 CAL_EXPORT int cal_engine_debug_stop(int k) { g_stop_after = k; return 0; }

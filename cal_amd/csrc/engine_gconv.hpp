@@ -52,7 +52,12 @@ struct GconvBranch {
     const float* coef_in;
     float* coef_out;
     float* w_out;            // with coef_out: the raw edge weights w_e in CSR-slot order (read by the per-graph attention backward), or null
+    // packed batch (TILED instantiation, cal_engine_set_tiles): the workgroup's unit is a tile of the consecutive graphs
+    // [tile_gptr[b], tile_gptr[b + 1]) and `pooled` is per GRAPH: batch [N] names the graph of every row
+    const int64_t* batch;
+    const int64_t* tile_gptr;
 };
+constexpr int GC_TILE_GRAPHS = 8;         // graphs per tile at most (the POOL backward keeps one pooled-gradient row per graph in LDS)
 
 struct GconvBranch2 { GconvBranch b[2]; };
 
@@ -180,7 +185,7 @@ __device__ __forceinline__ void gconv_mma_rowk(const float* At, const float* Zt,
     }
 }
 
-template <bool RS, int T, int NT = 256>
+template <bool RS, int T, int NT = 256, bool TILED = false>
 __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBranch2 bb, int relu, float loop_w, int H,
                                                    int K, int* __restrict__ status) {
@@ -200,6 +205,7 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
     __shared__ signed char er[ECAP];
     __shared__ double red[4][2][32];
     __shared__ float pool_s[4][32];
+    __shared__ unsigned char bg_s[TILED ? T : 4];        // TILED: graph (inside the tile) of every row
     BLK_CLK(0);
     warm_kernargs<sizeof(CSR) + 2 * sizeof(void*) + sizeof(GconvBranch2) + 32>();
     const GconvBranch& br = bb.b[blockIdx.z];           // indexed in the kernel-argument segment: one set of scalar loads (b0 / b1 as two parameters were loaded both and selected field by field)
@@ -212,15 +218,17 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
         vb[u] = *reinterpret_cast<const float4*>(br.W + (size_t)k * H + n0 + 4 * j4);
     }
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
+    const int tg0 = TILED ? (int)br.tile_gptr[b] : b, ng = TILED ? (int)br.tile_gptr[b + 1] - tg0 : 1;
     const bool want = br.st_sum.on();
     if (rows <= 0) {                                     // empty graph: its partial rows still have to exist
         if (br.bn.update && blockIdx.x == 0 && blockIdx.y == 0 && t < K) bn_update_running(br.bn, t);
         if (t < GC_N) {
             if (want) { br.st_sum.add(n0 + t, 0.0); br.st_sq.add(n0 + t, 0.0); }
-            if (br.pooled) br.pooled[(size_t)b * H + n0 + t] = 0.f;
+            if (br.pooled) for (int q = 0; q < ng; ++q) br.pooled[(size_t)(tg0 + q) * H + n0 + t] = 0.f;
         }
         return;
     }
+    if (TILED && (ng < 1 || ng > GC_TILE_GRAPHS)) { if (t == 0) atomicOr(status, 8); return; }
     if (rows > T || ne > ECAP || ne < 0) {            // the host's bounds were wrong: flag it, write nothing
         if (t == 0) atomicOr(status, 8);
         return;
@@ -246,6 +254,8 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
     }
     const int pv = g.ptr[g0 + min(t, rows)];
     const float dv = br.dis[g0 + min(t, rows - 1)];
+    long long bgv = 0;
+    if (TILED) bgv = br.batch[g0 + min(t, rows - 1)];
     float rsv[4] = {1.f, 1.f, 1.f, 1.f};                 // row scale of this lane's x row in each RPP-row block
     if (RS) {
 #pragma unroll
@@ -310,6 +320,7 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
     // ---- stage everything in LDS ---------------------------------------------------------------------------
     if (t <= rows) ptr_s[t] = pv - e0;
     if (t < rows) dis_s[t] = dv;
+    if (TILED && t < rows) bg_s[t] = (unsigned char)min(max((int)(bgv - tg0), 0), ng - 1);
 #pragma unroll
     for (int u = 0; u < CU; ++u) {
         const int s = t + u * NT;
@@ -447,6 +458,11 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
     float psum = 0.f;
     const int col = n0 + ct * 32 + li;
     asm volatile("" :: "v"(bias));                       // consume the bias load before the guarded stores (see gemm.hip)
+    // TILED: the add-pool is per graph, several graphs share the tile: the output tile is parked in LDS (over the adjacency
+    // block, once every wave has finished reading it) and summed per graph below, rows in order
+    constexpr int LDO = GC_N + 1;
+    float* Ot = As;
+    if (TILED) __syncthreads();
     if (own && r0 < R) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -455,6 +471,7 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
             if (relu) v = fmaxf(v, 0.f);
             if (row < rows) br.out[(size_t)(g0 + row) * H + col] = v;
             const float vm = row < rows ? v : 0.f;
+            if (TILED) Ot[row * LDO + ct * 32 + li] = vm;
             f1[r & 3] += vm; f2[r & 3] = fmaf(vm, vm, f2[r & 3]);
         }
         if (r0 + 2 < R) {
@@ -465,6 +482,7 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
                 if (relu) v = fmaxf(v, 0.f);
                 if (row < rows) br.out[(size_t)(g0 + row) * H + col] = v;
                 const float vm = row < rows ? v : 0.f;
+                if (TILED) Ot[row * LDO + ct * 32 + li] = vm;
                 f1[r & 3] += vm; f2[r & 3] = fmaf(vm, vm, f2[r & 3]);
             }
         }
@@ -483,7 +501,21 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
             br.st_sum.add(col, red[w][0][li] + red[w + 2][0][li]);
             br.st_sq.add(col, red[w][1][li] + red[w + 2][1][li]);
         }
-        if (br.pooled) br.pooled[(size_t)b * H + col] = pool_s[w][li] + pool_s[w + 2][li];
+        if (!TILED && br.pooled) br.pooled[(size_t)b * H + col] = pool_s[w][li] + pool_s[w + 2][li];
+    }
+    if (TILED && br.pooled && t < GC_N) {
+        // one lane per column walks the tile's rows in order and closes a pooled row whenever the graph changes; graphs
+        // without nodes keep the zero written first (same lane, same address: program order)
+        float* pp = br.pooled + (size_t)tg0 * H + n0 + t;
+        for (int q = 0; q < ng; ++q) pp[(size_t)q * H] = 0.f;
+        float sum = 0.f;
+        int cur = bg_s[0];
+        for (int r = 0; r < rows; ++r) {
+            const int gq = bg_s[r];
+            if (gq != cur) { pp[(size_t)cur * H] = sum; sum = 0.f; cur = gq; }
+            sum += Ot[r * LDO + t];
+        }
+        pp[(size_t)cur * H] = sum;
     }
     RO_CLK(39);
     BLK_CLK(1);

@@ -60,6 +60,10 @@ struct GconvBwdBranch {
     float* gn; float* gself; // this branch's [E] / [N] partials of slice 0; slice 1 is gn_stride / gself_stride further
     size_t gn_stride, gself_stride;
     int gn_slot;             // gn is written in CSR-slot order (gn[eptr[b] + s], for the per-graph attention backward) instead of edge-id order
+    // packed batch (TILED instantiation of the POOL variant, cal_engine_set_tiles): the unit is a tile of the consecutive
+    // graphs [tile_gptr[b], tile_gptr[b + 1]); gp0 / gp1 / iperm are per GRAPH, batch [N] names the graph of every row
+    const int64_t* batch;
+    const int64_t* tile_gptr;
 };
 
 struct GconvBwdBranch2 { GconvBwdBranch b[2]; };
@@ -155,7 +159,7 @@ __device__ __forceinline__ void gb_mma_rowk2(const float* a0_row, const float* a
     }
 }
 
-template <bool RS, int MODE>      // MODE 0: dOut given; 1: UP (from the upper layer's partials); 2: POOL (+ gn / gself)
+template <bool RS, int MODE, bool TILED = false>      // MODE 0: dOut given; 1: UP (from the upper layer's partials); 2: POOL (+ gn / gself)
 __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBwdBranch2 bb, float loop_w, int N, int H,
                                                    int K, int* __restrict__ status) {
@@ -171,21 +175,24 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     __shared__ float um_s[GC_N], ur_s[GC_N], ug_s[GC_N], u1_s[GC_N], u2_s[GC_N];     // upper BatchNorm, this slice's columns
     __shared__ float bs_s[GB_NT / 64][16][4];
     __shared__ __attribute__((aligned(16))) float Zr[MODE == 2 ? GB_T * GB_LDD : 4];       // POOL: z slice rows [j][n]
-    __shared__ float gv_s[GC_N];                         // POOL: gradient of this graph's pooled row, slice columns
+    __shared__ float gv_s[TILED ? GC_TILE_GRAPHS * GC_N : GC_N];   // POOL: gradient of this graph's pooled row (TILED: of every graph of the tile), slice columns
+    __shared__ unsigned char bg_s[TILED ? GB_T : 4];     // TILED: graph (inside the tile) of every row
     __shared__ int ee[MODE == 2 ? GB_E : 1];             // POOL: edge id of CSR slot s
     __shared__ short er[GB_E];                           // destination row of CSR slot s
     constexpr bool UP = MODE == 1, POOL = MODE == 2;
+    static_assert(!TILED || MODE == 2, "only the POOL variant looks at the graphs inside a tile");
     BLK_CLK(0);
     warm_kernargs<sizeof(CSR) + 2 * sizeof(void*) + sizeof(GconvBwdBranch2) + 32>();
     const GconvBwdBranch& br = bb.b[blockIdx.z];         // indexed in the kernel-argument segment (see k_gconv_fwd)
     const int b = blockIdx.x, sl = blockIdx.y, ns0 = sl * GC_N, t = threadIdx.x;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
-    const int pb = (MODE == 2 && br.iperm) ? br.iperm[b] : b;         // row of the second pooled-gradient partial (scalar load, with the extents)
+    const int pb = (MODE == 2 && !TILED && br.iperm) ? br.iperm[b] : b;         // row of the second pooled-gradient partial (scalar load, with the extents)
+    const int tg0 = TILED ? (int)br.tile_gptr[b] : b, ng = TILED ? (int)br.tile_gptr[b + 1] - tg0 : 1;
     const int lane = t & 63, li = lane & 31, lk = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     double* parts = br.dot_parts + ((size_t)sl * gridDim.x + b) * (2 * K);
     float* slab = br.slab + (size_t)b * K * H;
-    if (rows <= 0 || rows > GB_T || ne > GB_E || ne < 0) {
+    if (rows <= 0 || rows > GB_T || ne > GB_E || ne < 0 || (TILED && (ng < 1 || ng > GC_TILE_GRAPHS))) {
         // empty graph (or a violated bound, flagged): its partial row and its slab slice must still exist
         if (rows > 0 && t == 0) atomicOr(status, 8);
         for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
@@ -200,13 +207,20 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     RoBatch<float4, 4> bx, bw;                           // x[g0 + i][4 k4 ..]: rows x K/4;  W[k_in][ns0 + 4 n4 ..]: K x 16
     RoBatch<float4, 2> bz;                               // POOL: z[g0 + j][ns0 + 4 n4 ..]
     float gv = 0.f, gv1 = 0.f;
+    int pbq = 0;
+    long long bgv = 0;
     if (POOL) {
         ro_issue<GB_NT>(by, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(br.y + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
         ro_issue<GB_NT>(bz, rows, 16, [&](int j, int n4) { return *reinterpret_cast<const float4*>(br.z + (size_t)(g0 + j) * H + ns0 + 4 * n4); });
-        {   // gradient of this graph's pooled row, slice columns: both partials unconditionally (gp1 absent: gp0 twice, weight 0)
+        if (!TILED) {   // gradient of this graph's pooled row, slice columns: both partials unconditionally (gp1 absent: gp0 twice, weight 0)
             const float* gp1 = br.gp1 ? br.gp1 : br.gp0;
             gv = br.gp0[(size_t)b * H + ns0 + (t & (GC_N - 1))];
             gv1 = gp1[(size_t)pb * H + ns0 + (t & (GC_N - 1))];
+        } else {        // lane (q = t / 64, column t % 64): graph tg0 + q of the tile; the permuted row's index is a load of its own
+            const int gq = tg0 + min(t >> 6, ng - 1);
+            gv = br.gp0[(size_t)gq * H + ns0 + (t & (GC_N - 1))];
+            pbq = br.iperm ? br.iperm[gq] : gq;
+            bgv = br.batch[g0 + min(t, rows - 1)];
         }
     } else {
         const float* d0 = UP ? br.dy0 : br.dout;
@@ -249,7 +263,12 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     if (UP) { bn_raw_pin(uraw); asm volatile("" : "+v"(ud1), "+v"(ud2)); }
 #pragma unroll
     for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]), "+v"(cin[u]));
-    if (POOL) { asm volatile("" : "+v"(gv), "+v"(gv1)); gv += br.gp1 ? gv1 : 0.f; }
+    if (POOL && !TILED) { asm volatile("" : "+v"(gv), "+v"(gv1)); gv += br.gp1 ? gv1 : 0.f; }
+    if (TILED) {                                         // second round: the permuted graph's pooled-gradient row
+        asm volatile("" : "+v"(gv), "+v"(pbq), "+v"(bgv));
+        const float* gp1 = br.gp1 ? br.gp1 : br.gp0;
+        gv1 = gp1[(size_t)pbq * H + ns0 + (t & (GC_N - 1))];
+    }
     if (ne <= 0) { nv[0] = g0; nv[1] = g0; ev[0] = 0; ev[1] = 0; }   // no slot of this graph exists: the clamped loads fetched no index
     if (UP && t >= 256 && t < 256 + GC_N) {
         float m1, r1;
@@ -297,7 +316,11 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
             if (!inb) atomicOr(status, 16);
         }
     }
-    if (POOL && t < GC_N) gv_s[t] = gv;
+    if (POOL && !TILED && t < GC_N) gv_s[t] = gv;
+    if (TILED) {
+        if (t < ng * GC_N) gv_s[t] = gv + (br.gp1 ? gv1 : 0.f);
+        if (t < rows) bg_s[t] = (unsigned char)min(max((int)(bgv - tg0), 0), ng - 1);
+    }
     if (MODE == 0) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
     ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) { *reinterpret_cast<float4*>(Ws + k * GB_LDD + 4 * n4) = v; });
     __syncthreads();                                     // per-column BN constants, row scales, zeroed Ab, CSR
@@ -318,8 +341,9 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
             const int j = (t >> 4) + u * (GB_NT / 16);
             if (j < rows) {
                 const float4 yv = by.v[u];
-                const float4 o = make_float4(yv.x > 0.f ? gv_s[c] : 0.f, yv.y > 0.f ? gv_s[c + 1] : 0.f,
-                                             yv.z > 0.f ? gv_s[c + 2] : 0.f, yv.w > 0.f ? gv_s[c + 3] : 0.f);
+                const float* gvr = gv_s + (TILED ? bg_s[j] * GC_N : 0);
+                const float4 o = make_float4(yv.x > 0.f ? gvr[c] : 0.f, yv.y > 0.f ? gvr[c + 1] : 0.f,
+                                             yv.z > 0.f ? gvr[c + 2] : 0.f, yv.w > 0.f ? gvr[c + 3] : 0.f);
                 cs[0] += o.x; cs[1] += o.y; cs[2] += o.z; cs[3] += o.w;
                 *reinterpret_cast<float4*>(Ds + j * GB_LDD + c) = o;
                 *reinterpret_cast<float4*>(Zr + j * GB_LDD + c) = bz.v[u];

@@ -24,7 +24,8 @@ constexpr int GP_E2 = 2048;               // node_num = 15: up to ~250 nodes per
 template <int GT, int GE>
 __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ ei, int64_t E, int N, int B,
                                                     const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr,
-                                                    const int64_t* __restrict__ batch, float loop_w,
+                                                    const int64_t* __restrict__ batch, const int64_t* __restrict__ tile_gptr,
+                                                    int Bgraphs, float loop_w,
                                                     int* __restrict__ ptr_dst, int* __restrict__ nbr_dst, int* __restrict__ eid_dst,
                                                     int* __restrict__ ptr_src, int* __restrict__ nbr_src, int* __restrict__ eid_src,
                                                     int* __restrict__ row32, int* __restrict__ col32, int* __restrict__ gptr,
@@ -39,8 +40,13 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     __shared__ int deg_in[GT], deg_out[GT], off_in[GT + 1], off_out[GT + 1], cur_in[GT], cur_out[GT];
     __shared__ short rl[GE], cl[GE];                     // local endpoints of the graph's edges (edge-id order)
     __shared__ short tn_d[GE], te_d[GE], tn_s[GE], te_s[GE];             // unordered row contents: neighbour, local edge id
+    __shared__ int gid_s[GT];                            // packed batch: graph of every row of the tile
     BLK_CLK(0);
     const int b = blockIdx.x, t = threadIdx.x;
+    // packed batch (cal_engine_set_tiles): this workgroup's unit is a TILE of the consecutive graphs [tg0, tg1); node_ptr /
+    // edge_ptr are the tiles' offsets.  The batch vector must stay inside [tg0, tg1), sorted, and no edge may join two graphs
+    const int64_t tg0 = tile_gptr ? tile_gptr[b] : (int64_t)b, tg1 = tile_gptr ? tile_gptr[b + 1] : (int64_t)b + 1;
+    if (tile_gptr && t == 0 && ((b == 0 && tg0 != 0) || (b == B - 1 && tg1 != Bgraphs) || tg1 < tg0)) atomicOr(status, 2);
     const int g0 = (int)node_ptr[b], rows = (int)node_ptr[b + 1] - g0;
     const int64_t e0 = edge_ptr[b];
     const int m = (int)(edge_ptr[b + 1] - e0);
@@ -60,7 +66,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
         cv[u] = m > 0 ? ei[E + e] : 0;
     }
     const int64_t bv = rows > 0 ? batch[g0 + min(t, rows - 1)] : (int64_t)b;
-    if (t < GT) { deg_in[t] = 0; deg_out[t] = 0; cur_in[t] = 0; cur_out[t] = 0; }
+    if (t < GT) { deg_in[t] = 0; deg_out[t] = 0; cur_in[t] = 0; cur_out[t] = 0; gid_s[t] = (int)(bv - tg0); }
     if (t < 128) fs[t >> 6][t & 63] = 0.0;
     __syncthreads();
     if (x0) {
@@ -86,7 +92,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
             atomicAdd(&fs[1][t % F], (double)s2);
         }
     }
-    if (t < rows && bv != b) atomicOr(status, 2);
+    if (t < rows && (bv < tg0 || bv >= tg1 || (t > 0 && gid_s[t - 1] > gid_s[t]))) atomicOr(status, 2);
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
         const int s = t + u * 256;
@@ -95,6 +101,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
             const bool bad = r < 0 || r >= rows || c < 0 || c >= rows;
             if (bad) { atomicOr(status, 1); r = 0; c = 0; }
             if (r == c) atomicOr(status, bad ? 1 : 32);
+            if (gid_s[r] != gid_s[c]) atomicOr(status, 16);              // an edge between two graphs of the tile: not a mini-batch
             rl[s] = (short)r; cl[s] = (short)c;
             row32[e0 + s] = g0 + r; col32[e0 + s] = g0 + c;
             atomicAdd(&deg_out[r], 1);

@@ -24,6 +24,57 @@ import torch
 _NODE_KEYS = ("x", "feat")
 
 
+# Small-graph packing (cal_engine_set_tiles): the step engine's per-graph kernels give every workgroup a 64-row tile; a batch
+# whose graphs average <= 40 nodes (NCI1, MUTAG, ...) is grouped into tiles of CONSECUTIVE graphs -- each a block-diagonal
+# graph of its own -- with these bounds (engine_gconv.hpp: 64-node variant, GC_TILE_GRAPHS)
+TILE_NODES, TILE_EDGES, TILE_GRAPHS = 64, 1024, 8
+
+
+def pack_tiles(node_sizes, edge_sizes):
+    """Greedy grouping of consecutive graphs into tiles; returns the list of first-graph indices [T + 1] or None when
+    packing does not apply (large graphs) or gains nothing."""
+    nl = node_sizes.tolist() if hasattr(node_sizes, "tolist") else list(node_sizes)
+    el = edge_sizes.tolist() if hasattr(edge_sizes, "tolist") else list(edge_sizes)
+    B = len(nl)
+    if B < 2 or sum(nl) > 40 * B:
+        return None
+    first, cn, ce, cg = [0], 0, 0, 0
+    for i in range(B):
+        a, b = nl[i], el[i]
+        if a > TILE_NODES or b > TILE_EDGES:
+            return None
+        if cg and (cn + a > TILE_NODES or ce + b > TILE_EDGES or cg >= TILE_GRAPHS):
+            first.append(i)
+            cn = ce = cg = 0
+        cn += a
+        ce += b
+        cg += 1
+    first.append(B)
+    return first if len(first) - 1 < B else None
+
+
+def pack_order(node_sizes, edge_sizes):
+    """Order of the graphs of a mini-batch that fills the tiles best (first-fit decreasing, ``cal_pack_order``): returns
+    (order [B] positions, first [T + 1]) as Python lists, or None when packing does not apply.  A mini-batch is a set --
+    the loss is a mean over it and the intervention permutation is random -- so the order inside it is the loader's to
+    choose; ``pack_tiles`` of the reordered batch then finds (at least) these tiles."""
+    import ctypes
+    import numpy as np
+    from . import _lib
+    n = np.ascontiguousarray(node_sizes, dtype=np.int64)
+    e = np.ascontiguousarray(edge_sizes, dtype=np.int64)
+    B = int(n.shape[0])
+    if B < 2 or int(n.sum()) > 40 * B:
+        return None
+    order = np.empty(B, dtype=np.int64)
+    first = np.empty(B + 1, dtype=np.int64)
+    T = _lib.query("cal_pack_order", n.ctypes.data_as(ctypes.c_void_p), e.ctypes.data_as(ctypes.c_void_p), B, TILE_NODES,
+                   TILE_EDGES, TILE_GRAPHS, order.ctypes.data_as(ctypes.c_void_p), first.ctypes.data_as(ctypes.c_void_p))
+    if T <= 0 or T >= B:
+        return None
+    return order, first[:T + 1]
+
+
 class Data:
     def __init__(self, x=None, edge_index=None, y=None, feat=None, **kw):
         self.x = x
@@ -90,9 +141,29 @@ class Batch(Data):
         # [edge_ptr[b], edge_ptr[b+1]); no edge is a self loop): they select the engine's one-kernel CSR build
         self.edge_ptr = None
         self.no_self_loops = False
+        # small-graph packing (pack_tiles): first graph / node offset / edge offset of every tile ([T + 1] each) and the
+        # largest tile; None when the batch is not packed
+        self.tile_ptr = self.tile_node_ptr = self.tile_edge_ptr = None
+        self.tile_max_nodes = self.tile_max_edges = 0
+
+    def set_tiles(self, first, node_off, edge_off):
+        """Record a packing: ``first`` [T + 1] graph indices, ``node_off`` / ``edge_off`` [B + 1] offsets (host sequences)."""
+        tn = [int(node_off[i]) for i in first]
+        te = [int(edge_off[i]) for i in first]
+        self.tile_ptr = torch.tensor(first, dtype=torch.long)
+        self.tile_node_ptr = torch.tensor(tn, dtype=torch.long)
+        self.tile_edge_ptr = torch.tensor(te, dtype=torch.long)
+        self.tile_max_nodes = max(b - a for a, b in zip(tn[:-1], tn[1:]))
+        self.tile_max_edges = max(b - a for a, b in zip(te[:-1], te[1:]))
 
     @staticmethod
-    def from_data_list(data_list: Sequence[Data]) -> "Batch":
+    def from_data_list(data_list: Sequence[Data], pack: bool = False) -> "Batch":
+        """``pack``: reorder the graphs so that runs of consecutive small graphs fill the engine's 64-node tiles
+        (``pack_order``; the batch is the same set of graphs)."""
+        if pack and len(data_list) > 1:
+            po = pack_order([d.num_nodes for d in data_list], [int(d.edge_index.size(1)) for d in data_list])
+            if po is not None:
+                data_list = [data_list[int(i)] for i in po[0]]
         b = Batch()
         xs, feats, eis, ys, bvec, ptr = [], [], [], [], [], [0]
         off = 0
@@ -122,6 +193,10 @@ class Batch(Data):
             eptr.append(eptr[-1] + int(d.edge_index.size(1)))
         b.edge_ptr = torch.tensor(eptr, dtype=torch.long)
         b.no_self_loops = bool(b.edge_index.numel() == 0 or (b.edge_index[0] != b.edge_index[1]).all().item())
+        if b.no_self_loops:
+            first = pack_tiles([q - p for p, q in zip(ptr[:-1], ptr[1:])], [q - p for p, q in zip(eptr[:-1], eptr[1:])])
+            if first is not None:
+                b.set_tiles(first, ptr, eptr)
         return b
 
     @property

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .data import Batch, shard_indices
+from .data import Batch, pack_order, pack_tiles, shard_indices
 from .plan import _p, _stream
 
 
@@ -44,16 +44,29 @@ class DeviceDataset:
     def __len__(self):
         return self.G
 
-    def collate(self, idx) -> Batch:
-        """Assemble the mini-batch of graphs ``idx`` (host int sequence / numpy / CPU tensor) on the GPU."""
+    def collate(self, idx, pack: bool = False) -> Batch:
+        """Assemble the mini-batch of graphs ``idx`` (host int sequence / numpy / CPU tensor) on the GPU.  ``pack``: the
+        graphs may be reordered inside the batch so that consecutive small graphs fill the engine's 64-node tiles
+        (data.pack_order: same set of graphs, another order)."""
         idx = np.asarray(idx, dtype=np.int64)
         B = int(idx.shape[0])
         n, e = self.node_sizes[idx], self.edge_sizes[idx]
+        first = None
+        if pack and self.no_self_loops:
+            po = pack_order(n, e)
+            if po is not None:
+                idx = idx[po[0]]
+                n, e = self.node_sizes[idx], self.edge_sizes[idx]
+                first = po[1].tolist()
         noff = np.concatenate([[0], np.cumsum(n)])
         eoff = np.concatenate([[0], np.cumsum(e)])
         N, E = int(noff[-1]), int(eoff[-1])
-        # one pinned staging buffer for [sel | node offsets | edge offsets]
-        need = 3 * B + 2
+        # small-graph packing: tiles of consecutive graphs for the engine's per-graph kernels (data.pack_tiles)
+        if first is None and self.no_self_loops:
+            first = pack_tiles(n, e)
+        T1 = len(first) if first is not None else 0
+        # one pinned staging buffer for [sel | node offsets | edge offsets | tile first graph | tile node off | tile edge off]
+        need = 3 * B + 2 + 3 * T1
         if not self._pin or self._pin[0][0].numel() < need:
             self._pin = [[torch.empty(max(need, 4096), dtype=torch.long).pin_memory(), None] for _ in range(16)]
         slot = self._pin[self._pin_i]
@@ -63,7 +76,14 @@ class DeviceDataset:
         host = slot[0][:need]
         host[:B] = torch.from_numpy(np.ascontiguousarray(idx))
         host[B:2 * B + 1] = torch.from_numpy(noff)
-        host[2 * B + 1:] = torch.from_numpy(eoff)
+        host[2 * B + 1:3 * B + 2] = torch.from_numpy(eoff)
+        if T1:
+            fi = np.asarray(first, dtype=np.int64)
+            tn, te = noff[fi], eoff[fi]
+            o = 3 * B + 2
+            host[o:o + T1] = torch.from_numpy(fi)
+            host[o + T1:o + 2 * T1] = torch.from_numpy(tn)
+            host[o + 2 * T1:o + 3 * T1] = torch.from_numpy(te)
         meta = host.to(self.device, non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()
@@ -85,6 +105,10 @@ class DeviceDataset:
         b.ptr = meta[B:2 * B + 1]                 # node / edge offsets per graph, already on the device for cal_collate
         b.edge_ptr = meta[2 * B + 1:3 * B + 2]
         b.no_self_loops = self.no_self_loops
+        if T1:
+            o = 3 * B + 2
+            b.tile_ptr, b.tile_node_ptr, b.tile_edge_ptr = meta[o:o + T1], meta[o + T1:o + 2 * T1], meta[o + 2 * T1:o + 3 * T1]
+            b.tile_max_nodes, b.tile_max_edges = int((tn[1:] - tn[:-1]).max()), int((te[1:] - te[:-1]).max())
         b._meta = meta            # keep the device copy alive until the kernel has consumed it
         return b
 
@@ -95,8 +119,10 @@ class DeviceLoader:
 
     def __init__(self, dataset: DeviceDataset, batch_size: int, shuffle: bool = False, rank: int = 0,
                  world_size: int = 1, drop_last: bool = False, generator: Optional[torch.Generator] = None,
-                 seed: int = 0):
+                 seed: int = 0, pack: Optional[bool] = None):
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
+        # small graphs (mean <= 40 nodes: NCI1, MUTAG, ...): order every mini-batch for the engine's 64-node tiles
+        self.pack = bool(dataset.G and dataset.node_sizes.mean() <= 40) if pack is None else bool(pack)
         self.rank, self.world_size, self.drop_last, self.generator = rank, world_size, drop_last, generator
         self.seed, self.epoch = int(seed), 0
 
@@ -120,4 +146,4 @@ class DeviceLoader:
             chunk = idx[s:s + self.batch_size]
             if self.drop_last and len(chunk) < self.batch_size:
                 return
-            yield self.dataset.collate(chunk)
+            yield self.dataset.collate(chunk, pack=self.pack)

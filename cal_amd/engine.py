@@ -15,6 +15,7 @@ attention and CausalGIN (every causal variant ``opts.get_model`` builds).
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -184,6 +185,9 @@ class StepEngine:
         #: False withholds the batch layout from the engine: generic CSR build + unfused GEMM / aggregation kernels
         #: (what a batch too large for the per-graph kernels runs anyway); tests compare the two paths with it
         self.fused = True
+        #: False keeps one graph per workgroup for batches of small graphs too (tests compare the two)
+        self.tiles = os.environ.get("CAL_AMD_TILES", "1") != "0"
+        self._tiles = (0, 0)
         self._ws: Optional[torch.Tensor] = None
         self.ws_generation = 0          # bumped whenever the workspace is re-allocated (captured graphs check it)
         self._cap = (0, 0, 0)
@@ -317,10 +321,21 @@ class StepEngine:
               and nptr.is_cuda and eptr.is_cuda and nptr.dtype == torch.long and eptr.dtype == torch.long
               and nptr.numel() == B + 1 and eptr.numel() == B + 1 and nptr.is_contiguous() and eptr.is_contiguous())
         ptrs = (nptr.data_ptr(), eptr.data_ptr()) if ok else (0, 0)
+        bounds = (lay["max_nodes"], lay["max_edges"])
+        # small-graph packing: a collated batch of small graphs carries tiles of consecutive graphs (data.pack_tiles); the
+        # per-graph kernels then take the TILES' offsets and bounds, and the first graph of every tile (cal_engine_set_tiles)
+        tp = getattr(batch, "tile_ptr", None) if (ok and self.tiles and self.H in (64, 128)) else None
+        tiles = (0, 0)
+        if torch.is_tensor(tp) and tp.is_cuda and batch.tile_node_ptr.is_cuda and batch.tile_edge_ptr.is_cuda and tp.numel() >= 2:
+            tiles = (tp.data_ptr(), int(tp.numel()) - 1)
+            ptrs = (batch.tile_node_ptr.data_ptr(), batch.tile_edge_ptr.data_ptr())
+            bounds = (int(batch.tile_max_nodes), int(batch.tile_max_edges))
+        if tiles != self._tiles:
+            _lib.call("cal_engine_set_tiles", self._h, tiles[0] or None, tiles[1])
+            self._tiles = tiles
         if ptrs != self._ptrs:
             _lib.call("cal_engine_set_graph_ptrs", self._h, ptrs[0] or None, ptrs[1] or None)
             self._ptrs = ptrs
-        bounds = (lay["max_nodes"], lay["max_edges"])
         if bounds != self._bounds:
             _lib.call("cal_engine_set_graph_bounds", self._h, bounds[0], bounds[1])
             self._bounds = bounds

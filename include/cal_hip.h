@@ -129,6 +129,12 @@ CAL_API int cal_collate(const float* X, const int64_t* EI, int64_t sumE, int64_t
                         float* xo, int64_t* eio, int64_t Eout, int64_t* batcho, int64_t* yo, int64_t B,
                         void* stream);
 
+/* host-side helper of the small-graph packing (cal_engine_set_tiles): first-fit-decreasing order of the B graphs of a
+ * mini-batch under the tile bounds; order_out [B] positions, first_out [T + 1] first emitted graph of every tile; returns T
+ * (-1: a graph exceeds a bound).  Host pointers, no device work. */
+CAL_API int64_t cal_pack_order(const int64_t* node_sizes, const int64_t* edge_sizes, int64_t B, int64_t max_nodes,
+                               int64_t max_edges, int64_t max_graphs, int64_t* order_out, int64_t* first_out);
+
 /* ---- random-intervention permutation (model.py:147-152, `random.shuffle(range(num))`) drawn on the
  * device: perm[0..B) <- uniformly random permutation keyed by (seed, *counter); the kernel advances
  * *counter (a device uint64), so a replayed hipGraph draws a fresh permutation every step.  B <= 4096 */
@@ -174,6 +180,11 @@ CAL_API int cal_engine_step(void* engine, const float* x0, const int64_t* edge_i
                             int64_t E, int64_t B, float wc, float wo, float wco, int mode,
                             void* stream);
 CAL_API int cal_engine_adam(void* engine, void* stream);
+/* small-graph packing: the per-graph kernels run one workgroup per TILE of consecutive graphs (<= 64 nodes, <= 1024 edges,
+ * <= 8 graphs); the tiles' node / edge offsets and bounds go through cal_engine_set_graph_ptrs / _set_graph_bounds, and
+ * tile_gptr [ntiles + 1] (device int64) names the first graph of every tile.  Only global_add_pool (model.py:115-116) and its
+ * backward distinguish the graphs of a tile.  ntiles = 0: one graph per workgroup. */
+CAL_API int cal_engine_set_tiles(void* engine, const int64_t* tile_gptr, int64_t ntiles);
 /* torch.optim.Adam's betas / eps / weight_decay (train_causal.py:21,76) after the bind, e.g. when an optimizer object that
  * owns them is attached to an engine-backed model (cal_amd/optim.py); the learning rate is the bound device float `lr` */
 CAL_API int cal_engine_set_adam(void* engine, float beta1, float beta2, float eps, float weight_decay);

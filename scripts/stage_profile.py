@@ -20,7 +20,7 @@ else:
     nf, nc = 10, 4
 m = getattr(M, os.environ.get("CAL_STAGE_MODEL", "CausalGCN"))(nf, nc, args).cuda().train()
 eng = StepEngine(m)
-b = Batch.from_data_list(gl).to("cuda")
+b = Batch.from_data_list(gl, pack=True).to("cuda")
 perm = torch.randperm(len(gl), device="cuda")
 eng.train_step(b, perm, adam=False)
 torch.cuda.synchronize()
