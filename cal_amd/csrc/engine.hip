@@ -32,6 +32,7 @@
 #include "engine_attbwd.hpp"
 #include "engine_ro_step.hpp"
 #include "engine_gin.hpp"
+#include "engine_ggin.hpp"
 
 namespace cal {
 
@@ -808,6 +809,24 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     const bool gc = use_gc(c);
     const bool gat = e->K > 0;
     for (int i = 1; i <= L; ++i) {
+        if (e->gin && gc && gc_small(c) && e->max_edges <= gc_edge_cap(64)) {
+            // GINConv per graph (engine_ggin.hpp): (A + I)(h W1^T) + b1 with the BatchNorm statistics | BN, ReLU, Linear, ReLU
+            const float* hin = e->h + (size_t)(i - 1) * NH;
+            float* t1 = e->gt1 + (size_t)(i - 1) * NH;
+            GginFwdArgs ga;
+            memset(&ga, 0, sizeof(ga));
+            ga.x = hin; ga.W = e->P + e->o_conv_w[i - 1]; ga.bias = e->P + e->o_conv_b[i - 1]; ga.out = t1;
+            if (c.training) { ga.st_sum = graph_acc(c, bn_stsum(c, i), H); ga.st_sq = graph_acc(c, bn_stsq(c, i), H); }
+            hipLaunchKernelGGL((k_ggin_fwd<1>), dim3(T, H / GC_N), dim3(512), 0, st, gd, e->gptr, e->eptr, ga, H, H, e->status);
+            CAL_CHECK_LAUNCH("k_ggin_fwd<1>"); STAGE();
+            RC(flush_finals(c)); STAGE();
+            memset(&ga, 0, sizeof(ga));
+            ga.x = t1; ga.W = e->P + e->o_gin_w2[i - 1]; ga.bias = e->P + e->o_gin_b2[i - 1]; ga.out = e->h + (size_t)i * NH;
+            ga.bn = bnref(c, i, N, 1);
+            hipLaunchKernelGGL((k_ggin_fwd<2>), dim3(T, H / GC_N), dim3(512), 0, st, gd, e->gptr, e->eptr, ga, H, H, e->status);
+            CAL_CHECK_LAUNCH("k_ggin_fwd<2>"); STAGE();
+            continue;
+        }
         if (e->gin) {    // GINConv: unit-coefficient aggregation -> Linear -> BN -> ReLU -> Linear -> ReLU (model.py:188-194)
             const float* hin = e->h + (size_t)(i - 1) * NH;
             float* agg = e->gagg + (size_t)(i - 1) * NH;
@@ -1351,6 +1370,65 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     for (int i = L; i >= 1; --i) {
         float* dzi = e->dzi + (size_t)(i - 1) * NH;     // per layer: the side-stream dW GEMM reads it later
         const bool gat = e->K > 0;
+        if (e->gin && gcb && e->max_edges <= GB_E) {
+            // GINConv backward per graph (engine_ggin.hpp): second Linear (+ the BatchNorm-backward sums behind the ReLU) |
+            // BatchNorm backward, first Linear, transposed aggregation.  Partial input gradients (one per output-column
+            // slice): PART 2 -> (dXh, gy[i-1]), PART 1 -> (z, gagg[i-1]); the layer below (or the mask pass in front of the
+            // feature layer) adds the two and masks by h_{i-1} > 0.
+            const int nsl = H / GC_N;
+            const bool two = nsl > 1;
+            float* c0 = e->dXh; float* c1 = e->gy + (size_t)(i - 1) * NH;
+            float* d0 = e->z; float* d1 = e->gagg + (size_t)(i - 1) * NH;
+            const float* t1 = e->gt1 + (size_t)(i - 1) * NH;
+            if (slab_off + 2 * (size_t)T * H * H > e->slab_floats || fa.nst + 2 > MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
+            GginBwdArgs ga;
+            memset(&ga, 0, sizeof(ga));
+            if (i == L) ga.dout = e->dZ;
+            else {
+                ga.dy0 = e->z; ga.dy1 = two ? e->gagg + (size_t)i * NH : nullptr; ga.hmask = e->h + (size_t)i * NH;
+                Deferred& db = d_convb[i - 1];           // d b2 of this layer: column sums of the masked d h_i, one partial row per unit
+                db.p = parts_alloc(c, (size_t)T * H); db.P = T; db.stride = H;
+                if (!db.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+                ga.bias_parts = db.p;
+            }
+            ga.x = t1; ga.W = e->P + e->o_gin_w2[i - 1]; ga.bn = bnref(c, i, N, 0);
+            ga.dxp0 = c0; ga.dxp1 = c1;
+            ga.slab = e->slabs + slab_off;
+            fa.st[fa.nst++] = SlabTask{ga.slab, e->G + e->o_gin_w2[i - 1], H * H, T};
+            slab_off += (size_t)T * H * H;
+            double* pp = parts_alloc(c, (size_t)T * nsl * 2 * H);
+            if (!pp) { set_error("engine: partial-row workspace exhausted"); return 2; }
+            ga.dot_parts = pp;
+            final_task(c, pp, T * nsl, 2 * H, H, bn_dsum(c, i));
+            final_task(c, pp + H, T * nsl, 2 * H, H, bn_dprod(c, i));
+            hipLaunchKernelGGL((k_ggin_bwd<2>), dim3(T, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+            CAL_CHECK_LAUNCH("k_ggin_bwd<2>"); STAGE();
+            RC(flush_finals(c)); STAGE();
+            memset(&ga, 0, sizeof(ga));
+            ga.dy0 = c0; ga.dy1 = two ? c1 : nullptr; ga.t1 = t1;
+            ga.dot_sum = bn_dsum(c, i); ga.dot_prod = bn_dprod(c, i);
+            {
+                Deferred& db = d_gin_b1[i - 1];          // d b1: column sums of dt1
+                db.p = parts_alloc(c, (size_t)T * H); db.P = T; db.stride = H;
+                if (!db.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+                ga.bias_parts = db.p;
+            }
+            ga.x = e->h + (size_t)(i - 1) * NH; ga.W = e->P + e->o_conv_w[i - 1]; ga.bn = bnref(c, i, N, 0);
+            ga.dxp0 = d0; ga.dxp1 = d1;
+            ga.slab = e->slabs + slab_off;
+            fa.st[fa.nst++] = SlabTask{ga.slab, e->G + e->o_conv_w[i - 1], H * H, T};
+            slab_off += (size_t)T * H * H;
+            hipLaunchKernelGGL((k_ggin_bwd<1>), dim3(T, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+            CAL_CHECK_LAUNCH("k_ggin_bwd<1>"); STAGE();
+            if (i == 1) {                                // the feature layer below takes d h0 masked by h0 > 0 in e->dZ
+                GinRowArgs gr;
+                memset(&gr, 0, sizeof(gr));
+                gr.a = d0; gr.a2 = two ? d1 : nullptr; gr.y = e->h; gr.out = e->dZ;
+                RC(gin_rows(c, 3, gr));
+                CAL_CHECK_LAUNCH("k_gin_mask"); STAGE();
+            }
+            continue;
+        }
         if (e->gin) {
             // GINConv backward (model.py:188-194 differentiated).  e->dZ holds dz2 = d h_i masked by h_i > 0 (its column sums,
             // d b2, are already deferred): dW2 = dz2^T y, dy = dz2 W2, BatchNorm backward behind the ReLU -> dt1 (+ d b1),

@@ -16,6 +16,7 @@ namespace cal {
 
 struct GinRowArgs {
     const float* a;        // first input  [N,W]: t1 (fwd) / dy (dots, bn_bwd) / dh (mask)
+    const float* a2;       // mask only: a second partial of dh added to the first (per-graph GINConv backward), or null
     const float* y;        // relu(BN(t1)) [N,W] (dots, bn_bwd) or h (mask)
     const float* t1;       // pre-BatchNorm activations (dots, bn_bwd)
     float* out;            // y (fwd) / dt1 (bn_bwd) / dz (mask)
@@ -58,16 +59,17 @@ __global__ void __launch_bounds__(256) k_gin_rows(const GinRowArgs p, int N, int
             }
         }
         for (int r0 = rbeg + grp; r0 < rend; r0 += RPB * UR) {
-            V va[UR], vy[UR], vt[UR];
+            V va[UR], vy[UR], vt[UR], v2[UR];
 #pragma unroll
             for (int u = 0; u < UR; ++u) {
                 const size_t r = (size_t)min(r0 + u * RPB, rend - 1);
                 va[u] = V::ld(p.a + r * W + cc);
+                v2[u] = (MODE == 3 && p.a2) ? V::ld(p.a2 + r * W + cc) : V::zero();
                 vy[u] = MODE != 0 ? V::ld(p.y + r * W + cc) : V::zero();
                 vt[u] = (MODE == 1 || MODE == 2) ? V::ld(p.t1 + r * W + cc) : V::zero();
             }
 #pragma unroll
-            for (int u = 0; u < UR; ++u) { va[u].pin(); if (MODE != 0) vy[u].pin(); if (MODE == 1 || MODE == 2) vt[u].pin(); }
+            for (int u = 0; u < UR; ++u) { va[u].pin(); if (MODE != 0) vy[u].pin(); if (MODE == 1 || MODE == 2) vt[u].pin(); if (MODE == 3) { v2[u].pin(); va[u].add(v2[u]); } }
 #pragma unroll
             for (int u = 0; u < UR; ++u) {
                 const int r = r0 + u * RPB;
