@@ -359,6 +359,8 @@ def reference_loop(wl, margs, gs, steps=60):
     loader, device, args)`` (train_causal.py:162-200) with an ``Adam`` object and a cosine schedule stepped once per epoch
     (train_causal.py:21-29), shuffled epochs over the same 2048-graph dataset.  Three feeds:
       fused_device_loader  what ``train_causal_syn`` builds on a GPU: device-resident dataset + one-call fused step
+      fused_device_loader_device_perm   the same with ``args.device_perm`` (the permutation of model.py:147-152 drawn inside the
+                           step's first kernel instead of by Python's RNG + a pinned H2D copy)
       fused_host_loader    a caller's own host DataLoader (Python collate + H2D per batch) in front of the fused step
       module_surface       ``--no_fused_step``: model(data) -> torch loss -> backward -> optimizer.step(), statement by
                            statement on the nn.Module surface (what a foreign loop gets), with a host read-back of the
@@ -372,15 +374,16 @@ def reference_loop(wl, margs, gs, steps=60):
     from cal_amd.train_causal import causal_loss, train_causal_epoch
     dev = torch.device("cuda")
     out = {}
-    for kind in ("fused_device_loader", "fused_host_loader", "module_surface"):
+    for kind in ("fused_device_loader", "fused_device_loader_device_perm", "fused_host_loader", "module_surface"):
         args = copy.copy(margs)
         args.no_fused_step = kind == "module_surface"
+        args.device_perm = kind.endswith("device_perm")     # (not a reference flag: the intervention permutation drawn on the GPU)
         torch.manual_seed(1)
         random.seed(1)
         model = getattr(M, wl["model"])(wl["nfeat"], wl["ncls"], args).cuda()
         opt = EngineAdam(model.parameters(), lr=1e-3)
         sched = CosineAnnealingLR(opt, T_max=100, eta_min=1e-6)
-        if kind == "fused_device_loader":
+        if kind.startswith("fused_device_loader"):
             loader = DeviceLoader(DeviceDataset(gs), wl["batch"], shuffle=True)
         else:
             loader = DataLoader(gs, wl["batch"], shuffle=True)

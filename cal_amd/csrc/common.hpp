@@ -145,6 +145,35 @@ __device__ __forceinline__ void randperm_block(int64_t* __restrict__ perm, int B
     if (threadIdx.x == 0) *counter = cnt + 1;
 }
 
+// The same permutation by SEVERAL workgroups (the step's first kernel: B = 512 took 30 us in one workgroup -- B^2 64-bit
+// compares at 4 cycles per wave instruction).  Workgroup `part` of `nparts` hashes all B keys into LDS and ranks the elements
+// [part * NT / 4, (part + 1) * NT / 4) with four lanes per element (a quarter of the keys each); positions are scattered to
+// global memory, so no workgroup waits for another.  The counter is only READ: the caller advances it in a later kernel
+// of the same step (k_finish), after every workgroup here has used it.
+template <int NT>
+__device__ __forceinline__ void randperm_slice(int64_t* __restrict__ perm, int B, unsigned long long seed,
+                                               const unsigned long long* __restrict__ counter, unsigned long long* key, int part) {
+    const unsigned long long cnt = *counter;
+    for (int i = threadIdx.x; i < B; i += NT)
+        key[i] = splitmix64(splitmix64(seed ^ (cnt * 0xD1342543DE82EF95ull)) + (unsigned long long)i) >> 1;
+    __syncthreads();
+    const int i = part * (NT / 4) + ((int)threadIdx.x >> 2), q = threadIdx.x & 3;
+    const int ic = min(i, B - 1);
+    const unsigned long long k = key[ic];
+    const int per = (B + 3) >> 2, lo = q * per, hi = min(B, lo + per);
+    int r = 0;
+    for (int j = lo; j < hi; j += 8) {
+        unsigned long long kj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kj[u] = key[min(j + u, B - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r += (j + u < hi && (kj[u] < k || (kj[u] == k && j + u < ic))) ? 1 : 0;
+    }
+    r += __shfl_xor(r, 1, 64);
+    r += __shfl_xor(r, 2, 64);
+    if (q == 0 && i < B) perm[r] = i;
+}
+
 // Touch every 64 B line of the kernel-argument segment in ONE round of scalar loads at the top of a kernel: hipcc sinks
 // argument loads into the blocks that use them, and each first touch of another line is a scalar-cache miss (a few
 // hundred ns) in its own dependent round; after this every later argument load is a hit.

@@ -47,6 +47,7 @@ struct FinishArgs {
     float* stats;            // fused readout: stats[0] = wc*stats[1] + wo*stats[2] + wco*stats[3]
     float wc, wo, wco;
     float* tick;             // Adam step counter to advance (the update follows in the same step) or null
+    unsigned long long* perm_ctr;   // counter of the in-step permutation draw to advance (k_zero_f64's rank-sort workgroups only read it), or null
     // Adam inside this kernel (single-process steps, mode bit 4 without bit 8): every gradient element is updated by the
     // thread that finishes it, the ranges no task writes (gradients other kernels stored directly) by `nar` extra tasks
     // of 256 elements per block; the step counter was advanced by the step's FIRST kernel (a ticket of 2700 blocks on one
@@ -69,6 +70,7 @@ __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __re
     if (fa.stats && blockIdx.x == 0 && threadIdx.x == 0)
         fa.stats[0] = fa.wc * fa.stats[1] + fa.wo * fa.stats[2] + fa.wco * fa.stats[3];
     if (fa.tick && blockIdx.x == 0 && threadIdx.x == 0) fa.tick[0] += 1.f;
+    if (fa.perm_ctr && blockIdx.x == 0 && threadIdx.x == 0) fa.perm_ctr[0] += 1;
     // Both task kinds are pure reductions over S slabs / P partial rows: the loops keep 8 loads in flight
     // per lane (unconditional on a clamped index, pinned, masked when added) -- as dependent loops with
     // two loads in flight the 58-slab weight-gradient sums made this kernel 11 us.
@@ -762,7 +764,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     // 0. zero the fp64 arena and the GraphPlan counters (one kernel, not memset nodes)
     {
         const int64_t ni = fast_plan ? 0 : 4 * ((int64_t)N + 1);
-        hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256) + (c.draw_perm ? 1 : 0)), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256) + (c.draw_perm ? cdiv(B, ZP_EPB) : 0)), dim3(256), 0, st,
                            e->arena, (int64_t)e->arena_n, e->work, ni, e->status, (e->K > 0 && c.training) ? e->gat_ctr : nullptr,
                            c.draw_perm ? e->perm_dev : nullptr, B, e->perm_seed, e->perm_ctr, c.adam_in_finish ? e->step : nullptr);
         CAL_CHECK_LAUNCH("k_zero_f64"); STAGE();
@@ -1111,6 +1113,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     FinishArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.tick = (c.tick_in_finish && !c.adam_in_finish) ? e->step : nullptr;      // (adam_in_finish: k_zero_f64 did it)
+    fa.perm_ctr = c.draw_perm ? e->perm_ctr : nullptr;
     size_t slab_off = 0;
     auto commit_p = [&](const double* src, int P, int stride, int dst, int n, float scale) {
         if (fa.nct < MAX_COMMITS) fa.ct[fa.nct] = CommitTask{src, P, stride, dst, n, scale};
@@ -1363,7 +1366,37 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         CAL_CHECK_LAUNCH("k_att_bwd"); STAGE();
         }
     }
-    bool feat_done = false;     // the per-graph feature-layer backward (k_feat_bwd) has run
+    bool feat_done = false;     // the per-graph feature-layer backward (k_feat_bwd_mma) has run
+    // feature layer h0 = relu(BN0(x0) W_feat) per unit, fed from the first backbone layer's partial input gradients
+    // (engine_gconv_bwd.hpp: one MFMA product per unit, any F <= 160); nobn: no BatchNorm between h0 and that layer (GIN)
+    auto feat_bwd = [&](const float* p0, const float* p1, bool nobn) -> int {
+        FeatBwdArgs fb;
+        memset(&fb, 0, sizeof(fb));
+        fb.dy0 = p0; fb.dy1 = p1; fb.y = e->h;
+        if (!nobn) { fb.ubn = bnref(c, 1, N, 0); fb.udot_sum = bn_dsum(c, 1); fb.udot_prod = bn_dprod(c, 1); }
+        fb.x0 = x0; fb.W = e->P + e->o_feat_w; fb.bn0 = bnref(c, 0, N, 0);
+        const size_t need = (size_t)T * F * H;
+        if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
+        fb.slab = e->slabs + slab_off;
+        fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, T};
+        slab_off += need;
+        d_bn0.p = parts_alloc(c, (size_t)T * 2 * F); d_bn0.P = T; d_bn0.stride = 2 * F;
+        if (!d_bn0.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+        fb.parts = d_bn0.p;
+        const dim3 grid(T), blk(GB_NT);
+        if (F <= FB_F && !nobn) {
+            // few features (SPMotif: F = 10): the FMA-loop kernel is 1.7 us shorter than one MFMA tile behind three barriers
+            hipLaunchKernelGGL(k_feat_bwd, grid, blk, 0, st, e->gptr, fb, H, F, e->status);
+        } else if (F <= 64) {
+            hipLaunchKernelGGL((k_feat_bwd_mma<8, true>), grid, blk, 0, st, e->gptr, fb, H, F, e->status);
+        } else {
+            if (nobn) hipLaunchKernelGGL((k_feat_bwd_mma<20, true>), grid, blk, 0, st, e->gptr, fb, H, F, e->status);
+            else hipLaunchKernelGGL((k_feat_bwd_mma<20, false>), grid, blk, 0, st, e->gptr, fb, H, F, e->status);
+        }
+        CAL_CHECK_LAUNCH("k_feat_bwd");
+        feat_done = true;
+        return 0;
+    };
     // Q. backbone layers, last to first
     Deferred d_gin_b1[MAX_LAYERS];
     memset(d_gin_b1, 0, sizeof(d_gin_b1));
@@ -1420,7 +1453,9 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             slab_off += (size_t)T * H * H;
             hipLaunchKernelGGL((k_ggin_bwd<1>), dim3(T, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
             CAL_CHECK_LAUNCH("k_ggin_bwd<1>"); STAGE();
-            if (i == 1) {                                // the feature layer below takes d h0 masked by h0 > 0 in e->dZ
+            if (i == 1 && F <= FM_F && H <= FB_H) {
+                RC(feat_bwd(d0, two ? d1 : nullptr, true)); STAGE();
+            } else if (i == 1) {                         // the feature layer below takes d h0 masked by h0 > 0 in e->dZ
                 GinRowArgs gr;
                 memset(&gr, 0, sizeof(gr));
                 gr.a = d0; gr.a2 = two ? d1 : nullptr; gr.y = e->h; gr.out = e->dZ;
@@ -1544,24 +1579,9 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             }
             CAL_CHECK_LAUNCH("k_ggat_bwd"); STAGE();
             RC(flush_finals(c)); STAGE();
-            if (i == 1 && F <= FB_F && H <= FB_H) {
+            if (i == 1 && F <= FM_F && H <= FB_H) {
                 // the feature layer's backward per graph, fed from this layer's partial dX' (as in the GCNConv path)
-                FeatBwdArgs fb;
-                memset(&fb, 0, sizeof(fb));
-                fb.dy0 = p0; fb.dy1 = H > GC_N ? dzi : nullptr; fb.y = hin;
-                fb.ubn = bnref(c, 1, N, 0); fb.udot_sum = bn_dsum(c, 1); fb.udot_prod = bn_dprod(c, 1);
-                fb.x0 = x0; fb.W = e->P + e->o_feat_w; fb.bn0 = bnref(c, 0, N, 0);
-                const size_t need = (size_t)T * F * H;
-                if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
-                fb.slab = e->slabs + slab_off;
-                fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, T};
-                slab_off += need;
-                d_bn0.p = parts_alloc(c, (size_t)T * 2 * F); d_bn0.P = T; d_bn0.stride = 2 * F;
-                if (!d_bn0.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
-                fb.parts = d_bn0.p;
-                hipLaunchKernelGGL(k_feat_bwd, dim3(T), dim3(GB_NT), 0, st, e->gptr, fb, H, F, e->status);
-                CAL_CHECK_LAUNCH("k_feat_bwd"); STAGE();
-                feat_done = true;
+                RC(feat_bwd(p0, H > GC_N ? dzi : nullptr, false)); STAGE();
             } else if (i == 1) {       // the feature layer below is a plain GEMM: materialise dZ for it
                 BnBwdProb p{p0, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i), Acc(), H > GC_N ? dzi : nullptr};
                 RC(with_g(H, [&](auto g) {
@@ -1599,24 +1619,9 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             double* dsum[1] = {bn_dsum(c, i)}; double* dprod[1] = {bn_dprod(c, i)};
             { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false)); } STAGE();
             RC(flush_finals(c)); STAGE();
-            if (i == 1 && F <= FB_F && H <= FB_H) {
+            if (i == 1 && F <= FM_F && H <= FB_H) {
                 // the feature layer's backward per graph, fed from this layer's partial dX' (no k_bn_bwd, no dZ round trip)
-                FeatBwdArgs fb;
-                memset(&fb, 0, sizeof(fb));
-                fb.dy0 = p0; fb.dy1 = H > GC_N ? dzi : nullptr; fb.y = hin;
-                fb.ubn = bnref(c, 1, N, 0); fb.udot_sum = bn_dsum(c, 1); fb.udot_prod = bn_dprod(c, 1);
-                fb.x0 = x0; fb.W = e->P + e->o_feat_w; fb.bn0 = bnref(c, 0, N, 0);
-                const size_t need = (size_t)T * F * H;
-                if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
-                fb.slab = e->slabs + slab_off;
-                fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, T};
-                slab_off += need;
-                d_bn0.p = parts_alloc(c, (size_t)T * 2 * F); d_bn0.P = T; d_bn0.stride = 2 * F;
-                if (!d_bn0.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
-                fb.parts = d_bn0.p;
-                hipLaunchKernelGGL(k_feat_bwd, dim3(T), dim3(GB_NT), 0, st, e->gptr, fb, H, F, e->status);
-                CAL_CHECK_LAUNCH("k_feat_bwd"); STAGE();
-                feat_done = true;
+                RC(feat_bwd(p0, H > GC_N ? dzi : nullptr, false)); STAGE();
             } else if (i == 1) {       // the feature layer below is a plain GEMM: materialise dZ for it
                 BnBwdProb p{p0, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i), Acc(), H > GC_N ? dzi : nullptr};
                 RC(with_g(H, [&](auto g) {
@@ -1808,7 +1813,7 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     c.adam_in_finish = ((mode & 4) && e->adam_fused) ? 1 : 0;
     const int want_grad = (mode & 2) ? 1 : 0;
     c.draw_perm = (mode & 16) ? 1 : 0;
-    CAL_REQUIRE(!c.draw_perm || (e->perm_ctr && B <= ZP_CAP), "mode bit 16 needs cal_engine_set_perm_rng and at most 1024 graphs per batch");
+    CAL_REQUIRE(!c.draw_perm || (e->perm_ctr && B <= ZP_CAP && want_grad), "mode bit 16 needs cal_engine_set_perm_rng, at most 1024 graphs per batch and the backward pass (its last kernel advances the permutation counter)");
     CAL_REQUIRE(c.draw_perm || perm, "perm is null and the step does not draw its own (mode bit 16)");
     if (c.draw_perm) perm = e->perm_dev;
     c.y = y; c.perm = perm; c.wc = wc; c.wo = wo; c.wco = wco; c.want_grad = want_grad;

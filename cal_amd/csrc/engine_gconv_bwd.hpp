@@ -691,4 +691,208 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
     BLK_CLK(1);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same feature-layer backward on the matrix cores, for any F <= FM_F (one-hot degree features of the TU datasets:
+// F = 109 / 139, datasets.py:16-20) -- and without the dX0 = dZ W_feat^T product at all.  With P = x0_hat^T dZ (this unit's
+// [F,H] block) and cs = column sums of dZ, everything the layer needs is linear in P:
+//     dW_feat   = (gamma0 x0_hat + beta0)^T dZ  = gamma0[f] P[f,:] + beta0[f] cs
+//     sum_j dX0[j,f]            = <W[f,:], cs>            (dX0 = dZ W^T)
+//     sum_j dX0[j,f] x0_hat[j,f] = <W[f,:], P[f,:]>
+// so one MFMA product per unit replaces two products and a row pass.  NOBN: the layer above is not behind a BatchNorm
+// (CausalGIN: h0 feeds GINConv directly): dZ = (dy0 + dy1) masked by h0 > 0.
+//   grid (units), 512 threads; XU = x0 loads per lane (8: F <= 64, 20: F <= 160).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FM_F = 160;
+template <int XU, bool NOBN>
+__global__ void __launch_bounds__(GB_NT) k_feat_bwd_mma(const int* __restrict__ gptr, const FeatBwdArgs a, int H, int F,
+                                                      int* __restrict__ status) {
+    constexpr int FP = XU == 8 ? 64 : FM_F, LDXN = FP + 1, LDZ = FB_H + 4;
+    __shared__ __attribute__((aligned(16))) float Dz[FB_T * LDZ];           // dZ rows [j][n]
+    __shared__ float Xn[FB_T * LDXN];                    // x0_hat rows [j][f] (normalised, no affine), zero beyond F / rows
+    __shared__ float um_s[FB_H], ur_s[FB_H], ug_s[FB_H], u1_s[FB_H], u2_s[FB_H];
+    __shared__ float m0_s[FP], r0_s[FP], g0_s[FP], b0_s[FP];
+    __shared__ float cs_s[FB_H];
+    __shared__ float csp[GB_NT / 64][32][4];
+    __shared__ float s12[2][4][FP];                      // per column tile: partial <W[f,:], cs>, <W[f,:], P[f,:]>
+    __shared__ float red_s[GB_NT / 64][2][32][33];       // per wave: the two product tiles [feature][column], summed over the columns
+    BLK_CLK(0);
+    warm_kernargs<sizeof(FeatBwdArgs) + 32>();
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int g0 = gptr[b], rows = gptr[b + 1] - g0;
+    float* slab = a.slab + (size_t)b * F * H;
+    double* parts = a.parts + (size_t)b * 2 * F;
+    if (rows <= 0 || rows > FB_T) {
+        if (rows > 0 && t == 0) atomicOr(status, 8);
+        for (int i = t; i < F * H; i += GB_NT) slab[i] = 0.f;
+        for (int i = t; i < 2 * F; i += GB_NT) parts[i] = 0.0;
+        return;
+    }
+    const int H4 = H >> 2, rowsP = (rows + 31) & ~31, nct = H >> 5, nft = (F + 31) >> 5;
+    RoBatch<float4, 4> b0, b1, by;
+    const float* d1 = a.dy1 ? a.dy1 : a.dy0;
+    ro_issue<GB_NT>(b0, rows, H4, [&](int j, int c) { return *reinterpret_cast<const float4*>(a.dy0 + (size_t)(g0 + j) * H + 4 * c); });
+    ro_issue<GB_NT>(b1, rows, H4, [&](int j, int c) { return *reinterpret_cast<const float4*>(d1 + (size_t)(g0 + j) * H + 4 * c); });
+    ro_issue<GB_NT>(by, rows, H4, [&](int j, int c) { return *reinterpret_cast<const float4*>(a.y + (size_t)(g0 + j) * H + 4 * c); });
+    float xr[XU];                                        // x0[g0 .. g0 + rows) is contiguous: rows * F floats
+#pragma unroll
+    for (int u = 0; u < XU; ++u) xr[u] = a.x0[(size_t)g0 * F + min(t + u * GB_NT, rows * F - 1)];
+    // W rows of this wave's first output tile (the epilogue's <W[f,:], .> sums): requested now, not behind the product
+    const int lane = t & 63, li = lane & 31, lk = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ct = w % nct, fstep = (GB_NT / 64) / nct;
+    float wv[16];
+    auto load_w = [&](int ft) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wv[r] = a.W[(size_t)min(ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, F - 1) * H + ct * 32 + li];
+    };
+    load_w(w / nct);
+    const int uc = min(t, H - 1), fc = min(max(t - 128, 0), F - 1);
+    BNRaw uraw, raw0 = bn_raw_load(a.bn0, fc);
+    double ud1 = 0.0, ud2 = 0.0;
+    if (!NOBN) { uraw = bn_raw_load(a.ubn, uc); ud1 = a.udot_sum[uc]; ud2 = a.udot_prod[uc]; bn_raw_pin(uraw); asm volatile("" : "+v"(ud1), "+v"(ud2)); }
+    bn_raw_pin(raw0);
+    if (!NOBN && t < H) {
+        float m1, r1;
+        bn_raw_mean_rstd(a.ubn, uraw, m1, r1);
+        um_s[t] = m1; ur_s[t] = r1;
+        ug_s[t] = uraw.g * r1;
+        u1_s[t] = (float)(ud1 * (double)a.ubn.inv_n);
+        u2_s[t] = (float)(ud2 * (double)a.ubn.inv_n);
+    }
+    if (t >= 128 && t - 128 < FP) {
+        const int f = t - 128;
+        float m1, r1;
+        bn_raw_mean_rstd(a.bn0, raw0, m1, r1);
+        m0_s[f] = m1; r0_s[f] = f < F ? r1 : 0.f;
+        g0_s[f] = raw0.g;
+        b0_s[f] = raw0.b;
+    }
+#pragma unroll
+    for (int u = 0; u < XU; ++u) asm volatile("" : "+v"(xr[u]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(wv[r]));
+    // zero the padding of the x0_hat tile (columns F .. FP of every row, rows rows .. rowsP): they are reduced over / read
+    for (int i = t; i < rowsP * LDXN; i += GB_NT) Xn[i] = 0.f;
+    __syncthreads();
+    {
+        const bool two = a.dy1 != nullptr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ro_pin(b0.v[u]); ro_pin(b1.v[u]); ro_pin(by.v[u]); }
+        // item (u, t): row (t + u * 512) / H4, float4 column t % H4 (512 % H4 == 0: a lane keeps its column group)
+        const int col = t % H4, c = 4 * col, rstep = GB_NT / H4;
+        int row = t / H4;
+        float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (row < rowsP) {
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
+                if (row < rows) {
+                    const float4 v0 = b0.v[u], v1 = b1.v[u], yv = by.v[u];
+                    const float d[4] = {v0.x + (two ? v1.x : 0.f), v0.y + (two ? v1.y : 0.f), v0.z + (two ? v1.z : 0.f), v0.w + (two ? v1.w : 0.f)};
+                    const float yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float g1 = d[k];
+                        if (!NOBN) {
+                            const float yn = (yy[k] - um_s[c + k]) * ur_s[c + k];
+                            g1 = ug_s[c + k] * (d[k] - u1_s[c + k] - yn * u2_s[c + k]);
+                        }
+                        o[k] = yy[k] > 0.f ? g1 : 0.f;
+                        cs[k] += o[k];
+                    }
+                }
+                *reinterpret_cast<float4*>(Dz + row * LDZ + c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            row += rstep;
+        }
+        // column sums of dZ: lanes of a wave with the same column group, then the eight waves through LDS
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (H4 <= 32) cs[k] += __shfl_xor(cs[k], 32, 64);
+            if (H4 <= 16) cs[k] += __shfl_xor(cs[k], 16, 64);
+        }
+        const int lane = t & 63;
+        if (lane < H4 && lane < 32) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) csp[t >> 6][lane][k] = cs[k];
+        }
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = t + u * GB_NT;
+            if (i < rows * F) { const int f = i % F; Xn[(i / F) * LDXN + f] = (xr[u] - m0_s[f]) * r0_s[f]; }
+        }
+    }
+    __syncthreads();
+    if (t < H) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < GB_NT / 64; ++k) tot += csp[k][t >> 2][t & 3];
+        cs_s[t] = tot;
+    }
+    __syncthreads();
+    BLK_CLK(2);
+    // P = x0_hat^T dZ on the matrix cores: wave w takes column tile w % nct and the feature tiles w / nct, + 8 / nct, ..
+    auto ident = [](float v) { return v; };
+    for (int ft = w / nct; ft < nft; ft += fstep) {
+        gc_f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
+        gb_mma<1, 1, LDXN, LDZ>(Xn + ft * 32 + li, nullptr, Dz + ct * 32 + li, nullptr, rowsP, lk, ident, acc);
+        const int h = ct * 32 + li;
+        const float csh = cs_s[h];
+        float wc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wc[r] = wv[r];
+        float p1[16], p2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const float pv = acc[0][r];
+            acc[1][r] = fmaf(g0_s[min(f, FP - 1)], pv, b0_s[min(f, FP - 1)] * csh);         // this unit's dW_feat entry
+            p1[r] = f < F ? wc[r] * csh : 0.f;
+            p2[r] = f < F ? wc[r] * pv : 0.f;
+        }
+        // sums over the tile's 32 columns through this wave's LDS scratch: lane (which = lane / 32, feature = lane % 32) adds
+        // its row (160 ds_bpermute shuffles per tile, each behind its own lgkmcnt wait, were ~4 us per tile)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int fl = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            red_s[w][0][fl][li] = p1[r];
+            red_s[w][1][fl][li] = p2[r];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the wave's own LDS writes (no other wave touches red_s[w])
+        {
+            const float* rr = &red_s[w][lk][li][0];
+            float v[32], tot = 0.f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) v[q] = rr[q];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) tot += v[q];
+            const int f = ft * 32 + li;
+            if (f < FP) s12[lk][ct][f] = tot;
+        }
+        // the guarded stores go LAST, with no load in flight (hipcc waits for vmcnt(0) at the head of every guarded block --
+        // with the next tile's W rows already requested, each of the 16 stores waited for them and for its predecessor:
+        // 4 us per tile), and the next tile's W rows are requested behind them, under the next product
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (f < F) slab[(size_t)f * H + h] = acc[1][r];
+        }
+        if (ft + fstep < nft) {
+            load_w(ft + fstep);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(wv[r]));
+        }
+    }
+    BLK_CLK(3);
+    __syncthreads();
+    if (t < F) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < nct; ++k) { s1 += (double)s12[0][k][t]; s2 += (double)s12[1][k][t]; }
+        parts[t] = s1; parts[F + t] = s2;
+    }
+    BLK_CLK(1);
+}
+
 }  // namespace cal

@@ -123,16 +123,21 @@ __global__ void __launch_bounds__(256) k_stats_final(const FinalArgs fa) {
 // First kernel of a step: zero the fp64 arena, the GraphPlan degree counters / cursors and the status word (the previous
 // step's status bits are folded into the sticky word status[1] first, read by StepEngine.check_status once per epoch);
 // for a GAT backbone in training, advance the attention-dropout step counter (one fresh mask per step); and, when the
-// step draws its own random-intervention permutation (mode bit 16), the LAST workgroup sorts it (B <= ZP_CAP) -- it is
-// consumed only by the readout, so no launch of its own in front of the step.
+// step draws its own random-intervention permutation (mode bit 16), the LAST cdiv(B, 64) workgroups rank-sort it (B <= ZP_CAP;
+// randperm_slice: 64 elements each) -- it is consumed only by the readout, so no launch of its own in front of the step.  The
+// permutation counter is advanced by the step's last kernel (k_finish).
 constexpr int ZP_CAP = 1024;
+constexpr int ZP_EPB = 64;                 // elements ranked per workgroup
 __global__ void __launch_bounds__(256) k_zero_f64(double* __restrict__ a, int64_t n, int* __restrict__ ints, int64_t ni,
                                                   int* __restrict__ status, unsigned long long* __restrict__ tick,
                                                   int64_t* __restrict__ perm, int B, unsigned long long seed,
                                                   unsigned long long* __restrict__ counter, float* __restrict__ adam_step) {
     __shared__ unsigned long long key[ZP_CAP];
-    __shared__ int idx[ZP_CAP];
-    if (perm && blockIdx.x == gridDim.x - 1) { randperm_block<256>(perm, B, seed, counter, key, idx); return; }
+    const int pblocks = perm ? (B + ZP_EPB - 1) / ZP_EPB : 0;
+    if (perm && (int)blockIdx.x >= (int)gridDim.x - pblocks) {
+        randperm_slice<256>(perm, B, seed, counter, key, (int)blockIdx.x - ((int)gridDim.x - pblocks));
+        return;
+    }
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = 0.0;
     if (i < ni) ints[i] = 0;

@@ -186,7 +186,9 @@ class StepEngine:
         #: (what a batch too large for the per-graph kernels runs anyway); tests compare the two paths with it
         self.fused = True
         #: False keeps one graph per workgroup for batches of small graphs too (tests compare the two)
-        self.tiles = os.environ.get("CAL_AMD_TILES", "1") != "0"
+        #: True: pack when it pays (below); "force": whenever the batch carries tiles (tests); False: never
+        self.tiles = {"0": False, "force": "force"}.get(os.environ.get("CAL_AMD_TILES", "1"), True)
+        self.tile_min_units = 256
         self._tiles = (0, 0)
         self._ws: Optional[torch.Tensor] = None
         self.ws_generation = 0          # bumped whenever the workspace is re-allocated (captured graphs check it)
@@ -324,7 +326,12 @@ class StepEngine:
         bounds = (lay["max_nodes"], lay["max_edges"])
         # small-graph packing: a collated batch of small graphs carries tiles of consecutive graphs (data.pack_tiles); the
         # per-graph kernels then take the TILES' offsets and bounds, and the first graph of every tile (cal_engine_set_tiles)
-        tp = getattr(batch, "tile_ptr", None) if (ok and self.tiles and self.H in (64, 128)) else None
+        # (only when one graph per workgroup would need more than one round of the one-per-CU backward kernels: below that
+        #  a tile is just a bigger unit of the same launch -- MUTAG-like B = 64 measured 0.253 ms unpacked, 0.275 ms packed)
+        want_tiles = bool(self.tiles)
+        if self.tiles is True:
+            want_tiles = B * (self.H // 64) > self.tile_min_units
+        tp = getattr(batch, "tile_ptr", None) if (ok and want_tiles and self.H in (64, 128)) else None
         tiles = (0, 0)
         if torch.is_tensor(tp) and tp.is_cuda and batch.tile_node_ptr.is_cuda and batch.tile_edge_ptr.is_cuda and tp.numel() >= 2:
             tiles = (tp.data_ptr(), int(tp.numel()) - 1)

@@ -33,7 +33,7 @@ def _engine(name, sd, args, nfeat, ncls, tiles=True):
         for c in m.convs:
             c.dropout = 0.0
     eng = StepEngine(m)
-    eng.tiles = tiles
+    eng.tiles = "force" if tiles else False          # ("force": also below the batch size from which packing pays)
     return m, eng
 
 
