@@ -149,3 +149,68 @@ def test_edge_between_two_graphs_of_a_tile_is_flagged():
     eng.train_step(bd, torch.arange(16, device=DEV), adam=False)
     with pytest.raises(_lib.CalError, match="status"):
         eng.check_status()
+
+
+@pytest.mark.parametrize("B", [65, 200, 513, 1024])
+def test_in_step_permutation_draw_by_several_workgroups_equals_cal_randperm(B):
+    """The step's first kernel ranks the permutation with cdiv(B, 64) workgroups (randperm_slice) and its last kernel
+    advances the counter: for the same (seed, counter) the result is cal_randperm's permutation, step after step."""
+    from cal_amd import _lib, synth
+    from cal_amd.data import Batch
+    from cal_amd.plan import _p, _stream
+    gs = synth.tu_like(B, kind="mutag", seed=B)
+    bd = Batch.from_data_list(gs, pack=True).to(DEV)
+    F = gs[0].x.size(1)
+    torch.manual_seed(2)
+    sd = O.init_state("CausalGCN", F, 2, hidden=64, layers=1)
+    m, eng = _engine("CausalGCN", sd, _args(hidden=64, layers=1), F, 2)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    eng.set_perm_rng(4242, cnt)
+    ref_cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ref = torch.empty(B, dtype=torch.long, device=DEV)
+    for k in range(2):
+        eng.train_step(bd, None, adam=False, draw_perm=True)
+        _lib.call("cal_randperm", _p(ref), B, 4242, _p(ref_cnt), _stream())
+        got = eng.drawn_perm(B)
+        assert torch.equal(got, ref) and int(cnt.item()) == k + 1
+        assert torch.equal(torch.sort(got).values, torch.arange(B, device=DEV))
+    eng.check_status()
+
+
+@pytest.mark.parametrize("name,F,hidden", [("CausalGCN", 70, 128), ("CausalGCN", 160, 64), ("CausalGIN", 97, 128), ("CausalGIN", 10, 64)])
+def test_feature_layer_backward_on_the_matrix_cores(name, F, hidden):
+    """k_feat_bwd_mma (65 <= F <= 160, and CausalGIN's feature layer at any F <= 160): one train step vs the oracle evaluated
+    in fp32 and fp64 -- conv_feat.weight / bn_feat.* are what the kernel produces."""
+    from cal_amd import spmotif
+    from cal_amd.data import Batch, Data
+    g = torch.Generator().manual_seed(F)
+    gs = []
+    for d in spmotif.train_mix(40, seed=3):
+        n = d.num_nodes
+        x = (torch.rand(n, F, generator=g) < 0.2).float() + 0.1 * torch.randn(n, F, generator=g)
+        gs.append(Data(x=x, edge_index=d.edge_index, y=d.y))
+    b, bd = Batch.from_data_list(gs), Batch.from_data_list(gs).to(DEV)
+    layers = 2
+    torch.manual_seed(9)
+    sd = O.init_state(name, F, 4, hidden=hidden, layers=layers, heads=4)
+    perm = torch.randperm(40)
+    tr = O.CpuTrainer(name, {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=layers, heads=4)
+    loss, lc, lo, lco, logits = tr.step(b.x, b.edge_index, b.batch, b.y, perm=perm)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    tr64 = O.CpuTrainer(name, sd64, 4, lr=1e-3, layers=layers, heads=4)
+    tr64.step(b.x.double(), b.edge_index, b.batch, b.y, perm=perm)
+    m, eng = _engine(name, {k: v.clone() for k, v in sd.items()}, _args(hidden=hidden, layers=layers), F, 4)
+    stats = eng.train_step(bd, perm.to(DEV), adam=False).cpu().numpy()
+    eng.check_status()
+    lp = eng.buffer("logp", 3 * 40 * 4).view(3, 40, 4).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert abs(stats[0] - loss.item()) < 1e-4
+    for k, p in m.named_parameters():
+        g32, g64 = tr.sd[k].grad, tr64.sd[k].grad
+        if g32 is not None:
+            e_gpu = (p.grad.cpu().double() - g64).abs().max().item()
+            e_cpu = (g32.double() - g64).abs().max().item()
+            # (floor 2e-5: with these dense random features more activations sit within rounding of a ReLU boundary than with
+            #  one-hot degrees; measured 1.03e-5 on bnc.weight for CausalGIN, where the fp32 oracle happens to be 2e-8 away)
+            assert e_gpu <= 4 * e_cpu + 2e-5 * max(1.0, g64.abs().max().item()), (k, e_gpu, e_cpu)
