@@ -719,7 +719,7 @@ RoArgs make_ro(const Ctx& c) {
     }
     a.pooled = e->pooled; a.perm = c.perm; a.iperm = e->iperm; a.xco = e->xco; a.y1 = e->y1;
     a.zl = e->zl; a.logp = e->logp; a.dzl = e->dzl; a.dy1 = e->dy1; a.dxin = e->dxh;
-    a.rowloss = e->dyh1;                  // [4,B] scratch: the unfused path's dyh1 is idle here
+    a.rowloss = e->dyh1;                  // [6,B] scratch: the unfused path's dyh1 is idle here
     a.y = c.y; a.stats = e->stats; a.B = B; a.H = H; a.C = C;
     a.wc = c.wc; a.wo = c.wo; a.wco = c.wco; a.training = c.training; a.want_grad = c.want_grad;
     return a;

@@ -579,9 +579,9 @@ __global__ void __launch_bounds__(NT) k_loss(const float* __restrict__ z, const 
                                               float* __restrict__ stats, double* __restrict__ db2, int B, int C,
                                               float wc, float wo, float wco, int want_grad) {
     __shared__ double red[NT];
-    __shared__ double tot[4];
+    __shared__ double tot[6];
     const float w[3] = {wc, wo, wco};
-    double part[4] = {0.0, 0.0, 0.0, 0.0};   // c, o, co, correct
+    double part[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // losses c, o, co; hits o, c, co
     const float u = 1.0f / (float)C, invB = 1.0f / (float)B;
     for (int t = threadIdx.x; t < 3 * B; t += NT) {
         const int hd = t / B, b = t % B;
@@ -605,9 +605,10 @@ __global__ void __launch_bounds__(NT) k_loss(const float* __restrict__ z, const 
             }
         }
         if (hd == 1) { part[1] += (double)(-(zr[yy] - lse)); part[3] += (arg == yy) ? 1.0 : 0.0; }
-        if (hd == 2) part[2] += (double)(-(zr[yy] - lse));
+        if (hd == 2) { part[2] += (double)(-(zr[yy] - lse)); part[5] += (arg == yy) ? 1.0 : 0.0; }
+        if (hd == 0) part[4] += (arg == yy) ? 1.0 : 0.0;
     }
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 6; ++q) {
         red[threadIdx.x] = part[q];
         __syncthreads();
         for (int o = NT / 2; o > 0; o >>= 1) {
@@ -620,7 +621,7 @@ __global__ void __launch_bounds__(NT) k_loss(const float* __restrict__ z, const 
     if (threadIdx.x == 0) {
         const float lc = (float)(tot[0] * invB), lo = (float)(tot[1] * invB), lco = (float)(tot[2] * invB);
         stats[0] = wc * lc + wo * lo + wco * lco;
-        stats[1] = lc; stats[2] = lo; stats[3] = lco; stats[4] = (float)tot[3];
+        stats[1] = lc; stats[2] = lo; stats[3] = lco; stats[4] = (float)tot[3]; stats[5] = (float)tot[4]; stats[6] = (float)tot[5];
     }
     if (want_grad) {
         __syncthreads();

@@ -61,8 +61,8 @@ struct RoArgs {
     float* dy1;                           // [3,B,H]
     float* dxin;                          // [3,B,H] gradient w.r.t. the three readout inputs
     const int64_t* y;
-    float* rowloss;                       // [4,B]: per-graph loss of the three heads, hit flag of the o head
-    float* stats;                         // [8]: [1+h] = loss of head h, [4] = correct_o
+    float* rowloss;                       // [6,B]: per-graph loss of the three heads, then their hit flags (argmax == y)
+    float* stats;                         // [8]: [1+h] = loss of head h, [4] = correct_o, [5] = correct_c, [6] = correct_co (eval_acc_causal, train_causal.py:214-218)
     int B, H, C;
     float wc, wo, wco;
     int training, want_grad;
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) k_ro_fwd_b(const RoArgs a) {
             }
         }
         a.rowloss[(size_t)hd * B + b] = (float)lrow;
-        if (hd == 1) a.rowloss[(size_t)3 * B + b] = arg == yy ? 1.f : 0.f;
+        a.rowloss[(size_t)(3 + hd) * B + b] = arg == yy ? 1.f : 0.f;
     }
     RO_CLK(10);
 }
@@ -402,15 +402,15 @@ __device__ __forceinline__ void ro_loss_sums(const RoArgs& a, int hd, float lv, 
     }
     if (threadIdx.x == 0) {
         a.stats[1 + hd] = (float)(red[0] / (double)a.B);
-        if (hd == 1) a.stats[4] = (float)red[256];
+        a.stats[hd == 1 ? 4 : (hd == 0 ? 5 : 6)] = (float)red[256];
     }
     __syncthreads();
 }
 __device__ __forceinline__ void ro_loss_load(const RoArgs& a, int hd, float& lv, float& cv) {
     const int b = min((int)threadIdx.x, a.B - 1);
     const bool ok = (int)threadIdx.x < a.B;
-    const float l = a.rowloss[(size_t)hd * a.B + b], c = a.rowloss[(size_t)3 * a.B + b];
-    lv = ok ? l : 0.f; cv = ok && hd == 1 ? c : 0.f;
+    const float l = a.rowloss[(size_t)hd * a.B + b], c = a.rowloss[(size_t)(3 + hd) * a.B + b];
+    lv = ok ? l : 0.f; cv = ok ? c : 0.f;
 }
 // forward-only steps (no k_ro_bwd_a): grid (3)
 __global__ void __launch_bounds__(256) k_ro_loss(const RoArgs a) {

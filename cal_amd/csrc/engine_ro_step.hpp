@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
             const float lse = m + logf(se);
             for (int k = 0; k < C; ++k) finish(k, zr[k], lse);
         }
-        lv = (float)lrow; cv = hd == 1 && arg == yy ? 1.f : 0.f;
+        lv = (float)lrow; cv = arg == yy ? 1.f : 0.f;
     }
     if (duty_loss) {                           // per-head loss = mean of the per-graph losses, correct_o = number of hits
         double ls = (double)lv, cs = (double)cv;
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         __syncthreads();
         if (threadIdx.x == 0) {
             a.stats[1 + hd] = (float)((red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (double)B);
-            if (hd == 1) a.stats[4] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+            a.stats[hd == 1 ? 4 : (hd == 0 ? 5 : 6)] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
         }
     }
     __syncthreads();

@@ -190,6 +190,7 @@ class StepEngine:
         self.tiles = {"0": False, "force": "force"}.get(os.environ.get("CAL_AMD_TILES", "1"), True)
         self.tile_min_units = 256
         self._tiles = (0, 0)
+        self._identity = {}             # identity permutations by batch size (eval passes, models that do not shuffle)
         self._ws: Optional[torch.Tensor] = None
         self.ws_generation = 0          # bumped whenever the workspace is re-allocated (captured graphs check it)
         self._cap = (0, 0, 0)
@@ -349,7 +350,9 @@ class StepEngine:
         if mode & 16:
             perm = None                                   # drawn by the step's first kernel
         elif perm is None:
-            perm = torch.arange(B, device=self.device)
+            perm = self._identity.get(B)
+            if perm is None:
+                perm = self._identity[B] = torch.arange(B, device=self.device)
         if y is None:
             y = torch.zeros(B, dtype=torch.long, device=self.device)
         _lib.call("cal_engine_step", self._h, _p(x.contiguous()), _p(ei.contiguous()), _p(bvec.contiguous()),

@@ -169,10 +169,38 @@ def train_causal_epoch(model, optimizer, loader, device, args, grad_sync=None):
     return total_loss, total_loss_c, total_loss_o, total_loss_co, correct_o
 
 
+def _engine_for_eval(model, device, args):
+    """The model's step engine when an evaluation pass can count its hits on the device (engine-backed model on the GPU)."""
+    if torch.device(device).type != "cuda" or not getattr(model, "use_engine", False) or getattr(args, "no_fused_step", False):
+        return None
+    get = getattr(model, "engine", None)
+    return get() if callable(get) else None
+
+
 def eval_acc_causal(model, loader, device, args):
-    """train_causal.py:202-223."""
+    """train_causal.py:202-223.  Engine-backed models: one eval-mode forward call per mini-batch whose readout kernel also
+    counts the three heads' hits (stats[4:7] = o, c, co) -- no log-prob copies, no argmax / compare / sum launches."""
     model.eval()
     eval_random = args.eval_random
+    eng = _engine_for_eval(model, device, args)
+    if eng is not None:
+        hits = torch.zeros(3, dtype=torch.float64, device=device)              # o, c, co
+        shuffles = bool(eval_random and (model.with_random if model._gate_on_with_random else True))
+        stage = None
+        for data in loader:
+            data = data.to(device)
+            perm = None                                                        # identity (model.py:147-152 with the gate off)
+            if shuffles:
+                if stage is None:
+                    stage = getattr(eng, "_perm_stage", None) or _PermStage(device)
+                    eng._perm_stage = stage
+                perm = stage.put(model.intervention_index(num_graphs(data), eval_random))
+            eng.forward(data, perm, training=False)
+            hits.add_(eng.buffer("stats", 8)[4:7])
+        n = len(loader.dataset)
+        acc_o, acc_c, acc_co = (hits / n).tolist()
+        _check_engine(model)
+        return acc_co, acc_c, acc_o
     acc = torch.zeros(3, dtype=torch.float64, device=device)
     for data in loader:
         data = data.to(device)

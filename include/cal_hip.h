@@ -154,8 +154,9 @@ CAL_API int cal_engine_set_gat(void* engine, int64_t heads, float p, float slope
  * slot order of `offs` / `bn_ptrs`.  mode bits: 1 = training-mode forward, 2 = loss gradient +
  * backward into the flat gradient buffer, 4 = Adam (applied inside the step's last kernel; the step counter is advanced by
  * its first one), 8 = Adam follows separately (cal_engine_adam_ticked),
- * 16 = draw the random-intervention permutation on the device inside the step's first kernel (`perm` ignored; cal_engine_set_perm_rng).  Outputs ("logp" [3,B,C], "stats" [5] =
- * loss, c_loss, o_loss, co_loss, correct_o) live in the caller-owned workspace at
+ * 16 = draw the random-intervention permutation on the device inside the step's first kernel (`perm` ignored; cal_engine_set_perm_rng).  Outputs ("logp" [3,B,C], "stats" [7] =
+ * loss, c_loss, o_loss, co_loss, correct_o, correct_c, correct_co: the hit counts eval_acc_causal needs, train_causal.py:214-218)
+ * live in the caller-owned workspace at
  * cal_engine_buffer_offset(name) floats from its base. */
 CAL_API void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L);
 CAL_API void cal_engine_destroy(void* engine);

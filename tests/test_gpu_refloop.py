@@ -205,3 +205,27 @@ def test_train_causal_syn_log_lines_and_device_loader():
     assert getattr(model, "_engine", None) is not None
     for h in history:
         assert abs(h["loss"] - (0.5 * h["loss_c"] + h["loss_o"] + 0.5 * h["loss_co"])) < 1e-5
+
+
+@pytest.mark.parametrize("name,batch", [("CausalGCN", 32), ("CausalGAT", 24), ("CausalGCN", 300)])
+def test_eval_acc_causal_counts_on_the_device_like_the_statement_loop(name, batch):
+    """eval_acc_causal (train_causal.py:202-223): the engine path counts the three heads' hits inside the readout kernel
+    (stats[4:7]); the statement-by-statement loop (``no_fused_step``) takes argmax / eq / sum of the returned log-probs.
+    Same tuple (acc_co, acc_c, acc_o), also with ``eval_random`` shuffling (same Python-RNG stream)."""
+    from cal_amd.device_data import DeviceDataset, DeviceLoader
+    from cal_amd.train_causal import eval_acc_causal
+    gs = _graphs(2 * batch + 5, seed=21)
+    torch.manual_seed(4)
+    sd = O.init_state(name, 10, 4, hidden=64, layers=2, heads=4)
+    for eval_random in (False, True):
+        out = {}
+        for kind in ("engine", "statement"):
+            args = _args(layers=2, hidden=64, eval_random=eval_random, no_fused_step=(kind == "statement"))
+            m = _model(name, {k: v.clone() for k, v in sd.items()}, args)
+            loader = DeviceLoader(DeviceDataset(gs), batch, shuffle=False, pack=False)
+            random.seed(31)
+            out[kind] = eval_acc_causal(m, loader, torch.device(DEV), args)
+        assert len(out["engine"]) == 3 and all(0.0 <= v <= 1.0 for v in out["engine"])
+        # identical up to one graph per head whose two best classes tie within rounding
+        for a, b in zip(out["engine"], out["statement"]):
+            assert abs(a - b) <= 1.0 / len(gs) + 1e-12, (eval_random, out)
