@@ -541,7 +541,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         trainer.flat_g.copy_(saved)
-        dp_diag = {"exchange_in_graph": bool(trainer.exchange_in_graph), "fused_opt": bool(trainer.fused_opt),
+        dp_diag = {"exchange": "one-shot peer-memory kernel (CAL_AMD_P2P_EXCHANGE=1)" if getattr(trainer, "p2p", None) is not None else "all-reduce (%s)" % dist.get_backend(),
+                   "exchange_in_graph": bool(trainer.exchange_in_graph), "fused_opt": bool(trainer.fused_opt),
                    "sequence_graph": bool(seq), "backend": dist.get_backend(),
                    "bucket_bytes": int(trainer.flat_g.numel() * 4),
                    "allreduce_us_eager": 1e3 * e0.elapsed_time(e1) / 20,

@@ -157,6 +157,7 @@ struct Engine {
     float beta1, beta2, eps, wd;
     unsigned long long perm_seed; unsigned long long* perm_ctr;   // device draw of the random-intervention permutation (mode bit 16)
     int64_t* perm_dev;          // [capB] the permutation drawn by the step itself
+    P2PArgs p2p; int p2p_on;    // one-shot peer-memory gradient exchange (cal_engine_p2p_bind)
     float grad_scale;           // gradient factor inside Adam (1 / world_size after a sum all-reduce)
     // parameter offsets (floats into P / G)
     int o_feat_w;
@@ -1961,6 +1962,45 @@ CAL_EXPORT int cal_engine_adam_ticked(void* h, void* stream_) {
     hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
                        e->beta2, e->eps, e->wd, e->nparam, 1, e->grad_scale);
     CAL_CHECK_LAUNCH("k_adam");
+    return 0;
+}
+// ---- one-shot gradient exchange over peer-mapped memory (k_p2p_adam, engine_kernels.hpp) ------------------------------
+// Bytes of the region every rank allocates (zero-initialised, its own allocation) and shares with the others.
+CAL_EXPORT int64_t cal_engine_p2p_region_bytes(void* h) {
+    Engine* e = (Engine*)h;
+    const int64_t np = (e->nparam + 63) / 64 * 64;
+    return (2 * np + 64) * 4;
+}
+// peer_bases[r]: device address, in THIS process, of rank r's region (its own at index `rank`); peer_devices[r]: the HIP device
+// that owns it (peer access is enabled here when it is another device), or null when all regions live on the current device
+CAL_EXPORT int cal_engine_p2p_bind(void* h, void* const* peer_bases, const int64_t* peer_devices, int64_t world, int64_t rank) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e && e->P && world >= 1 && world <= P2P_MAX_WORLD && rank >= 0 && rank < world && peer_bases, "bad arguments (bind the parameters first; at most 8 ranks)");
+    int dev = 0;
+    hipGetDevice(&dev);
+    memset(&e->p2p, 0, sizeof(e->p2p));
+    for (int r = 0; r < world; ++r) {
+        CAL_REQUIRE(peer_bases[r] != nullptr, "null peer region");
+        e->p2p.region[r] = (float*)peer_bases[r];
+        if (peer_devices && (int)peer_devices[r] != dev) {
+            hipError_t rc = hipDeviceEnablePeerAccess((int)peer_devices[r], 0);
+            if (rc != hipSuccess && rc != hipErrorPeerAccessAlreadyEnabled) { set_error("cal_engine_p2p_bind: no peer access to device %d", (int)peer_devices[r]); return 3; }
+            (void)hipGetLastError();
+        }
+    }
+    e->p2p.rank = (int)rank; e->p2p.world = (int)world; e->p2p.np = (e->nparam + 63) / 64 * 64;
+    e->p2p_on = 1;
+    return 0;
+}
+// The exchange + update of a step that ran with mode bit 8 (its last kernel advanced the Adam step counter): ONE launch.
+// The gradient factor is cal_engine_set_grad_scale's (1 / world for the replicas' mean).
+CAL_EXPORT int cal_engine_p2p_adam(void* h, void* stream_) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e && e->p2p_on && e->ws, "cal_engine_p2p_bind first");
+    const AdamArgs A{e->P, e->M1, e->M2, e->step, e->lr, e->beta1, e->beta2, e->eps, e->wd, e->grad_scale, 1};
+    const int nb = (int)std::min<int64_t>(P2P_BLOCKS, cdiv(e->nparam, 256));
+    hipLaunchKernelGGL(k_p2p_adam, dim3(nb), dim3(256), 0, (hipStream_t)stream_, e->p2p, e->G, A, e->nparam, e->status);
+    CAL_CHECK_LAUNCH("k_p2p_adam");
     return 0;
 }
 // Model variants (opts.py:96-103 / model.py:24-31): cat = the random-intervention readout concatenates xc[perm] and xo

@@ -1110,4 +1110,80 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
 }
 __global__ void k_adam_tick(float* step) { step[0] += 1.f; }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One-shot gradient exchange over peer-mapped memory + Adam (the data-parallel exchange of the ~0.5 MB
+// gradient bucket is latency-bound; this is the alternative to the RCCL all-reduce node).  Every rank owns a REGION that all
+// ranks have mapped (IPC handles; xGMI peer access between GPUs):
+//     stage[2][np] floats (two parities of the gradient bucket) | flags[8] u64 | ctr[2] u32 | epoch u64
+// and runs, in stream order behind its backward (cal_engine_step mode 1|2|8):
+//   1. copy its gradient bucket into its own stage[epoch & 1], system-scope fence; the LAST workgroup to finish writes
+//      flags[rank] = epoch into EVERY rank's region (peers poll their own memory);
+//   2. every workgroup waits until all `world` flags of its own region have reached `epoch`, then reads its slice of every
+//      rank's stage (system-scope loads), sums in RANK ORDER (all replicas get the same bits) and applies Adam with the
+//      1 / world gradient factor;
+//   3. the last workgroup through advances the local epoch.
+// Two parities: a rank can only publish epoch e + 1 after its own step e finished, i.e. after it has seen every peer's flag
+// e -- every peer has finished step e - 1's reads by then, so stage[(e + 1) & 1] is free.  The grid (<= P2P_BLOCKS
+// workgroups, grid-stride) is fully resident: the in-kernel wait of step 2 cannot starve step 1.  Spins give up after
+// ~2^22 polls and flag status bit 64 instead of hanging.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int P2P_MAX_WORLD = 8, P2P_BLOCKS = 448;
+struct P2PArgs {
+    float* region[P2P_MAX_WORLD];          // every rank's region, as mapped in THIS process
+    int rank, world;
+    int64_t np;                            // floats per stage parity (nparam rounded up to 64)
+};
+__device__ __forceinline__ unsigned long long* p2p_flags(float* region, int64_t np) { return reinterpret_cast<unsigned long long*>(region + 2 * np); }
+__global__ void __launch_bounds__(256) k_p2p_adam(const P2PArgs pa, const float* __restrict__ G, const AdamArgs A, int64_t nparam,
+                                                  int* __restrict__ status) {
+    float* mine = pa.region[pa.rank];
+    unsigned long long* flags = p2p_flags(mine, pa.np);
+    unsigned* ctr = reinterpret_cast<unsigned*>(flags + P2P_MAX_WORLD);
+    unsigned long long* epoch_p = flags + P2P_MAX_WORLD + 1;
+    __shared__ unsigned long long ep_s;
+    __shared__ int last_s;
+    if (threadIdx.x == 0) ep_s = __hip_atomic_load(epoch_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    __syncthreads();
+    const unsigned long long epoch = ep_s;
+    const int par = (int)(epoch & 1);
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    // 1. publish
+    float* st = mine + (size_t)par * pa.np;
+    for (int64_t i = gid; i < nparam; i += stride) st[i] = G[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ctr + 0, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = old == (unsigned)(gridDim.x * epoch - 1);
+        if (last_s) {
+            __threadfence_system();
+            for (int r = 0; r < pa.world; ++r)
+                __hip_atomic_store(p2p_flags(pa.region[r], pa.np) + pa.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        // 2. wait for every rank's flag in OUR region
+        for (int r = 0; r < pa.world; ++r) {
+            int spins = 0;
+            while (__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 22)) { atomicOr(status, 64); break; }
+            }
+        }
+        __threadfence_system();
+    }
+    __syncthreads();
+    const float adam_t = A.step[0], adam_lr = A.lr[0];
+    for (int64_t i = gid; i < nparam; i += stride) {
+        float g = 0.f;
+        for (int r = 0; r < pa.world; ++r)
+            g += __hip_atomic_load(pa.region[r] + (size_t)par * pa.np + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        adam_update(A, i, g, adam_t, adam_lr);
+    }
+    // 3. the last workgroup through closes the epoch
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(gridDim.x * epoch - 1)) __hip_atomic_store(epoch_p, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace cal

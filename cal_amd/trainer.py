@@ -99,7 +99,8 @@ class CausalTrainer:
     def __init__(self, model, args, lr: float = 1e-3, weight_decay: float = 0.0,
                  use_graph: bool = True, world_size: int = 1, rebuild_plan: bool = True,
                  use_engine: Optional[bool] = None, device_perm: bool = True,
-                 force_exchange: bool = False, graph_exchange: Optional[bool] = None):
+                 force_exchange: bool = False, graph_exchange: Optional[bool] = None,
+                 p2p_exchange: Optional[bool] = None):
         from . import engine as eng_mod
         self.model, self.args = model, args
         self.use_graph = use_graph
@@ -151,8 +152,16 @@ class CausalTrainer:
                                       and dist.get_backend() == "nccl")
         if self.exchange and self.engine is not None:
             self.engine.set_grad_scale(1.0 / max(1, dist.get_world_size()))
+        # one-shot peer-memory exchange instead of the collective (cal_amd/p2p.py): a plain kernel node behind the backward
+        if p2p_exchange is None:
+            p2p_exchange = os.environ.get("CAL_AMD_P2P_EXCHANGE", "0") == "1"
+        self.p2p = None
+        if p2p_exchange and self.exchange and self.engine is not None:
+            from .p2p import P2PExchange
+            self.p2p = P2PExchange(self.engine)
+            self.exchange_in_graph = bool(use_graph)
         # the optimizer update rides in the same graph as forward/backward (always on one GPU)
-        self.fused_opt = self.engine is not None and (not self.exchange or self.exchange_in_graph or not use_graph)
+        self.fused_opt = self.engine is not None and (not self.exchange or self.exchange_in_graph or not use_graph or self.p2p is not None)
         self.model.train()
 
     # ------------------------------------------------------------------ pieces
@@ -214,7 +223,9 @@ class CausalTrainer:
             if not self.exchange:
                 return self.engine.train_step(batch, perm, adam=True, draw_perm=draw)
             stats = self.engine.train_step(batch, perm, adam=False, tick=True, draw_perm=draw)  # k_finish advances the Adam step
-            if self.fused_opt:                        # collective + update in stream order (captured with the step)
+            if self.p2p is not None:                  # publish / wait / sum / Adam: one kernel
+                self.p2p.adam()
+            elif self.fused_opt:                      # collective + update in stream order (captured with the step)
                 dist.all_reduce(self.flat_g)
                 self.engine.adam_ticked()
             return stats

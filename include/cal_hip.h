@@ -197,6 +197,13 @@ CAL_API int cal_engine_set_perm_rng(void* engine, uint64_t seed, uint64_t* count
  * the update in ONE launch with the gradient multiplied by cal_engine_set_grad_scale's factor (1 / world_size = mean) */
 CAL_API int cal_engine_adam_ticked(void* engine, void* stream);
 CAL_API int cal_engine_set_grad_scale(void* engine, float scale);
+/* the same exchange WITHOUT a collective library (the ~0.5 MB bucket is latency-bound): every rank shares one
+ * region (cal_engine_p2p_region_bytes, zero-initialised) with the others through IPC / xGMI peer mappings;
+ * cal_engine_p2p_adam is ONE launch that publishes the bucket, waits for every rank's flag, sums in rank order and applies
+ * Adam.  peer_bases[r] / peer_devices[r]: rank r's region as mapped in this process and the device that owns it. */
+CAL_API int64_t cal_engine_p2p_region_bytes(void* engine);
+CAL_API int cal_engine_p2p_bind(void* engine, void* const* peer_bases, const int64_t* peer_devices, int64_t world, int64_t rank);
+CAL_API int cal_engine_p2p_adam(void* engine, void* stream);
 /* backward from an external d loss / d log-probs [3,B,C] of the last training-mode forward (autograd surface) */
 CAL_API int cal_engine_backward_from(void* engine, const float* x0, const int64_t* batch,
                                      const float* dlogp, int64_t N, int64_t E, int64_t B, void* stream);

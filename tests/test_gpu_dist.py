@@ -34,7 +34,7 @@ def _margs(**kw):
     return argparse.Namespace(**d)
 
 
-def _gloo_worker(rank, world, port, sd, q):
+def _gloo_worker(rank, world, port, sd, q, p2p=False, use_graph=True):
     try:
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -46,8 +46,11 @@ def _gloo_worker(rank, world, port, sd, q):
         m = M.CausalGCN(10, 4, _margs())
         m.load_state_dict(sd)
         m = m.cuda()
-        trn = CausalTrainer(m, _margs(), lr=1e-2, use_graph=True, world_size=world)
-        assert trn.exchange and not trn.exchange_in_graph and not trn.fused_opt
+        trn = CausalTrainer(m, _margs(), lr=1e-2, use_graph=use_graph, world_size=world, p2p_exchange=p2p)
+        if p2p:
+            assert trn.exchange and trn.p2p is not None and trn.fused_opt          # exchange + Adam: one kernel node of the step
+        else:
+            assert trn.exchange and not trn.exchange_in_graph and not trn.fused_opt
         batches = [ref_batch(list(range(12 * rank + 4 * s, 12 * rank + 4 * s + 4)) * 2).to("cuda") for s in range(3)]
         trn.reserve_for(batches)
         out = []
@@ -110,6 +113,40 @@ def test_two_ranks_on_one_gpu_over_gloo_match_the_mean_gradient_oracle():
         else:
             assert k == "conv_feat.bias" and float(g_sum.abs().max()) == 0.0
         off += n
+
+
+def _run_two_ranks(sd, **kw):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, {k: v.clone() for k, v in sd.items()}, q), kwargs=kw) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out, err = q.get(timeout=600)
+        assert err is None, err
+        res[rank] = out
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_one_shot_peer_memory_exchange_equals_the_all_reduce(use_graph):
+    """cal_amd/p2p.py: two ranks on one GPU map each other's region through IPC handles and end every step
+    with k_p2p_adam (publish the bucket, wait for the peer's flag, sum in rank order, Adam) -- eagerly and as a node of the
+    captured step graph.  Replicas stay bit-identical, and with two ranks the sum r0 + r1 is the all-reduce's: parameters
+    equal the gloo all-reduce run bit for bit after three steps."""
+    from oracle import cal_oracle as O
+    torch.manual_seed(12)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=2)
+    ref = _run_two_ranks(sd)
+    got = _run_two_ranks(sd, p2p=True, use_graph=use_graph)
+    for s in range(3):
+        assert np.array_equal(got[0][s][1], got[1][s][1]), s                     # replicas
+        assert np.array_equal(got[0][s][1], ref[0][s][1]), s                     # == all-reduce + Adam
 
 
 def _nccl_worker(port, sd, q):
