@@ -219,7 +219,8 @@ def engine_roofline(trainer, batches, workload, iters=20):
     n = int(h.cal_engine_profile_read(buf, cap))
     rec = np.array(buf[:3 * n], dtype=np.float64).reshape(n, 3)
     out = {}
-    for cls, key in ((0, "gemm"), (1, "spmm"), (2, "gconv"), (3, "dual"), (4, "gconv_bwd"), (5, "gat_fwd"), (6, "gat_bwd"), (7, "ggat"), (8, "ggat_bwd")):
+    for cls, key in ((0, "gemm"), (1, "spmm"), (2, "gconv"), (3, "dual"), (4, "gconv_bwd"), (5, "gat_fwd"), (6, "gat_bwd"), (7, "ggat"), (8, "ggat_bwd"),
+                     (9, "ggin"), (10, "ggin_bwd")):
         r = rec[(rec[:, 0] == cls) & (rec[:, 1] > 0)]
         if len(r) == 0:
             continue
@@ -264,6 +265,10 @@ def engine_roofline(trainer, batches, workload, iters=20):
                                "dense attention-block aggregation MFMA + bias/ReLU/BN statistics (backbone layers, forward)", "k_ggat_fwd"),
         "ggat_bwd": ("k_ggat_bwd", "k_ggat_bwd: per-graph fused GATConv backward -- attention backward on two dense blocks (MFMA) + dX' = dz W^T "
                                    "(BN-backward sums) + dW = x'^T dz + d att (backbone layers, backward)", "k_ggat_bwd"),
+        "ggin": ("k_ggin_fwd", "k_ggin_fwd<1>: per-graph fused GINConv first half -- [n,H]x[H,64] MFMA GEMM (W1^T slice) + unit dense-block aggregation "
+                               "MFMA + bias + BN statistics (backbone layers, forward)", "k_ggin_fwd"),
+        "ggin_bwd": ("k_ggin_bwd", "k_ggin_bwd<1>: per-graph fused GINConv backward, first half -- BatchNorm backward + transposed unit aggregation + "
+                                   "d h = dz W1 + dW1 = dz^T h, all on MFMA (backbone layers, backward)", "k_ggin_bwd"),
         "dual": ("k_gemm_dual", "k_gemm_dual / k_gemm_big_dual: dX = dZ W^T (NT, BN-backward sums) + dW = BN(h)^T dZ (TN, split-K) in one grid "
                                 "(backbone layers, backward)", "k_gemm_dual"),
     }

@@ -820,7 +820,10 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             memset(&ga, 0, sizeof(ga));
             ga.x = hin; ga.W = e->P + e->o_conv_w[i - 1]; ga.bias = e->P + e->o_conv_b[i - 1]; ga.out = t1;
             if (c.training) { ga.st_sum = graph_acc(c, bn_stsum(c, i), H); ga.st_sq = graph_acc(c, bn_stsq(c, i), H); }
-            hipLaunchKernelGGL((k_ggin_fwd<1>), dim3(T, H / GC_N), dim3(512), 0, st, gd, e->gptr, e->eptr, ga, H, H, e->status);
+            {
+                ProfScope ps(st, 9, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
+                PROF_LAUNCH((k_ggin_fwd<1>), dim3(T, H / GC_N), dim3(512), 0, st, gd, e->gptr, e->eptr, ga, H, H, e->status);
+            }
             CAL_CHECK_LAUNCH("k_ggin_fwd<1>"); STAGE();
             RC(flush_finals(c)); STAGE();
             memset(&ga, 0, sizeof(ga));
@@ -1452,7 +1455,10 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             ga.slab = e->slabs + slab_off;
             fa.st[fa.nst++] = SlabTask{ga.slab, e->G + e->o_conv_w[i - 1], H * H, T};
             slab_off += (size_t)T * H * H;
-            hipLaunchKernelGGL((k_ggin_bwd<1>), dim3(T, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+            {
+                ProfScope ps(st, 10, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
+                PROF_LAUNCH((k_ggin_bwd<1>), dim3(T, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
+            }
             CAL_CHECK_LAUNCH("k_ggin_bwd<1>"); STAGE();
             if (i == 1 && F <= FM_F && H <= FB_H) {
                 RC(feat_bwd(d0, two ? d1 : nullptr, true)); STAGE();

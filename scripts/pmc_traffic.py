@@ -9,8 +9,9 @@ from cal_amd.build import kernel_source_sha
 fetch, write, workload = json.load(open(sys.argv[1])), json.load(open(sys.argv[2])), sys.argv[3]
 # bench.py roofline class -> substring of the kernel name in the PMC summaries
 classes = {
-    "k_gconv_fwd": "k_gconv_fwd<false", "k_gconv_fwd_co": "k_gconv_fwd<true", "k_gconv_bwd": "k_gconv_bwd<false, 1>",
-    "k_gconv_bwd_top": "k_gconv_bwd<false, 0>", "k_gconv_bwd_co": "k_gconv_bwd<true, 2>", "k_att_fwd_graph": "k_att_fwd_graph",
+    "k_gconv_fwd": "k_gconv_fwd<false", "k_gconv_fwd_co": "k_gconv_fwd<true", "k_gconv_bwd": "k_gconv_bwd<false, 1",
+    "k_gconv_bwd_top": "k_gconv_bwd<false, 0", "k_gconv_bwd_co": "k_gconv_bwd<true, 2", "k_att_fwd_graph": "k_att_fwd_graph",
+    "k_ggin_fwd": "k_ggin_fwd<1>", "k_ggin_bwd": "k_ggin_bwd<1>", "k_feat_bwd": "k_feat_bwd",
     "k_att_bwd_graph": "k_att_bwd_graph", "k_finish": "k_finish", "k_espmm": "k_espmm", "k_gemm_backbone": "k_gemm<",
     "k_gemm_dual": "k_gemm_dual", "k_ggat_fwd": "k_ggat_fwd", "k_ggat_bwd": "k_ggat_bwd", "k_gat_fwd": "k_gat_fwd",
     "k_gat_bwd_dst": "k_gat_bwd_dst", "k_gat_bwd_src": "k_gat_bwd_src", "k_gemm_big": "k_gemm_big<", "k_gemm_big_dual": "k_gemm_big_dual",
