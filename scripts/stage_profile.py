@@ -12,6 +12,10 @@ if os.environ.get("CAL_STAGE_DATA") == "nci1":          # config 4 stand-in: 512
     from cal_amd import synth
     gl = synth.tu_like(512, kind="nci1", seed=5)
     nf, nc = 139, 2
+elif os.environ.get("CAL_STAGE_DATA") == "mutag":       # config 3 stand-in: 64 MUTAG-like graphs, F = 109, 2 classes
+    from cal_amd import synth
+    gl = synth.tu_like(64, kind="mutag", seed=5)
+    nf, nc = 109, 2
 elif os.environ.get("CAL_STAGE_DATA") == "nn15":        # the reference's default SPMotif shape (opts.py:18): 32 graphs of ~235 nodes
     gl = spmotif.train_mix(32, seed=5, node_num=15)
     nf, nc = 10, 4
