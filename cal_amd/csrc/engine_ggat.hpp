@@ -343,9 +343,9 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     constexpr int T = GB_T;
     __shared__ float um_s[GC_N], ur_s[GC_N], ug_s[GC_N], u1_s[GC_N], u2_s[GC_N];     // upper BatchNorm, this slice's columns
     __shared__ float bs_s[GB_NT / 64][16][4];
-    __shared__ __attribute__((aligned(16))) float Bk[T * GB_LDJ];          // alpha~ of the current head: Bk[i][j] (edge j -> i)
+    __shared__ __attribute__((aligned(16))) float Bk[T * GB_LDJ];          // alpha~ of the slice's first head: Bk[i][j] (edge j -> i); the second head's block and dalpha live in Ws until W is committed
     __shared__ __attribute__((aligned(16))) float Ds[T * GB_LDD];          // dOut slice [j][n]; later dz [i][n]
-    __shared__ __attribute__((aligned(16))) float Zt[GC_N * GB_LDJ];       // dalpha of the current head [i][j]; later dz^T [n][i]
+    __shared__ __attribute__((aligned(16))) float Zt[GC_N * GB_LDJ];       // dalpha of the first head [i][j]; later dz^T [n][i]
     __shared__ __attribute__((aligned(16))) float Ws[GC_K * GB_LDD];       // W[:, ns] as loaded: Ws[k_in][n] (16 B operand reads, see k_gconv_bwd)
     __shared__ __attribute__((aligned(16))) float Xs[T * GB_LDX];          // x_hat rows [i][k_in]
     __shared__ __attribute__((aligned(16))) float Zr[T * GB_LDD];          // z slice [j][n]
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     __shared__ int ptr_s[T + 4];
     __shared__ signed char en[GGB_E], er[GGB_E];        // source / destination node of a CSR slot, local to the graph
     __shared__ int ee[GGB_E];
-    __shared__ float al_s[GGB_E + T], ak_s[GGB_E + T], dk_s[GGB_E + T], dr_s[GGB_E + T];     // per slot (edges, then self loops), current head
+    __shared__ float al_s[2][GGB_E + T], dk_s[2][GGB_E + T], dr_s[2][GGB_E + T];     // per (head of the slice, slot): edges, then self loops
     __shared__ float att_s[2 * GC_N];
     __shared__ float ad_s[2][T], as_s[2][T], mx_s[2][T], dn_s[2][T], dad_s[2][T], das_s[2][T];
     BLK_CLK(0);
@@ -456,8 +456,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     }
     if (!UP) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
     ro_commit<GB_NT>(bz, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Zr + j * GB_LDD + 4 * n4) = v; });
-    ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) { *reinterpret_cast<float4*>(Ws + k * GB_LDD + 4 * n4) = v; });
-    __syncthreads();                                     // BN constants
+    __syncthreads();                                     // BN constants (W stays in registers: its LDS tile holds the second head's blocks first)
     ro_commit<GB_NT>(bx, rows, K4, [&](int i, int k4, float4 v) {
         const int k = 4 * k4;
         v.x = (v.x - mean_s[k]) * rstd_s[k]; v.y = (v.y - mean_s[k + 1]) * rstd_s[k + 1];
@@ -517,100 +516,137 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     const float inv_keep = a.p > 0.f ? 1.f / (1.f - a.p) : 1.f;
     const int rt = w >> 1, ct = w & 1;                   // waves 0-3: the 32 x 32 tile (rt, ct) of a 64 x 64 product
     BLK_CLK(2);
-    // ---- the heads of the slice, one after the other ------------------------------------------------------------------
-    for (int h = 0; h < hs; ++h) {
-        const int hg = h0 + h;
-        // (a) dalpha block: Zt[i][j] = <g_i, z_j> over the head's D columns (rows i x columns j, reduction over D)
-        if (w < 4 && rt < R && ct < R) {
+    // ---- the heads of the slice, side by side (D = 32: two heads, 256 lanes each in the per-slot passes; D = 64: one) ----------
+    // One head after the other, this section was 4 barriers and ~7 us per head with a quarter of the lanes busy.
+    static_assert(GC_K * GB_LDD >= 2 * GC_N * GB_LDJ, "the W tile holds the second head's dalpha and alpha~ blocks");
+    float* const Zt1 = Ws;                               // dalpha of the second head
+    float* const Bk1 = Ws + GC_N * GB_LDJ;               // alpha~ of the second head
+    const int nsl = ne + rows;                           // slots: the graph's edges, then one self loop per node
+    const int LPH = GB_NT / hs;                          // lanes per head in the per-slot passes
+    const int hq = t / LPH, tl = t - hq * LPH;
+    {
+        // (a) dalpha blocks: Zt_h[i][j] = <g_i, z_j> over the head's D columns -- waves 0-3 the first head, 4-7 the second
+        const int ha = w >> 2, rta = (w & 3) >> 1, cta = w & 1;
+        if (ha < hs && rta < R && cta < R) {
+            float* Zh = ha ? Zt1 : Zt;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-            gb_mma_rowk(Ds + (rt * 32 + li) * GB_LDD + h * D, Zr + (ct * 32 + li) * GB_LDD + h * D, D, lk, acc[0]);      // (16 B reads: the 4 B form was a 4-way bank conflict)
+            gb_mma_rowk(Ds + (rta * 32 + li) * GB_LDD + ha * D, Zr + (cta * 32 + li) * GB_LDD + ha * D, D, lk, acc[0]);      // (16 B reads: the 4 B form was a 4-way bank conflict)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                Zt[i * GB_LDJ + ct * 32 + li] = acc[0][r];
+                const int i = rta * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                Zh[i * GB_LDJ + cta * 32 + li] = acc[0][r];
             }
         }
-        for (int i = t; i < (T * GB_LDJ) / 4; i += GB_NT) reinterpret_cast<float4*>(Bk)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
-        // (b1) one lane per slot -- the graph's edges, then one self loop per node: alpha, alpha * keep, keep * dalpha.
-        //      (One lane per destination ROW made the hub rows of a BA graph the critical path: 2 passes x 30 slots of
-        //      expf + mask hash in one lane, 7 us per head.)
-        for (int s = t; s < ne + rows; s += GB_NT) {
-            const bool self = s >= ne;
-            const int i = self ? s - ne : er[s], j = self ? s - ne : en[s];
-            float al = 0.f, kp = 0.f, dk = 0.f;
-            if (j >= 0) {
-                al = expf(gg_lrelu(ad_s[h][i] + as_s[h][j], a.slope) - mx_s[h][i]) / dn_s[h][i];
-                kp = keep_scale(seed, self ? a.E + g0 + i : (int64_t)ee[s], hg, a.heads, a.p, inv_keep);
-                dk = Zt[i * GB_LDJ + j] * kp;
-            }
-            al_s[s] = al; ak_s[s] = al * kp; dk_s[s] = dk;
+        for (int i = t; i < (T * GB_LDJ) / 4; i += GB_NT) {
+            reinterpret_cast<float4*>(Bk)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hs > 1) reinterpret_cast<float4*>(Bk1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
-        // (b2 + b3) one lane per slot: S_i = sum over the slots of its destination row of alpha * dalpha, computed by the lane
-        //      itself in slot order (8 independent LDS reads per round; the row sums used to be a phase of their own -- one
-        //      lane per row, a barrier, the other 450 lanes idle), then d(raw logit) into dr_s and alpha~ into the block
-        //      (atomic: duplicate edges share an entry)
-        for (int s = t; s < ne + rows; s += GB_NT) {
-            const bool self = s >= ne;
-            const int i = self ? s - ne : er[s], j = self ? s - ne : en[s];
-            float dr = 0.f;
-            if (j >= 0) {
-                float S = al_s[ne + i] * dk_s[ne + i];
-                const int s1 = ptr_s[i + 1];
-                for (int q0 = ptr_s[i]; q0 < s1; q0 += 8) {
-                    float x[8], y[8];
+    }
+    __syncthreads();
+    // (b1) one lane per (head, slot): alpha, alpha * keep (stays in a register for b2), keep * dalpha.
+    //      (One lane per destination ROW made the hub rows of a BA graph the critical path: 2 passes x 30 slots of
+    //      expf + mask hash in one lane, 7 us per head.)
+    float akr[3] = {0.f, 0.f, 0.f};
+    {
+        const float* Zh = hq ? Zt1 : Zt;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { const int sq = min(q0 + q, s1 - 1); x[q] = al_s[sq]; y[q] = dk_s[sq]; }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) S = fmaf(q0 + q < s1 ? x[q] : 0.f, y[q], S);
+        for (int it = 0; it < 3; ++it) {
+            const int s = tl + it * LPH;
+            if (s < nsl) {
+                const bool self = s >= ne;
+                const int i = self ? s - ne : er[s], j = self ? s - ne : en[s];
+                float al = 0.f, kp = 0.f, dk = 0.f;
+                if (j >= 0) {
+                    al = expf(gg_lrelu(ad_s[hq][i] + as_s[hq][j], a.slope) - mx_s[hq][i]) / dn_s[hq][i];
+                    kp = keep_scale(seed, self ? a.E + g0 + i : (int64_t)ee[s], h0 + hq, a.heads, a.p, inv_keep);
+                    dk = Zh[i * GB_LDJ + j] * kp;
                 }
-                const float raw = ad_s[h][i] + as_s[h][j];
-                dr = al_s[s] * (dk_s[s] - S) * (raw > 0.f ? 1.f : a.slope);
-                atomicAdd(&Bk[i * GB_LDJ + j], ak_s[s]);
+                al_s[hq][s] = al; akr[it] = al * kp; dk_s[hq][s] = dk;
             }
-            dr_s[s] = dr;
         }
-        __syncthreads();
-        // (c) waves 0-3: dz tile (rows j, 32 columns of this head) = alpha~^T G_h; waves 4-5: d a_dst_i (row sums of dr);
-        //     waves 6-7: d a_src_j (the slots whose source is j, scanned in slot order: deterministic)
-        if (w < 4) {
-            if (rt < R && (ct * 32) / D == h) gb_mma<1, 1, GB_LDJ, GB_LDD>(Bk + rt * 32 + li, nullptr, Ds + ct * 32 + li, nullptr, rowsP, lk, ident, dzacc);
-        } else if (w < 6) {
-            const int i = t - 256;
-            if (i < rows) {
-                float sd = dr_s[ne + i];
-                const int s1 = ptr_s[i + 1];
-                for (int s = ptr_s[i]; s < s1; s += 8) {
-                    float y[8];
+    }
+    __syncthreads();
+    // (b2 + b3) one lane per (head, slot): S_i = sum over the slots of its destination row of alpha * dalpha, computed by the lane
+    //      itself in slot order (8 independent LDS reads per round; the row sums used to be a phase of their own -- one
+    //      lane per row, a barrier, the other 450 lanes idle), then d(raw logit) into dr_s and alpha~ into the block
+    //      (atomic: duplicate edges share an entry)
+    {
+        float* Bh = hq ? Bk1 : Bk;
+        const float* alh = al_s[hq];
+        const float* dkh = dk_s[hq];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) y[q] = dr_s[min(s + q, s1 - 1)];
+        for (int it = 0; it < 3; ++it) {
+            const int s = tl + it * LPH;
+            if (s < nsl) {
+                const bool self = s >= ne;
+                const int i = self ? s - ne : er[s], j = self ? s - ne : en[s];
+                float dr = 0.f;
+                if (j >= 0) {
+                    float S = alh[ne + i] * dkh[ne + i];
+                    const int s1 = ptr_s[i + 1];
+                    for (int q0 = ptr_s[i]; q0 < s1; q0 += 8) {
+                        float x[8], y[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) sd += s + q < s1 ? y[q] : 0.f;
+                        for (int q = 0; q < 8; ++q) { const int sq = min(q0 + q, s1 - 1); x[q] = alh[sq]; y[q] = dkh[sq]; }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) S = fmaf(q0 + q < s1 ? x[q] : 0.f, y[q], S);
+                    }
+                    const float raw = ad_s[hq][i] + as_s[hq][j];
+                    dr = alh[s] * (dkh[s] - S) * (raw > 0.f ? 1.f : a.slope);
+                    atomicAdd(&Bh[i * GB_LDJ + j], akr[it]);
                 }
-                dad_s[h][i] = sd;
+                dr_s[hq][s] = dr;
             }
-        } else {
-            // two lanes per source node j, each scanning one half of the slots in order; lane 0 adds the halves
-            const int j = (t - 384) >> 1, half = (t - 384) & 1;
+        }
+    }
+    __syncthreads();
+    // (c) waves 0-3: dz tile (rows j, 32 columns: the head those columns belong to) = alpha~^T G_h; waves 4-7: d a_src_j (the
+    //     slots whose source is j, scanned in slot order by two lanes per (head, node): deterministic), then d a_dst_i (row sums of dr)
+    if (w < 4) {
+        if (rt < R) {
+            const float* Bh = (ct * 32) / D ? Bk1 : Bk;
+            gb_mma<1, 1, GB_LDJ, GB_LDD>(Bh + rt * 32 + li, nullptr, Ds + ct * 32 + li, nullptr, rowsP, lk, ident, dzacc);
+        }
+    } else {
+        const int q = t - 256;
+        {
+            const int hh = q >> 7, j = (q & 127) >> 1, half = q & 1;
             const int qb = half ? (ne + 1) / 2 : 0, qe = half ? ne : (ne + 1) / 2;
+            const float* drh = dr_s[min(hh, hs - 1)];
             float sj = 0.f;
-            if (j < rows) {
+            if (hh < hs && j < rows) {
                 for (int q0 = qb; q0 < qe; q0 += 8) {
                     int e8[8];
                     float y[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) { const int sq = min(q0 + q, qe - 1); e8[q] = en[sq]; y[q] = dr_s[sq]; }
+                    for (int u = 0; u < 8; ++u) { const int sq = min(q0 + u, qe - 1); e8[u] = en[sq]; y[u] = drh[sq]; }
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) sj += (q0 + q < qe && e8[q] == j) ? y[q] : 0.f;
+                    for (int u = 0; u < 8; ++u) sj += (q0 + u < qe && e8[u] == j) ? y[u] : 0.f;
                 }
             }
             const float other = __shfl_xor(sj, 1, 64);
-            if (j < rows && half == 0) das_s[h][j] = dr_s[ne + j] + sj + other;
+            if (hh < hs && j < rows && half == 0) das_s[hh][j] = drh[ne + j] + sj + other;
         }
-        __syncthreads();
+        if (q < 2 * T) {
+            const int hh = q >> 6, i = q & 63;
+            if (hh < hs && i < rows) {
+                const float* drh = dr_s[hh];
+                float sd = drh[ne + i];
+                const int s1 = ptr_s[i + 1];
+                for (int s0 = ptr_s[i]; s0 < s1; s0 += 8) {
+                    float y[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) y[u] = drh[min(s0 + u, s1 - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sd += s0 + u < s1 ? y[u] : 0.f;
+                }
+                dad_s[hh][i] = sd;
+            }
+        }
     }
+    __syncthreads();
+    ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) { *reinterpret_cast<float4*>(Ws + k * GB_LDD + 4 * n4) = v; });
     BLK_CLK(3);
     // ---- dz = aggregated part + the two rank-1 terms; d att of this slice's heads -----------------------------------------
     if (w < 4 && rt < R) {
