@@ -63,6 +63,45 @@ struct GconvBranch2 { GconvBranch b[2]; };
 
 typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- storing a 32 x 32 MFMA accumulator tile --------------------------------------------------------------------------
+// Lane (li, lk) of a 32x32 tile holds ONE column (li) of the rows (r & 3) + 8 (r >> 2) + 4 lk: stored as it lies that is 16
+// 4-byte store instructions per tile.  The four registers of a row group and the four lanes of a quad form a 4 x 4 block of
+// (row, column): transposed inside the quad (two DPP exchanges, no LDS) every lane holds four CONSECUTIVE columns of one
+// row, i.e. one 16-byte store -- 4 instructions per tile instead of 16, same bytes, same addresses.  Measured on
+// k_gconv_bwd (profiles/r3/store_burst.txt): the store phase of a workgroup is 3.4 us of its 12 us and stays 2.8 us with
+// the wide stores -- it is bound by BYTES (every one of the 256 workgroups stores its 64 KB in the same 3 us: ~6 TB/s
+// chip-wide), not by instruction issue; the wide form is kept for the 0.5 us.
+__device__ __forceinline__ float gc_dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float gc_dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+// in: lane q of the quad holds (v0..v3) = column q of rows 0..3; out: row q of columns 0..3
+__device__ __forceinline__ void gc_quad_transpose(float& v0, float& v1, float& v2, float& v3, int q) {
+    const bool o1 = q & 1, o2 = q & 2;
+    float r = gc_dpp_xor1(o1 ? v0 : v1);
+    if (o1) v0 = r; else v1 = r;
+    r = gc_dpp_xor1(o1 ? v2 : v3);
+    if (o1) v2 = r; else v3 = r;
+    r = gc_dpp_xor2(o2 ? v0 : v2);
+    if (o2) v0 = r; else v2 = r;
+    r = gc_dpp_xor2(o2 ? v1 : v3);
+    if (o2) v1 = r; else v3 = r;
+}
+// tile(row, col) -> base[row * ld + col] for the rows with row < nrow (base, ld: 16-byte aligned / a multiple of 4 floats);
+// f(v): applied to every element before the store (bias, ReLU ..)
+template <typename F>
+__device__ __forceinline__ void gc_store_tile(const gc_f32x16& acc, float* base, size_t ld, int nrow, int li, int lk, F f) {
+    const int q = li & 3, c4 = li & ~3;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v0 = f(acc[4 * g]), v1 = f(acc[4 * g + 1]), v2 = f(acc[4 * g + 2]), v3 = f(acc[4 * g + 3]);
+        gc_quad_transpose(v0, v1, v2, v3, q);
+        const int row = 8 * g + 4 * lk + q;
+        if (row < nrow) *reinterpret_cast<float4*>(base + (size_t)row * ld + c4) = make_float4(v0, v1, v2, v3);
+    }
+}
+__device__ __forceinline__ void gc_store_tile(const gc_f32x16& acc, float* base, size_t ld, int nrow, int li, int lk) {
+    gc_store_tile(acc, base, ld, nrow, li, lk, [](float v) { return v; });
+}
+
 // kred/32 blocks of 16 MFMA steps over k-major LDS operands A[k][row] (stride LDA) and B[k][col]
 // (stride LDB); TWO = this wave also owns row tile r0 + 2 (graphs with more than 64 nodes)
 template <bool TWO, int LDA, int LDB>
@@ -469,7 +508,7 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
             const int row = r0 * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
             float v = acc0[r] + bias;
             if (relu) v = fmaxf(v, 0.f);
-            if (row < rows) br.out[(size_t)(g0 + row) * H + col] = v;
+            acc0[r] = v;                                 // (stored below, four columns per lane)
             const float vm = row < rows ? v : 0.f;
             if (TILED) Ot[row * LDO + ct * 32 + li] = vm;
             f1[r & 3] += vm; f2[r & 3] = fmaf(vm, vm, f2[r & 3]);
@@ -480,12 +519,14 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
                 const int row = (r0 + 2) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 float v = acc1[r] + bias;
                 if (relu) v = fmaxf(v, 0.f);
-                if (row < rows) br.out[(size_t)(g0 + row) * H + col] = v;
+                acc1[r] = v;
                 const float vm = row < rows ? v : 0.f;
                 if (TILED) Ot[row * LDO + ct * 32 + li] = vm;
                 f1[r & 3] += vm; f2[r & 3] = fmaf(vm, vm, f2[r & 3]);
             }
         }
+        gc_store_tile(acc0, br.out + (size_t)(g0 + r0 * 32) * H + n0 + ct * 32, H, rows - r0 * 32, li, lk);
+        if (r0 + 2 < R) gc_store_tile(acc1, br.out + (size_t)(g0 + (r0 + 2) * 32) * H + n0 + ct * 32, H, rows - (r0 + 2) * 32, li, lk);
     }
     psum = (f1[0] + f1[1]) + (f1[2] + f1[3]);
     double s1 = ((double)f1[0] + (double)f1[1]) + ((double)f1[2] + (double)f1[3]);

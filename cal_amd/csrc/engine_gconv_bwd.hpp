@@ -484,11 +484,13 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
             for (int r = 0; r < 16; ++r) {
                 const int i = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 const float v = acc[q][r];                   // (row tile 1 of a one-tile graph: zero accumulators)
-                if (i < rows) dxp[(size_t)(g0 + i) * K + k] = v;
                 f1[r & 3] += v;
                 f2[r & 3] = fmaf(v, xh[q][r], f2[r & 3]);
             }
         }
+        // (16-byte stores, four columns per lane: gc_store_tile)
+        gc_store_tile(acc[0], dxp + (size_t)g0 * K + w * 32, K, rows, li, lk);
+        if (R == 2) gc_store_tile(acc[1], dxp + (size_t)(g0 + 32) * K + w * 32, K, rows - 32, li, lk);
         double s1 = ((double)f1[0] + (double)f1[1]) + ((double)f1[2] + (double)f1[3]);
         double s2 = ((double)f2[0] + (double)f2[1]) + ((double)f2[2] + (double)f2[3]);
         s1 += __shfl_xor(s1, 32, 64);
@@ -505,12 +507,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
         gb_mma<1, 2, GB_LDX, GB_LDD>(Xs + wq * 32 + li, nullptr, Ds + li, Ds + 32 + li, rowsP, lk, affine, acc);
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kk = wq * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                slab[(size_t)kk * H + ns0 + q * 32 + li] = acc[q][r];
-            }
+        for (int q = 0; q < 2; ++q) gc_store_tile(acc[q], slab + (size_t)(wq * 32) * H + ns0 + q * 32, H, 32, li, lk);
     }
     BLK_CLK(1);
 }
