@@ -1043,7 +1043,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     if (use_ro(c) && want_grad && c.training && B <= RS_B && H <= RS_K && e->ro_step) {
         // the whole readout, forward and backward, in one launch (engine_ro_step.hpp)
         RoStepArgs sa;
-        sa.a = make_ro(c); sa.zpart = e->zpart; sa.sync = reinterpret_cast<int*>(e->arena + e->a_sync);
+        sa.a = make_ro(c); sa.zpart = e->zpart; sa.sync = reinterpret_cast<int*>(e->arena + e->a_sync); sa.status = e->status;
         hipLaunchKernelGGL(k_ro_step, dim3(3, H / RO_CW), dim3(256), 0, st, sa);
         CAL_CHECK_LAUNCH("k_ro_step"); STAGE();
         c.ro_done = 1;

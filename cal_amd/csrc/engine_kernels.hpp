@@ -608,14 +608,33 @@ __global__ void __launch_bounds__(NT) k_loss(const float* __restrict__ z, const 
         if (hd == 2) { part[2] += (double)(-(zr[yy] - lse)); part[5] += (arg == yy) ? 1.0 : 0.0; }
         if (hd == 0) part[4] += (arg == yy) ? 1.0 : 0.0;
     }
-    for (int q = 0; q < 6; ++q) {
-        red[threadIdx.x] = part[q];
+    // the six sums in two levels behind two barriers (six trees of log2(NT) barrier-separated stages were ~8 us of this kernel
+    // at NT = 1024): wave sums by DPP-free LDS strips -- thread (q, j) adds the 64 values of statistic q that wave j parked
+    constexpr int NW = NT / 64;
+    static_assert(6 * NW <= NT, "one thread per (statistic, wave)");
+    {
+        __shared__ double park[6][NT + 8];
+        __shared__ double wsum[6][NW];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) park[q][threadIdx.x] = part[q];
         __syncthreads();
-        for (int o = NT / 2; o > 0; o >>= 1) {
-            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
+        if (threadIdx.x < 6 * NW) {
+            const int q = threadIdx.x / NW, j = threadIdx.x % NW;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 64; k += 4) {
+                a0 += park[q][j * 64 + k]; a1 += park[q][j * 64 + k + 1];
+                a2 += park[q][j * 64 + k + 2]; a3 += park[q][j * 64 + k + 3];
+            }
+            wsum[q][j] = (a0 + a1) + (a2 + a3);
         }
-        if (threadIdx.x == 0) tot[q] = red[0];
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) a += wsum[threadIdx.x][j];
+            tot[threadIdx.x] = a;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -636,9 +655,14 @@ __global__ void __launch_bounds__(NT) k_loss(const float* __restrict__ z, const 
         red[threadIdx.x] = sacc;
         __syncthreads();
         if (threadIdx.x < nc) {
-            double tsum = 0.0;
-            for (int q = 0; q < nl; ++q) tsum += red[q * nc + threadIdx.x];
-            db2[threadIdx.x] = tsum;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;      // (four chains: the serial tail was nl dependent fp64 adds)
+            int q = 0;
+            for (; q + 3 < nl; q += 4) {
+                t0 += red[q * nc + threadIdx.x]; t1 += red[(q + 1) * nc + threadIdx.x];
+                t2 += red[(q + 2) * nc + threadIdx.x]; t3 += red[(q + 3) * nc + threadIdx.x];
+            }
+            for (; q < nl; ++q) t0 += red[q * nc + threadIdx.x];
+            db2[threadIdx.x] = (t0 + t1) + (t2 + t3);
         }
     }
 }

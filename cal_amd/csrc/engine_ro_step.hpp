@@ -31,6 +31,7 @@ struct RoStepArgs {
     RoArgs a;
     float* zpart;                         // [3][H/16][B*C] partial logits
     int* sync;                            // [3][2] barrier counters (zero at the start of the step)
+    int* status;                          // the engine's status word (bit 256: a barrier timed out)
 };
 
 // Fences by ONE lane, around the workgroup barriers: the L2 write-back of a release and the invalidate of an acquire are
@@ -41,16 +42,23 @@ __device__ __forceinline__ void ro_step_arrive(int* ctr) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void ro_step_wait(int* ctr, int n) {
+// The poll gives up after ~2^21 rounds (a second or so) and flags status bit 256 instead of hanging the stream: the 24
+// workgroups are co-resident on an idle GPU (the engine checks the CU count), but a co-tenant holding CUs could keep a
+// partner from being dispatched; the step's results are garbage then and check_status says so.
+__device__ __forceinline__ void ro_step_wait(int* ctr, int n, int* status) {
     if (threadIdx.x == 0) {
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) __builtin_amdgcn_s_sleep(1);
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+            if (++spins > (1 << 21)) { if (status) atomicOr(status, 256); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 }
-__device__ __forceinline__ void ro_step_barrier(int* ctr, int n) {
+__device__ __forceinline__ void ro_step_barrier(int* ctr, int n, int* status) {
     ro_step_arrive(ctr);
-    ro_step_wait(ctr, n);
+    ro_step_wait(ctr, n, status);
 }
 // 16 x 16 output tiles (wave w owns tiles w, w + 4, ..) of a product whose operands are both ROW-MAJOR in k in LDS:
 // A[row][k] = X[min(row, nrow - 1) * ld + k] (optionally x * sc[k] + sh[k]), B[k][col] = Wr[col * ld + k].  Lane
@@ -291,7 +299,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         }
     }
     RO_CLK(44);
-    ro_step_barrier(sa.sync + hd * 2, nch);
+    ro_step_barrier(sa.sync + hd * 2, nch, sa.status);
     RO_CLK(45);
 
     // =============================== B: logits, loss, dz; fc2 + BN2 + ReLU backward of the chunk ===============
@@ -438,7 +446,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     RO_CLK(47);
     ro_step_arrive(sa.sync + hd * 2 + 1);
     RO_CLK(48);
-    ro_step_wait(sa.sync + hd * 2 + 1, nch);
+    ro_step_wait(sa.sync + hd * 2 + 1, nch, sa.status);
     RO_CLK(49);
     // =============================== C: fc1 + BN1 backward over the INPUT chunk =================================
     float* Ds = Xs;

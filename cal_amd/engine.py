@@ -259,7 +259,10 @@ class StepEngine:
                     (2, "batch vector is not sorted / has ids outside [0, num_graphs), or ptr / edge_ptr do not match it"),
                     (8, "a graph exceeds the per-graph bounds (max_nodes / max_edges) the batch declared"),
                     (16, "an edge leaves its graph's node range (edge_ptr / ptr are stale)"),
-                    (32, "edge_index has self loops although the batch declared no_self_loops"))
+                    (32, "edge_index has self loops although the batch declared no_self_loops"),
+                    (64, "the peer-memory gradient exchange timed out waiting for another rank"),
+                    (256, "the one-launch readout timed out at an in-kernel barrier (its workgroups were not co-resident: "
+                          "another process is holding CUs; CAL_AMD_RO_STEP=0 runs the readout as separate launches)"))
 
     def check_status(self, reset: bool = True):
         """Synchronising check of the device status word over every step since the last check: the per-graph kernels
