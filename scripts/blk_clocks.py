@@ -9,7 +9,7 @@ from cal_amd.engine import StepEngine
 args = argparse.Namespace(layers=3, hidden=128, with_random=True, without_node_attention=False,
                           without_edge_attention=False, fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
 torch.manual_seed(0)
-m = M.CausalGCN(10, 4, args).cuda().train()
+m = getattr(M, os.environ.get("CAL_STAGE_MODEL", "CausalGCN"))(10, 4, args).cuda().train()      # CAL_STAGE_MODEL=CausalGAT / CausalGIN
 eng = StepEngine(m)
 b = Batch.from_data_list(spmotif.train_mix(128, seed=5)).to("cuda")
 perm = torch.randperm(128, device="cuda")
