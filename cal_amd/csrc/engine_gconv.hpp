@@ -69,8 +69,8 @@ typedef float gc_f32x16 __attribute__((ext_vector_type(16)));
 // (row, column): transposed inside the quad (two DPP exchanges, no LDS) every lane holds four CONSECUTIVE columns of one
 // row, i.e. one 16-byte store -- 4 instructions per tile instead of 16, same bytes, same addresses.  Measured on
 // k_gconv_bwd (profiles/r3/store_burst.txt): the store phase of a workgroup is 3.4 us of its 12 us and stays 2.8 us with
-// the wide stores -- it is bound by BYTES (every one of the 256 workgroups stores its 64 KB in the same 3 us: ~6 TB/s
-// chip-wide), not by instruction issue; the wide form is kept for the 0.5 us.
+// the wide stores -- it is bound by BYTES (a workgroup's 64 KB leave its CU at ~20 GB/s), not by instruction issue; the wide
+// form is kept for the 0.5 us.
 __device__ __forceinline__ float gc_dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ float gc_dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
 // in: lane q of the quad holds (v0..v3) = column q of rows 0..3; out: row q of columns 0..3
