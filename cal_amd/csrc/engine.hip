@@ -176,6 +176,7 @@ struct Engine {
     // float regions
     float *h, *z, *zco, *hco, *anode, *pq, *att, *dis_unit, *dis_co, *pooled, *xco, *y1, *zl, *logp, *stats, *zpart;
     int adam_fused;          // 1: mode-4 steps apply Adam inside k_finish; CAL_AMD_ADAM_FUSED=0 keeps the k_adam launch
+    int ro_rows;             // 1: ... also for 129 .. 512 graphs, in row blocks (k_ro_step<true>); CAL_AMD_RO_ROWS=0: the GEMM chain there
     int ro_step;             // 1: training steps run the readout as one launch (k_ro_step); CAL_AMD_RO_STEP=0 keeps the four kernels
     float *dzl, *dyh1, *dy1, *dxh, *dpool, *dZco, *gn, *gself, *ddeg, *dl, *dzco, *dXhco, *dZ, *dzi, *dXh, *slabs;
     size_t slab_floats;
@@ -233,12 +234,14 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     Engine* e = new Engine();
     memset(e, 0, sizeof(Engine));
     { const char* v = getenv("CAL_AMD_RO_STEP"); e->ro_step = !(v && v[0] == '0'); }
+    { const char* v = getenv("CAL_AMD_RO_ROWS"); e->ro_rows = !(v && v[0] == '0'); }
     {
         // k_ro_step's 3 * H / 16 workgroups (133 KB of LDS each: one per CU) meet at spin barriers: they must all be
         // resident.  A device (or CU mask / partition) with fewer compute units than that takes the four-kernel readout.
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         if (cus < 3 * ((int)H / RO_CW) + 8) e->ro_step = 0;
+        if (cus < 3 * ((int)H / RO_CW) * RBK_MAXRB + 8) e->ro_rows = 0;
     }
     { const char* v = getenv("CAL_AMD_ADAM_FUSED"); e->adam_fused = !(v && v[0] == '0'); }
     e->F = (int)F; e->H = (int)H; e->C = (int)C; e->L = (int)L;
@@ -319,7 +322,7 @@ CAL_EXPORT int cal_engine_bind(void* h, float* P, float* G, float* M1, float* M2
     e->a_dwe = a; a += 2 * H + 4;
     e->a_db1 = a; a += 3 * H;
     e->a_db2 = a; a += (3 * C + 3) / 4 * 4;
-    e->a_sync = a; a += 4;                            // 6 barrier counters of k_ro_step (ints), zeroed with the arena
+    e->a_sync = a; a += (RBK_SYNC_INTS + 1) / 2 + 2;  // barrier counters of k_ro_step (ints: 6, or RBK_SYNC_INTS row-blocked), zeroed with the arena
     e->arena_n = a;
     (void)C;
     return 0;
@@ -694,6 +697,13 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
     return 0;
 }
 
+// the one-launch readout in row blocks (k_ro_step<true>): training steps of 129 .. 512 graphs
+bool use_ro_rows(const Ctx& c) {
+    const Engine* e = c.e;
+    const int B = c.B, H = e->H, C = e->C;
+    return e->ro_rows && e->ro_step && c.training && !e->cat && B > RS_B && B <= RBK_MAXRB * RS_B && H <= RS_K && H % RO_CW == 0 &&
+           RS_B * C <= 2048 && C <= 64 && (size_t)3 * cdiv(B, RS_B) * ((size_t)H * H + (size_t)C * H) <= e->slab_floats;
+}
 bool use_ro(const Ctx& c) {
     const int B = c.B, H = c.e->H, C = c.e->C;
     const int B4 = (B + 15) & ~15;
@@ -1043,10 +1053,28 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     if (use_ro(c) && want_grad && c.training && B <= RS_B && H <= RS_K && e->ro_step) {
         // the whole readout, forward and backward, in one launch (engine_ro_step.hpp)
         RoStepArgs sa;
+        memset(&sa, 0, sizeof(sa));
         sa.a = make_ro(c); sa.zpart = e->zpart; sa.sync = reinterpret_cast<int*>(e->arena + e->a_sync); sa.status = e->status;
-        hipLaunchKernelGGL(k_ro_step, dim3(3, H / RO_CW), dim3(256), 0, st, sa);
+        hipLaunchKernelGGL(k_ro_step<false>, dim3(3, H / RO_CW), dim3(256), 0, st, sa);
         CAL_CHECK_LAUNCH("k_ro_step"); STAGE();
         c.ro_done = 1;
+        return 0;
+    }
+    if (use_ro_rows(c) && want_grad) {
+        // 128 < B <= 512: the same launch in row blocks of 128 graphs (k_ro_step<true>): the sums over all rows are exchanged
+        // between the row blocks inside the kernel, the weight gradients leave as one slab per row block (front of the slab
+        // workspace; engine_backward registers them with k_finish)
+        const int nrb = cdiv(B, RS_B), nch = H / RO_CW;
+        RoStepArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.a = make_ro(c); sa.zpart = e->zpart; sa.sync = reinterpret_cast<int*>(e->arena + e->a_sync); sa.status = e->status;
+        sa.nrb = nrb;
+        sa.xch = parts_alloc(c, (size_t)3 * nch * RBK_XCH);
+        if (!sa.xch) { set_error("engine: partial-row workspace exhausted"); return 2; }
+        sa.gw1_slab = e->slabs; sa.gw2_slab = e->slabs + (size_t)3 * nrb * H * H;
+        hipLaunchKernelGGL(k_ro_step<true>, dim3(3, nch, nrb), dim3(256), 0, st, sa);
+        CAL_CHECK_LAUNCH("k_ro_step"); STAGE();
+        c.ro_done = 2;
         return 0;
     }
     if (use_ro(c)) {
@@ -1140,7 +1168,16 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     memset(d_convb, 0, sizeof(d_convb));
     d_bn0.p = nullptr;
 
-    const bool ro = use_ro(c);
+    const bool ro = use_ro(c) || c.ro_done == 2;
+    if (c.ro_done == 2) {                               // the row-blocked readout left one weight-gradient slab per row block
+        const int nrb = cdiv(B, RS_B);
+        for (int hd = 0; hd < 3; ++hd) {
+            fa.st[fa.nst++] = SlabTask{e->slabs + (size_t)hd * nrb * H * H, e->G + e->o_fc1_w[hd], H * H, nrb};
+            fa.st[fa.nst++] = SlabTask{e->slabs + (size_t)3 * nrb * H * H + (size_t)hd * nrb * C * H, e->G + e->o_fc2_w[hd], C * H, nrb};
+        }
+        slab_off = (size_t)3 * nrb * ((size_t)H * H + (size_t)C * H);
+        slab_off = (slab_off + 63) & ~(size_t)63;
+    }
     if (ro) {
         if (!c.ro_done) {
             const RoArgs ra = make_ro(c);

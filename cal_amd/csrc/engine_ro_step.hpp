@@ -30,9 +30,20 @@ constexpr int RS_LD = RS_K + 4;           // row stride of the [B][K] tile and o
 struct RoStepArgs {
     RoArgs a;
     float* zpart;                         // [3][H/16][B*C] partial logits
-    int* sync;                            // [3][2] barrier counters (zero at the start of the step)
+    int* sync;                            // [3][2] barrier counters (zero at the start of the step); row-blocked: RBK_SYNC_INTS of them
     int* status;                          // the engine's status word (bit 256: a barrier timed out)
+    // row-blocked variant (128 < B <= 512, k_ro_step<true>): grid (3, H/16, nrb); workgroup (hd, ch, rb) owns rows rb*128 ..
+    double* xch;                          // [3][H/16][RBK_XCH] exchange of the row blocks' partial sums
+    float* gw1_slab; float* gw2_slab;     // [3][nrb][H*H], [3][nrb][C*H]: per-row-block weight gradients (k_finish sums them)
+    int nrb;
 };
+// Exchange layout per (head, chunk): four sites (BN1 statistics of all K columns | BN2 statistics | BN2-backward sums + the
+// head's loss / hit partials | BN1-backward sums + d b1 + d b2), each [RBK_MAXRB][values per row block]
+constexpr int RBK_MAXRB = 4;
+constexpr int RBK_N0 = 2 * RS_K, RBK_N1 = 2 * RO_CW, RBK_N2 = 2 * (RO_CW + 1), RBK_N3 = 4 * 64;
+constexpr int RBK_O1 = RBK_MAXRB * RBK_N0, RBK_O2 = RBK_O1 + RBK_MAXRB * RBK_N1, RBK_O3 = RBK_O2 + RBK_MAXRB * RBK_N2;
+constexpr int RBK_XCH = RBK_O3 + RBK_MAXRB * RBK_N3;
+constexpr int RBK_SYNC_INTS = 3 * RBK_MAXRB * 2 + 3 * (RS_K / RO_CW) * 4;      // chunk barriers [3][4][2], then group barriers [3][H/16][4]
 
 // Fences by ONE lane, around the workgroup barriers: the L2 write-back of a release and the invalidate of an acquire are
 // cache-wide operations, so one wave's covers the workgroup once __syncthreads has drained every wave's stores
@@ -109,6 +120,30 @@ __device__ __forceinline__ void ro_mfma_rowk(int ntiles, int kred, const float* 
     }
 }
 
+// Row-blocked variant: the nrb workgroups (hd, ch, *) hold partial sums over their 128-row blocks and every one of them needs
+// the totals.  Thread t < n writes its NV partials to xs[rb][v * n + t]; group barrier (release / acquire as the chunk
+// barriers); every workgroup adds the partials in block order, so all of them get the same bits.  Called by the whole workgroup.
+template <int NV>
+__device__ __forceinline__ void rbk_total(double (&v)[NV], int t, int n, double* xs, int nrb, int rb, int* ctr, int* status) {
+    if (t < n) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) xs[(size_t)rb * NV * n + q * n + t] = v[q];
+    }
+    ro_step_barrier(ctr, nrb, status);
+    if (t < n) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            double tot = 0.0;
+            for (int r = 0; r < nrb; ++r) tot += xs[(size_t)r * NV * n + q * n + t];
+            v[q] = tot;
+        }
+    }
+}
+
+// RBK = false: B <= 128, grid (3, H/16).  RBK = true: 128 < B <= 512 in row blocks of 128, grid (3, H/16, cdiv(B, 128)): the
+// same phases per row block, the five sums over ALL rows (the two BatchNorms' statistics, their backward sums, the loss)
+// exchanged between the row blocks of a (head, chunk) at four more barriers, the weight gradients as one slab per row block.
+template <bool RBK>
 __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     warm_kernargs<(sizeof(RoStepArgs) < 1024 ? sizeof(RoStepArgs) : 1024)>();
     const RoArgs& a = sa.a;
@@ -124,8 +159,13 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     __shared__ int perm_s[256];
     __shared__ double red[2][256];
     __shared__ float c2[6][RO_CW];             // BN2 of the chunk: mean, rstd, gamma, beta; m1, m2 of a BatchNorm backward
+    __shared__ double lossp_s[2];              // RBK: this row block's loss / hit sums of the head (duty_loss workgroups)
     const int hd = blockIdx.x, ch = blockIdx.y, j0 = ch * RO_CW, nch = gridDim.y;
-    const int B = a.B, K = a.H, C = a.C, ld = RS_LD, K4 = K / 4, BC = B * C;
+    const int Bt = a.B, rb = RBK ? (int)blockIdx.z : 0, r0 = rb * RS_B, nrb = RBK ? sa.nrb : 1;      // rows r0 .. r0 + B of the batch's Bt
+    const int B = RBK ? min(RS_B, Bt - r0) : Bt, K = a.H, C = a.C, ld = RS_LD, K4 = K / 4, BC = B * C, BCt = Bt * C;
+    int* const cbar = RBK ? sa.sync + (hd * RBK_MAXRB + rb) * 2 : sa.sync + hd * 2;                 // the head's (row block's) two chunk barriers
+    int* const gbar = sa.sync + 3 * RBK_MAXRB * 2 + (hd * nch + ch) * 4;                           // RBK: the (head, chunk)'s four exchanges
+    double* const xch = RBK ? sa.xch + (size_t)(hd * nch + ch) * RBK_XCH : nullptr;
     const RoHead& h = a.h[hd];
     const int l = threadIdx.x & 63, w = threadIdx.x >> 6, j = l & 15, lk = l >> 4;     // j == threadIdx.x % 16
     const int rl = threadIdx.x / RO_CW;
@@ -161,11 +201,11 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     // Loads of the kernel's first round.  The co head gathers xc[perm]: its perm entry is requested FIRST (loads return in
     // order: asked for behind the tiles it arrived after all of them, and the gather was a second full round, 6.9 us to
     // 41), the weight chunks go out behind it, and the input rows and the gathered rows follow once it is here.
-    int pv = hd == 2 ? (int)a.perm[min((int)threadIdx.x, B - 1)] : 0;
+    int pv = hd == 2 ? (int)a.perm[r0 + min((int)threadIdx.x, B - 1)] : 0;
     float g2 = h.bn2.gamma[j0 + j], b2n = h.bn2.beta[j0 + j], rm2 = h.bn2.run_mean[j0 + j], rv2 = h.bn2.run_var[j0 + j];
     float bias1 = h.b1[j0 + j];
     float rm1 = h.bn1.run_mean[min((int)threadIdx.x, K - 1)], rv1 = h.bn1.run_var[min((int)threadIdx.x, K - 1)];
-    int ylab = (int)a.y[min((int)threadIdx.x, B - 1)];
+    int ylab = (int)a.y[r0 + min((int)threadIdx.x, B - 1)];
     {
         RoBatch<float4, 2> bw;
         RoBatch<float, 8> bt;
@@ -185,18 +225,18 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
             perm_s[threadIdx.x] = pv;
             __syncthreads();
             RoBatch<float4, 16> bp;
-            ro_issue(bx, B, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(a.pooled + (size_t)(B + b) * K + c * 4); });
+            ro_issue(bx, B, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(a.pooled + (size_t)(Bt + r0 + b) * K + c * 4); });
             ro_issue(bp, B, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(a.pooled + (size_t)perm_s[b] * K + c * 4); });
             commit_weights();
             ro_commit2(bx, bp, B, K4, [&](int b, int c, const float4 o, const float4 p) {
                 const float4 v = make_float4(p.x + o.x, p.y + o.y, p.z + o.z, p.w + o.w);
                 *reinterpret_cast<float4*>(Xs + b * ld + c * 4) = v;
                 if (colfix) add_stats(v);
-                if (duty_xco) *reinterpret_cast<float4*>(a.xco + (size_t)b * K + c * 4) = v;
+                if (duty_xco) *reinterpret_cast<float4*>(a.xco + (size_t)(r0 + b) * K + c * 4) = v;
             });
-            if (duty_xco && (int)threadIdx.x < B) a.iperm[pv] = threadIdx.x;
+            if (duty_xco && (int)threadIdx.x < B) a.iperm[pv] = r0 + threadIdx.x;
         } else {
-            const float* src = a.pooled + (hd == 0 ? (size_t)0 : (size_t)B * K);
+            const float* src = a.pooled + (hd == 0 ? (size_t)0 : (size_t)Bt * K) + (size_t)r0 * K;
             ro_issue(bx, B, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(src + (size_t)b * K + c * 4); });
             commit_weights();
             ro_commit(bx, B, K4, [&](int b, int c, const float4 v) {
@@ -221,14 +261,19 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
             red8[4 + c][threadIdx.x] = (double)qf[c] + 2.0 * P * S0 + n0 * P * P;
         }
         __syncthreads();
+        double SQ[2] = {0.0, 0.0};
         if ((int)threadIdx.x < K) {
-            const int k = threadIdx.x, g = k >> 2, c = k & 3;
-            double S = 0.0, Q = 0.0;
-            for (int p = 0; p < np; ++p) { S += red8[c][p * K4 + g]; Q += red8[4 + c][p * K4 + g]; }
+            const int g = threadIdx.x >> 2, c = threadIdx.x & 3;
+            for (int p = 0; p < np; ++p) { SQ[0] += red8[c][p * K4 + g]; SQ[1] += red8[4 + c][p * K4 + g]; }
+        }
+        if (RBK) rbk_total<2>(SQ, threadIdx.x, K, xch, nrb, rb, gbar + 0, sa.status);
+        if ((int)threadIdx.x < K) {
+            const int k = threadIdx.x;
+            const double S = SQ[0], Q = SQ[1];
             float sc, sh, mean, rstd;
             ro_bn_from_sums(h.bn1, k, S, Q, sc, sh, mean, rstd);
             sc_s[k] = sc; sh_s[k] = sh; mean1_s[k] = mean; rstd1_s[k] = rstd;
-            if (duty_run1) {
+            if (duty_run1 && rb == 0) {
                 const double m = S * (double)h.bn1.inv_n;
                 double v = Q * (double)h.bn1.inv_n - m * m;
                 if (v < 0.0) v = 0.0;
@@ -268,19 +313,23 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         red[0][threadIdx.x] = S0 + n0 * P; red[1][threadIdx.x] = (double)s2 + 2.0 * P * S0 + n0 * P * P;
     }
     __syncthreads();
+    double SQ2[2] = {0.0, 0.0};
+    if (threadIdx.x < RO_CW)
+        for (int p = 0; p < 16; ++p) { SQ2[0] += red[0][p * RO_CW + threadIdx.x]; SQ2[1] += red[1][p * RO_CW + threadIdx.x]; }
+    if (RBK) rbk_total<2>(SQ2, threadIdx.x, RO_CW, xch + RBK_O1, nrb, rb, gbar + 1, sa.status);
     if (threadIdx.x < RO_CW) {                 // BN2 of the chunk (column-local: final values)
-        double S = 0.0, Q = 0.0;
-        for (int p = 0; p < 16; ++p) { S += red[0][p * RO_CW + threadIdx.x]; Q += red[1][p * RO_CW + threadIdx.x]; }
-        h.st2_sum[j0 + threadIdx.x] = S;
-        h.st2_sq[j0 + threadIdx.x] = Q;
+        const double S = SQ2[0], Q = SQ2[1];
+        if (rb == 0) { h.st2_sum[j0 + threadIdx.x] = S; h.st2_sq[j0 + threadIdx.x] = Q; }
         const double m = S * (double)h.bn2.inv_n;
         double v = Q * (double)h.bn2.inv_n - m * m;
         if (v < 0.0) v = 0.0;
         c2[0][threadIdx.x] = (float)m; c2[1][threadIdx.x] = 1.0f / sqrtf((float)v + h.bn2.eps);
         c2[2][threadIdx.x] = g2; c2[3][threadIdx.x] = b2n;
-        h.bn2.run_mean[j0 + threadIdx.x] = 0.9f * rm2 + 0.1f * (float)m;
-        h.bn2.run_var[j0 + threadIdx.x] = 0.9f * rv2 + 0.1f * (float)(v * (double)h.bn2.unbias);
-        if (ch == 0 && threadIdx.x == 0 && h.bn2.nbt) *h.bn2.nbt += 1;
+        if (rb == 0) {
+            h.bn2.run_mean[j0 + threadIdx.x] = 0.9f * rm2 + 0.1f * (float)m;
+            h.bn2.run_var[j0 + threadIdx.x] = 0.9f * rv2 + 0.1f * (float)(v * (double)h.bn2.unbias);
+            if (ch == 0 && threadIdx.x == 0 && h.bn2.nbt) *h.bn2.nbt += 1;
+        }
     }
     __syncthreads();
     const float mean2 = c2[0][j], rstd2 = c2[1][j], gam2 = c2[2][j], bet2 = c2[3][j];
@@ -290,7 +339,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     }
     __syncthreads();
     {
-        float* zp = sa.zpart + ((size_t)hd * nch + ch) * BC;
+        float* zp = sa.zpart + ((size_t)hd * nch + ch) * BCt + (size_t)r0 * C;
         for (int o = threadIdx.x; o < BC; o += 256) {
             const int b = o / C, c = o % C;
             const float4* yr = reinterpret_cast<const float4*>(yn + b * RO_CW);
@@ -299,7 +348,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         }
     }
     RO_CLK(44);
-    ro_step_barrier(sa.sync + hd * 2, nch, sa.status);
+    ro_step_barrier(cbar, nch, sa.status);
     RO_CLK(45);
 
     // =============================== B: logits, loss, dz; fc2 + BN2 + ReLU backward of the chunk ===============
@@ -310,7 +359,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
             const int o = min(o0 + v * 256 + (int)threadIdx.x, BC - 1);
             bz[v] = h.b2[o % C];
 #pragma unroll
-            for (int p = 0; p < 8; ++p) pz[v][p] = sa.zpart[((size_t)hd * nch + min(p, nch - 1)) * BC + o];
+            for (int p = 0; p < 8; ++p) pz[v][p] = sa.zpart[((size_t)hd * nch + min(p, nch - 1)) * BCt + (size_t)r0 * C + o];
         }
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
@@ -327,7 +376,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
             z += bz[v];
             if (o < BC) {
                 zs[o] = z;
-                if (duty_out) a.zl[(size_t)hd * BC + o] = z;
+                if (duty_out) a.zl[(size_t)hd * BCt + (size_t)r0 * C + o] = z;
             }
         }
     }
@@ -335,7 +384,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
     float lv = 0.f, cv = 0.f;
     if ((int)threadIdx.x < B) {                // log_softmax / per-graph loss / dz (in place): one lane per graph
         const int b = threadIdx.x;
-        const float u = 1.0f / (float)C, invB = 1.0f / (float)B, logu = logf(u);
+        const float u = 1.0f / (float)C, invB = 1.0f / (float)Bt, logu = logf(u);
         const float wgt = hd == 0 ? a.wc : (hd == 1 ? a.wo : a.wco);
         float* zr = zs + b * C;
         const int yy = ylab;
@@ -349,7 +398,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
             const float p = expf(lp);
             const float dz = wgt * invB * (hd == 0 ? (p - u) : (p - (k == yy ? 1.f : 0.f)));
             zr[k] = dz;
-            if (duty_out) { a.logp[(size_t)hd * BC + b * C + k] = lp; a.dzl[(size_t)hd * BC + b * C + k] = dz; }
+            if (duty_out) { a.logp[(size_t)hd * BCt + (size_t)(r0 + b) * C + k] = lp; a.dzl[(size_t)hd * BCt + (size_t)(r0 + b) * C + k] = dz; }
         };
         if (C <= 8) {                              // the row in registers: one batch of LDS reads instead of three passes
             float zc[8];
@@ -381,13 +430,18 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         if (l == 0) { red[0][w] = ls; red[1][w] = cs; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            a.stats[1 + hd] = (float)((red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (double)B);
-            a.stats[hd == 1 ? 4 : (hd == 0 ? 5 : 6)] = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+            const double lsum = red[0][0] + red[0][1] + red[0][2] + red[0][3], csum = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            if (RBK) { lossp_s[0] = lsum; lossp_s[1] = csum; }       // (summed over the row blocks with the BN2-backward sums below)
+            else {
+                a.stats[1 + hd] = (float)(lsum / (double)Bt);
+                a.stats[hd == 1 ? 4 : (hd == 0 ? 5 : 6)] = (float)csum;
+            }
         }
     }
     __syncthreads();
     RO_CLK(46);
     const float* dzs = zs;
+    double db1_keep = 0.0, db2_keep = 0.0;
     {
         // d(BN2 out)[b, j] = sum_c dz[b, c] W2[c, j] for this lane's 8 rows: the class loop outside, so that a step is
         // nine independent LDS reads (inside the row guard it was one read pair + wait per (row, class))
@@ -414,9 +468,19 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         double t1 = (double)t1f, t2 = (double)t2f;
         red[0][threadIdx.x] = t1; red[1][threadIdx.x] = t2;
         __syncthreads();
+        if (rl == 0) for (int p = 1; p < 16; ++p) { t1 += red[0][p * RO_CW + j]; t2 += red[1][p * RO_CW + j]; }
+        if (RBK) {             // threads 0-15: the chunk's sums; thread 16: the head's loss / hits (duty_loss workgroups, else zeros)
+            double tt[2] = {rl == 0 ? t1 : 0.0, rl == 0 ? t2 : 0.0};
+            if (threadIdx.x == RO_CW) { tt[0] = duty_loss ? lossp_s[0] : 0.0; tt[1] = duty_loss ? lossp_s[1] : 0.0; }
+            rbk_total<2>(tt, threadIdx.x, RO_CW + 1, xch + RBK_O2, nrb, rb, gbar + 2, sa.status);
+            t1 = tt[0]; t2 = tt[1];
+            if (threadIdx.x == RO_CW && duty_loss && rb == 0) {
+                a.stats[1 + hd] = (float)(tt[0] / (double)Bt);
+                a.stats[hd == 1 ? 4 : (hd == 0 ? 5 : 6)] = (float)tt[1];
+            }
+        }
         if (rl == 0) {
-            for (int p = 1; p < 16; ++p) { t1 += red[0][p * RO_CW + j]; t2 += red[1][p * RO_CW + j]; }
-            h.d2_sum[j0 + j] = t1; h.d2_prod[j0 + j] = t2;
+            if (rb == 0) { h.d2_sum[j0 + j] = t1; h.d2_prod[j0 + j] = t2; }
             c2[4][j] = (float)(t1 * (double)h.bn2.inv_n); c2[5][j] = (float)(t2 * (double)h.bn2.inv_n);
         }
         __syncthreads();
@@ -429,7 +493,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
                 const float yv = y1c[b * RO_CW + j];
                 const float n = (yv - mean2) * rstd2;
                 const float dy = yv > 0.f ? gs * (dyh[b * RO_CW + j] - m1 - n * m2) : 0.f;     // ReLU mask
-                a.dy1[((size_t)hd * B + b) * K + j0 + j] = dy;
+                a.dy1[((size_t)hd * Bt + r0 + b) * K + j0 + j] = dy;
                 sbf += dy;
             }
         }
@@ -438,20 +502,20 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         __syncthreads();
         if (rl == 0) {
             for (int p = 1; p < 16; ++p) sb += red[0][p * RO_CW + j];
-            h.db1[j0 + j] = sb;
+            if (RBK) db1_keep = sb; else h.db1[j0 + j] = sb;       // (RBK: summed over the row blocks with the BN1-backward sums)
         }
     }
     // barrier 2 of the head, then phase C's dy1 tile is requested at once; d b2 and d W2 (LDS only; gradients nobody in
     // this kernel reads) run while it is in flight
     RO_CLK(47);
-    ro_step_arrive(sa.sync + hd * 2 + 1);
+    ro_step_arrive(cbar + 1);
     RO_CLK(48);
-    ro_step_wait(sa.sync + hd * 2 + 1, nch, sa.status);
+    ro_step_wait(cbar + 1, nch, sa.status);
     RO_CLK(49);
     // =============================== C: fc1 + BN1 backward over the INPUT chunk =================================
     float* Ds = Xs;
     RoBatch<float4, 16> bd;
-    ro_issue(bd, B, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(a.dy1 + ((size_t)hd * B + b) * K + c * 4); });
+    ro_issue(bd, B, K4, [&](int b, int c) { return *reinterpret_cast<const float4*>(a.dy1 + ((size_t)hd * Bt + r0 + b) * K + c * 4); });
     if (duty_db2) {                            // d b2[c] = sum_b dz[b, c]
         const int np = 256 / C, c = threadIdx.x % C, part = threadIdx.x / C;
         double sdz = 0.0;
@@ -460,7 +524,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         __syncthreads();
         if (part == 0) {
             for (int p2 = 1; p2 < np; ++p2) sdz += red[0][p2 * C + c];
-            h.db2[c] = sdz;
+            if (RBK) db2_keep = sdz; else h.db2[c] = sdz;
         }
         __syncthreads();
     }
@@ -481,7 +545,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
             __syncthreads();
             if (part == 0) {
                 for (int p = 1; p < np; ++p) accw += fred[p * no + threadIdx.x];
-                h.gW2[(size_t)c * K + j0 + jj] = accw;
+                (RBK ? sa.gw2_slab + ((size_t)hd * nrb + rb) * C * K : h.gW2)[(size_t)c * K + j0 + jj] = accw;
             }
         }
     }
@@ -505,11 +569,24 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         }
     red[0][threadIdx.x] = (double)u1; red[1][threadIdx.x] = (double)u2;
     __syncthreads();
-    if (threadIdx.x < RO_CW) {
-        double S = 0.0, Q = 0.0;
-        for (int p = 0; p < 16; ++p) { S += red[0][p * RO_CW + threadIdx.x]; Q += red[1][p * RO_CW + threadIdx.x]; }
-        h.d1_sum[i0 + threadIdx.x] = S; h.d1_prod[i0 + threadIdx.x] = Q;
-        c2[4][threadIdx.x] = (float)(S * (double)h.bn1.inv_n); c2[5][threadIdx.x] = (float)(Q * (double)h.bn1.inv_n);
+    {
+        double uu[4] = {0.0, 0.0, 0.0, 0.0};       // BN1-backward sums; RBK: + this row block's d b1 (threads 0-15) and d b2 (threads 0 .. C-1 of the duty workgroup)
+        if (threadIdx.x < RO_CW)
+            for (int p = 0; p < 16; ++p) { uu[0] += red[0][p * RO_CW + threadIdx.x]; uu[1] += red[1][p * RO_CW + threadIdx.x]; }
+        if (RBK) {
+            uu[2] = threadIdx.x < RO_CW ? db1_keep : 0.0;
+            uu[3] = (duty_db2 && (int)threadIdx.x < C) ? db2_keep : 0.0;
+            rbk_total<4>(uu, threadIdx.x, 64, xch + RBK_O3, nrb, rb, gbar + 3, sa.status);
+            if (rb == 0) {
+                if (threadIdx.x < RO_CW) h.db1[j0 + threadIdx.x] = uu[2];
+                if (duty_db2 && (int)threadIdx.x < C) h.db2[threadIdx.x] = uu[3];
+            }
+        }
+        if (threadIdx.x < RO_CW) {
+            const double S = uu[0], Q = uu[1];
+            if (rb == 0) { h.d1_sum[i0 + threadIdx.x] = S; h.d1_prod[i0 + threadIdx.x] = Q; }
+            c2[4][threadIdx.x] = (float)(S * (double)h.bn1.inv_n); c2[5][threadIdx.x] = (float)(Q * (double)h.bn1.inv_n);
+        }
     }
     __syncthreads();
     {
@@ -522,7 +599,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
                 if (b < B) {
                     const float xr = xn[b * RO_CW + i];
                     const float n = (xr - mean1) * rstd1;
-                    a.dxin[((size_t)hd * B + b) * K + i0 + i] = gs1 * (dacc[t][r] - m1 - n * m2);
+                    a.dxin[((size_t)hd * Bt + r0 + b) * K + i0 + i] = gs1 * (dacc[t][r] - m1 - n * m2);
                     xn[b * RO_CW + i] = fmaf(xr, gs1, sh1);      // BN1 output (fc1 input) for d W1
                 }
             }
@@ -538,7 +615,7 @@ __global__ void __launch_bounds__(256) k_ro_step(const RoStepArgs sa) {
         if (w + 4 * t < K / 16) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                h.gW1[(size_t)((w + 4 * t) * 16 + lk * 4 + r) * K + i0 + i] = wacc[t][r];
+                (RBK ? sa.gw1_slab + ((size_t)hd * nrb + rb) * K * K : h.gW1)[(size_t)((w + 4 * t) * 16 + lk * 4 + r) * K + i0 + i] = wacc[t][r];
         }
     RO_CLK(52);
 }
