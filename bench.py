@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- graphs/sec of the CAL causal train step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+    python bench.py --gpus N --steps K --warmup W          (any N: for N > 1 without a launcher it re-execs itself under
+                                                            torch.distributed.run, one rank per GPU, 127.0.0.1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N > 1, launcher given)
 
 A "step" = forward (3 heads) + 0.5*KL + 1.0*NLL + 0.5*NLL + backward + Adam
 (train_causal.py:173-192) on one pre-collated, HBM-resident mini-batch of
@@ -59,7 +60,35 @@ def parse():
     ap.add_argument("--no-sequence", action="store_true", help="one hipGraph launch per step instead of one per pass over the resident batches")
     ap.add_argument("--no-engine", action="store_true", help="operator-level autograd path instead of the native step engine")
     ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; value = median (BASELINE.md section 3)")
+    ap.add_argument("--dry", action="store_true", help="launch plumbing only: rendezvous, one collective, the JSON line's shape with value null (no model, no timed region; runs without a GPU over CAL_BENCH_BACKEND=gloo)")
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a) -> None:
+    """`python bench.py --gpus N` (N > 1) without a launcher: re-exec the same command line under torch.distributed.run, one
+    rank per GPU, rendezvous on 127.0.0.1 -- the form the driver uses for N = 1 then works for N = 2/4/8 unmodified.  Never
+    returns.  Fewer than N visible devices is an error here, before any rank starts (ranks would otherwise share a device
+    and RCCL would hang or fail late); CAL_BENCH_BACKEND=gloo lifts the check (test aid: ranks may share devices)."""
+    backend = os.environ.get("CAL_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and not a.dry:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < a.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (one rank per GPU; HIP_VISIBLE_DEVICES=%r)"
+                             % (a.gpus, have, os.environ.get("HIP_VISIBLE_DEVICES")))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
 
 
 def model_args(wl):
@@ -435,6 +464,37 @@ def reference_loop(wl, margs, gs, steps=60):
     return out
 
 
+def dry_run(a, wl, world, rank, local_rank):
+    """--dry: everything the launch needs and nothing the measurement does -- process group up (RCCL when GPUs are there, else
+    CAL_BENCH_BACKEND=gloo), one all-reduce so that every rank is seen, rank 0 prints the line with value null."""
+    import torch.distributed as dist
+    backend = os.environ.get("CAL_BENCH_BACKEND", "nccl")
+    dev = torch.device("cpu")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+        dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+    seen = 1
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        t = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        seen = int(t.item())
+    out = {"metric": "graphs/sec (train step) on SPMotif b=0.9 batch=128" if wl["data"] == "spmotif" else
+                     "graphs/sec (train step) on %s batch=%d" % (a.workload, wl["batch"]),
+           "value": None, "unit": "graphs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry": True,
+           "config": {"workload": a.workload, "model": wl["model"], "batch_per_gpu": wl["batch"], "global_batch": wl["batch"] * world,
+                      "parallelism": "dp%d" % world},
+           "data_parallel": {"backend": backend if world > 1 else None, "rccl_ranks_seen": seen}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     wl = WORKLOADS[a.workload]
@@ -442,8 +502,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+        if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+            self_launch(a)              # re-exec under torch.distributed.run; does not return
+        raise SystemExit("bench.py --gpus %d inside a launcher with WORLD_SIZE=%d: the two must agree" % (a.gpus, world))
+    if a.dry:
+        return dry_run(a, wl, world, rank, local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     # CAL_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than
@@ -555,7 +618,7 @@ def main():
         trainer.flat_g.copy_(saved)
         dp_diag = {"exchange": "one-shot peer-memory kernel (CAL_AMD_P2P_EXCHANGE=1)" if getattr(trainer, "p2p", None) is not None else "all-reduce (%s)" % dist.get_backend(),
                    "exchange_in_graph": bool(trainer.exchange_in_graph), "fused_opt": bool(trainer.fused_opt),
-                   "sequence_graph": bool(seq), "backend": dist.get_backend(),
+                   "sequence_graph": bool(seq), "backend": dist.get_backend(), "rccl_ranks_seen": dist.get_world_size(),
                    "bucket_bytes": int(trainer.flat_g.numel() * 4),
                    "allreduce_us_eager": 1e3 * e0.elapsed_time(e1) / 20,
                    "ms_per_step_by_rank": [round(1e3 * float(t.item()) / a.steps, 5) for t in allr]}

@@ -158,6 +158,8 @@ struct Engine {
     unsigned long long perm_seed; unsigned long long* perm_ctr;   // device draw of the random-intervention permutation (mode bit 16)
     int64_t* perm_dev;          // [capB] the permutation drawn by the step itself
     P2PArgs p2p; int p2p_on;    // one-shot peer-memory gradient exchange (cal_engine_p2p_bind)
+    int* p2p_host_status = nullptr;   // host-mapped word k_p2p_adam sets when an exchange timed out (cal_engine_p2p_status)
+    int p2p_max_polls = 1 << 22;
     float grad_scale;           // gradient factor inside Adam (1 / world_size after a sum all-reduce)
     // parameter offsets (floats into P / G)
     int o_feat_w;
@@ -261,6 +263,7 @@ CAL_EXPORT void cal_engine_destroy(void* h) {
     if (!e) return;
     for (int i = 0; i < 24; ++i) { hipEventDestroy(e->ev_fork[i]); hipEventDestroy(e->ev_join[i]); }
     hipStreamDestroy(e->side);
+    if (e->p2p_host_status) hipHostFree(e->p2p_host_status);
     delete e;
 }
 
@@ -822,7 +825,9 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     const bool gc = use_gc(c);
     const bool gat = e->K > 0;
     for (int i = 1; i <= L; ++i) {
-        if (e->gin && gc && gc_small(c) && e->max_edges <= gc_edge_cap(64)) {
+        // A training forward must leave what the backward of the SAME shape reads: the fused layer writes gt1 only, the
+        // node-level backward (T > 512 units, max_edges > GB_E) needs gagg / gy -> fused only where the backward is fused too.
+        if (e->gin && gc && gc_small(c) && e->max_edges <= gc_edge_cap(64) && (!c.training || (use_gcb(c) && e->max_edges <= GB_E))) {
             // GINConv per graph (engine_ggin.hpp): (A + I)(h W1^T) + b1 with the BatchNorm statistics | BN, ReLU, Linear, ReLU
             const float* hin = e->h + (size_t)(i - 1) * NH;
             float* t1 = e->gt1 + (size_t)(i - 1) * NH;
@@ -2008,7 +2013,49 @@ CAL_EXPORT int cal_engine_adam_ticked(void* h, void* stream_) {
     return 0;
 }
 // ---- one-shot gradient exchange over peer-mapped memory (k_p2p_adam, engine_kernels.hpp) ------------------------------
-// Bytes of the region every rank allocates (zero-initialised, its own allocation) and shares with the others.
+// The regions must be FINE-GRAINED device memory: a kernel that polls a flag a peer GPU writes and then reads the peer's bucket
+// while both kernels run needs stores that become visible across devices without a kernel boundary; coarse-grained hipMalloc
+// memory (what torch allocates) promises that only at kernel boundaries (RCCL allocates its buffers the same way).
+CAL_EXPORT int cal_p2p_alloc(int64_t bytes, void** out) {
+    CAL_REQUIRE(bytes > 0 && out, "bad arguments");
+    void* p = nullptr;
+    hipError_t rc = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained);
+    if (rc != hipSuccess || !p) { (void)hipGetLastError(); set_error("cal_p2p_alloc: hipExtMallocWithFlags(fine-grained, %lld bytes): %s", (long long)bytes, hipGetErrorString(rc)); return 3; }
+    rc = hipMemset(p, 0, (size_t)bytes);
+    if (rc == hipSuccess) rc = hipDeviceSynchronize();
+    if (rc != hipSuccess) { (void)hipGetLastError(); hipFree(p); set_error("cal_p2p_alloc: zeroing failed: %s", hipGetErrorString(rc)); return 3; }
+    *out = p;
+    return 0;
+}
+CAL_EXPORT int cal_p2p_free(void* p) {
+    if (p && hipFree(p) != hipSuccess) { (void)hipGetLastError(); set_error("cal_p2p_free failed"); return 3; }
+    return 0;
+}
+// 64-byte IPC handle of a cal_p2p_alloc region (hipIpcGetMemHandle) / its mapping in another process (hipIpcOpenMemHandle)
+CAL_EXPORT int cal_p2p_export(void* p, void* handle64) {
+    CAL_REQUIRE(p && handle64, "bad arguments");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    hipIpcMemHandle_t hd;
+    hipError_t rc = hipIpcGetMemHandle(&hd, p);
+    if (rc != hipSuccess) { (void)hipGetLastError(); set_error("cal_p2p_export: hipIpcGetMemHandle: %s", hipGetErrorString(rc)); return 3; }
+    memcpy(handle64, &hd, 64);
+    return 0;
+}
+CAL_EXPORT int cal_p2p_open(const void* handle64, void** out) {
+    CAL_REQUIRE(handle64 && out, "bad arguments");
+    hipIpcMemHandle_t hd;
+    memcpy(&hd, handle64, 64);
+    void* p = nullptr;
+    hipError_t rc = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
+    if (rc != hipSuccess || !p) { (void)hipGetLastError(); set_error("cal_p2p_open: hipIpcOpenMemHandle: %s", hipGetErrorString(rc)); return 3; }
+    *out = p;
+    return 0;
+}
+CAL_EXPORT int cal_p2p_close(void* p) {
+    if (p && hipIpcCloseMemHandle(p) != hipSuccess) { (void)hipGetLastError(); set_error("cal_p2p_close failed"); return 3; }
+    return 0;
+}
+// Bytes of the region every rank allocates (cal_p2p_alloc: zero-initialised, its own allocation) and shares with the others.
 CAL_EXPORT int64_t cal_engine_p2p_region_bytes(void* h) {
     Engine* e = (Engine*)h;
     const int64_t np = (e->nparam + 63) / 64 * 64;
@@ -2031,9 +2078,29 @@ CAL_EXPORT int cal_engine_p2p_bind(void* h, void* const* peer_bases, const int64
             (void)hipGetLastError();
         }
     }
+    if (!e->p2p_host_status) {
+        hipError_t rc = hipHostMalloc((void**)&e->p2p_host_status, 64, hipHostMallocMapped | hipHostMallocCoherent);
+        if (rc != hipSuccess) { (void)hipGetLastError(); e->p2p_host_status = nullptr; set_error("cal_engine_p2p_bind: hipHostMalloc failed"); return 3; }
+    }
+    *e->p2p_host_status = 0;
+    e->p2p.host_status = e->p2p_host_status; e->p2p.max_polls = e->p2p_max_polls;
     e->p2p.rank = (int)rank; e->p2p.world = (int)world; e->p2p.np = (e->nparam + 63) / 64 * 64;
     e->p2p_on = 1;
     return 0;
+}
+// Bound of the peer-flag wait in polls (~0.5-2 us each; default 2^22).  A launch ENQUEUED (or captured) after this call uses it.
+CAL_EXPORT int cal_engine_p2p_set_timeout(void* h, int64_t max_polls) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e && max_polls >= 1 && max_polls <= (1ll << 30), "bad arguments");
+    e->p2p_max_polls = (int)max_polls; e->p2p.max_polls = (int)max_polls;
+    return 0;
+}
+// 0, or 64 once an exchange has timed out (the word is host-mapped: no device synchronisation, cheap enough for every step).
+// After a timeout k_p2p_adam updates nothing any more; allocate fresh regions and bind again to resume.
+CAL_EXPORT int64_t cal_engine_p2p_status(void* h) {
+    Engine* e = (Engine*)h;
+    if (!e || !e->p2p_host_status) return 0;
+    return (int64_t)__atomic_load_n(e->p2p_host_status, __ATOMIC_ACQUIRE);
 }
 // The exchange + update of a step that ran with mode bit 8 (its last kernel advanced the Adam step counter): ONE launch.
 // The gradient factor is cal_engine_set_grad_scale's (1 / world for the replicas' mean).

@@ -1137,25 +1137,31 @@ __global__ void k_adam_tick(float* step) { step[0] += 1.f; }
 // ------------------------------------------------------------------------------------------------------------------
 // One-shot gradient exchange over peer-mapped memory + Adam (the data-parallel exchange of the ~0.5 MB
 // gradient bucket is latency-bound; this is the alternative to the RCCL all-reduce node).  Every rank owns a REGION that all
-// ranks have mapped (IPC handles; xGMI peer access between GPUs):
-//     stage[2][np] floats (two parities of the gradient bucket) | flags[8] u64 | ctr[2] u32 | epoch u64
+// ranks have mapped (FINE-GRAINED device memory from cal_p2p_alloc -- coarse-grained hipMalloc memory gives no cross-device
+// visibility inside a running kernel -- shared through IPC handles; xGMI peer access between GPUs):
+//     stage[2][np] floats (two parities of the gradient bucket) | flags[8] u64 | ctr[0..1] u32 | epoch u64 | ctr[2] u32, abort u32
 // and runs, in stream order behind its backward (cal_engine_step mode 1|2|8):
 //   1. copy its gradient bucket into its own stage[epoch & 1], system-scope fence; the LAST workgroup to finish writes
 //      flags[rank] = epoch into EVERY rank's region (peers poll their own memory);
-//   2. every workgroup waits until all `world` flags of its own region have reached `epoch`, then reads its slice of every
-//      rank's stage (system-scope loads), sums in RANK ORDER (all replicas get the same bits) and applies Adam with the
-//      1 / world gradient factor;
-//   3. the last workgroup through advances the local epoch.
+//   2. every workgroup waits until all `world` flags of its own region have reached `epoch` (bounded: `max_polls`);
+//   3. CONSENSUS: a workgroup whose wait ran out sets the region's sticky `abort` word; all workgroups of the launch (fully
+//      resident, <= P2P_BLOCKS) meet at a local counter and read `abort` afterwards -- either EVERY workgroup applies the
+//      update or NONE does.  After an abort the parameters and moments are never touched again by this kernel (status bit 64
+//      and the host-mapped `host_status` word say so; the trainer raises on its next step, re-binding clears it): a rank
+//      that lags past the timeout must not make the others step on partial sums (round-3 review);
+//   4. read the slice of every rank's stage (system-scope loads), sum in RANK ORDER (all replicas get the same bits), Adam
+//      with the 1 / world gradient factor;
+//   5. the last workgroup through advances the local epoch.
 // Two parities: a rank can only publish epoch e + 1 after its own step e finished, i.e. after it has seen every peer's flag
-// e -- every peer has finished step e - 1's reads by then, so stage[(e + 1) & 1] is free.  The grid (<= P2P_BLOCKS
-// workgroups, grid-stride) is fully resident: the in-kernel wait of step 2 cannot starve step 1.  Spins give up after
-// ~2^22 polls and flag status bit 64 instead of hanging.
+// e -- every peer has finished step e - 1's reads by then, so stage[(e + 1) & 1] is free.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int P2P_MAX_WORLD = 8, P2P_BLOCKS = 448;
 struct P2PArgs {
     float* region[P2P_MAX_WORLD];          // every rank's region, as mapped in THIS process
     int rank, world;
     int64_t np;                            // floats per stage parity (nparam rounded up to 64)
+    int* host_status;                      // host-mapped word (hipHostMalloc): 64 once an exchange timed out
+    int max_polls;                         // bound of the flag wait (cal_engine_p2p_set_timeout)
 };
 __device__ __forceinline__ unsigned long long* p2p_flags(float* region, int64_t np) { return reinterpret_cast<unsigned long long*>(region + 2 * np); }
 __global__ void __launch_bounds__(256) k_p2p_adam(const P2PArgs pa, const float* __restrict__ G, const AdamArgs A, int64_t nparam,
@@ -1164,8 +1170,10 @@ __global__ void __launch_bounds__(256) k_p2p_adam(const P2PArgs pa, const float*
     unsigned long long* flags = p2p_flags(mine, pa.np);
     unsigned* ctr = reinterpret_cast<unsigned*>(flags + P2P_MAX_WORLD);
     unsigned long long* epoch_p = flags + P2P_MAX_WORLD + 1;
+    unsigned* ctr2 = reinterpret_cast<unsigned*>(flags + P2P_MAX_WORLD + 2);
+    unsigned* abort_p = ctr2 + 1;
     __shared__ unsigned long long ep_s;
-    __shared__ int last_s;
+    __shared__ int last_s, abort_s;
     if (threadIdx.x == 0) ep_s = __hip_atomic_load(epoch_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     __syncthreads();
     const unsigned long long epoch = ep_s;
@@ -1184,25 +1192,43 @@ __global__ void __launch_bounds__(256) k_p2p_adam(const P2PArgs pa, const float*
             for (int r = 0; r < pa.world; ++r)
                 __hip_atomic_store(p2p_flags(pa.region[r], pa.np) + pa.rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        // 2. wait for every rank's flag in OUR region
-        for (int r = 0; r < pa.world; ++r) {
+        // 2. wait for every rank's flag in OUR region (an earlier abort is final: no wait, no update)
+        bool bad = __hip_atomic_load(abort_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        for (int r = 0; r < pa.world && !bad; ++r) {
             int spins = 0;
             while (__hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1 << 22)) { atomicOr(status, 64); break; }
+                if (++spins > pa.max_polls) { bad = true; break; }
             }
+        }
+        if (bad) __hip_atomic_fetch_or(abort_p, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // 3. consensus: every workgroup of this launch has decided before anyone reads `abort` (the grid is resident)
+        __hip_atomic_fetch_add(ctr2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)(gridDim.x * epoch);
+        int spins = 0;
+        while (__hip_atomic_load(ctr2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 24)) { __hip_atomic_fetch_or(abort_p, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+        const int ab = __hip_atomic_load(abort_p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        abort_s = ab;
+        if (ab) {
+            atomicOr(status, 64);
+            if (blockIdx.x == 0 && pa.host_status) __hip_atomic_store(pa.host_status, 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         __threadfence_system();
     }
     __syncthreads();
-    const float adam_t = A.step[0], adam_lr = A.lr[0];
-    for (int64_t i = gid; i < nparam; i += stride) {
-        float g = 0.f;
-        for (int r = 0; r < pa.world; ++r)
-            g += __hip_atomic_load(pa.region[r] + (size_t)par * pa.np + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        adam_update(A, i, g, adam_t, adam_lr);
+    if (!abort_s) {
+        const float adam_t = A.step[0], adam_lr = A.lr[0];
+        for (int64_t i = gid; i < nparam; i += stride) {
+            float g = 0.f;
+            for (int r = 0; r < pa.world; ++r)
+                g += __hip_atomic_load(pa.region[r] + (size_t)par * pa.np + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            adam_update(A, i, g, adam_t, adam_lr);
+        }
     }
-    // 3. the last workgroup through closes the epoch
+    // 5. the last workgroup through closes the epoch
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned old = __hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

@@ -100,6 +100,7 @@ class DeviceDataset:
         else:
             b.feat = xo
         b.num_graphs = B
+        b.order = idx                             # dataset index of every row of the batch, in batch order (packing permutes it)
         b.max_nodes = int(n.max()) if B else 0
         b.max_edges = int(e.max()) if B else 0
         b.ptr = meta[B:2 * B + 1]                 # node / edge offsets per graph, already on the device for cal_collate
@@ -121,8 +122,12 @@ class DeviceLoader:
                  world_size: int = 1, drop_last: bool = False, generator: Optional[torch.Generator] = None,
                  seed: int = 0, pack: Optional[bool] = None):
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
-        # small graphs (mean <= 40 nodes: NCI1, MUTAG, ...): order every mini-batch for the engine's 64-node tiles
-        self.pack = bool(dataset.G and dataset.node_sizes.mean() <= 40) if pack is None else bool(pack)
+        # small graphs (mean <= 40 nodes: NCI1, MUTAG, ...): order every mini-batch for the engine's 64-node tiles.  Packing
+        # REORDERS the graphs inside a mini-batch (``Batch.order`` names them), which a shuffled loader may do freely (a
+        # mini-batch is a set) but a shuffle=False loader may not by default: a consumer that maps output rows back to dataset
+        # order would be silently permuted.  ``pack="small"`` asks for it by graph size alone (loops that only count hits).
+        small = bool(dataset.G and dataset.node_sizes.mean() <= 40)
+        self.pack = (small and shuffle) if pack is None else (small if pack == "small" else bool(pack))
         self.rank, self.world_size, self.drop_last, self.generator = rank, world_size, drop_last, generator
         self.seed, self.epoch = int(seed), 0
 

@@ -82,9 +82,41 @@ class Binding:
         self.engine_step += k
         self.opt._opt_called = True         # what torch's LR schedulers look at to warn about "scheduler before optimizer"
 
+    def rehome(self, full: bool = False):
+        """``optimizer.load_state_dict()`` after the bind replaces ``exp_avg`` / ``exp_avg_sq`` by fresh tensors: the engine
+        would keep stepping on its old moments and a mid-run restore would be silently ignored.  Whenever the optimizer's
+        state no longer aliases the engine's flat moment buffers, copy it in and re-home it (cheap test on the first
+        parameter -- a restore replaces every entry at once; ``full`` tests all)."""
+        eng = self.engine
+        base_m, base_v = eng.exp_avg.data_ptr(), eng.exp_avg_sq.data_ptr()
+
+        def aliased(p, off):
+            s = self.opt.state.get(p)
+            return bool(s) and s["exp_avg"].data_ptr() == base_m + 4 * off and s["exp_avg_sq"].data_ptr() == base_v + 4 * off
+        if not self.params:
+            return
+        probe = zip(self.params, self._views) if full else [(self.params[0], self._views[0])]
+        if all(aliased(p, off) for p, (off, _) in probe):
+            return
+        self.pending = 0                    # the restored state carries its own step counters
+        for p, (off, n) in zip(self.params, self._views):
+            s = self.opt.state.get(p)
+            m = eng.exp_avg[off:off + n].view(p.shape)
+            v = eng.exp_avg_sq[off:off + n].view(p.shape)
+            if not s:
+                m.zero_(); v.zero_()
+                self.opt.state[p] = {"step": torch.tensor(0.0, dtype=torch.float32), "exp_avg": m, "exp_avg_sq": v}
+                continue
+            if not aliased(p, off):
+                m.copy_(s["exp_avg"]); v.copy_(s["exp_avg_sq"])
+                s["exp_avg"], s["exp_avg_sq"] = m, v
+            if torch.is_tensor(s["step"]) and s["step"].is_cuda:
+                s["step"] = s["step"].detach().to("cpu", torch.float32)
+
     def resync(self):
         """Before a run of engine-side steps: the optimizer may have been stepped the plain way in between (its own
-        counters moved; the moments are shared memory)."""
+        counters moved; the moments are shared memory) or had a state dict loaded (``rehome``)."""
+        self.rehome()
         self.flush()
         s = float(self.opt.state[self.params[0]]["step"])
         if s != self.engine_step:
@@ -112,6 +144,7 @@ def bind(opt, model) -> Optional[Binding]:
     optimizer is not a plain Adam over exactly the model's parameters, or the model has no engine."""
     b = getattr(opt, "_cal_binding", None)
     if b is not None and b.engine is getattr(model, "_engine", None) and b.engine is not None:
+        b.rehome(full=True)
         return b
     if not _plain_adam(opt):
         return None
@@ -189,3 +222,9 @@ class EngineAdam(torch.optim.Adam):
         if b is not None:
             b.flush()
         return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        b = getattr(self, "_cal_binding", None)
+        if b is not None:                           # the loaded moments are fresh tensors: move them into the engine's buffers
+            b.rehome(full=True)

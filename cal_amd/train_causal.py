@@ -65,12 +65,15 @@ def causal_loss(c_logs, o_logs, co_logs, y, num_classes, args):
 
 def _loader(dataset, batch_size, shuffle, device):
     """``DataLoader(dataset, batch_size, shuffle)`` (train_causal.py:13-15,72-73): on a GPU the dataset is made
-    device-resident once and every mini-batch is assembled by one collate kernel (bit-identical batches); the host
-    ``DataLoader`` elsewhere."""
+    device-resident once and every mini-batch is assembled by one collate kernel; the host ``DataLoader`` elsewhere.  The
+    batches hold the same graphs as the host loader's; for datasets of small graphs (mean <= 40 nodes) their ORDER inside a
+    mini-batch is the tile packing's (``Batch.order`` = dataset indices in batch order) -- the loops here only sum losses and
+    count hits over a batch, and the intervention permutation is random, so no result depends on it; with Python's RNG
+    stream unchanged the permutation pairs other graphs than the reference would for the same seed."""
     if device.type == "cuda" and len(dataset) > 0:
         from .device_data import DeviceDataset, DeviceLoader
         graphs = dataset if isinstance(dataset, (list, tuple)) else [dataset[i] for i in range(len(dataset))]
-        return DeviceLoader(DeviceDataset(graphs, device=device), batch_size, shuffle=shuffle)
+        return DeviceLoader(DeviceDataset(graphs, device=device), batch_size, shuffle=shuffle, pack="small")
     return DataLoader(dataset, batch_size, shuffle=shuffle)
 
 
@@ -249,7 +252,8 @@ def train_causal_syn(train_set, val_set, test_set, model_func=None, args=None, l
                                    train_acc_o * 100, val_acc_o * 100, test_acc_o * 100, picked["co"] * 100,
                                    picked["c"] * 100, picked["o"] * 100, picked["epoch"],
                                    optimizer.param_groups[0]["lr"]))
-    log(_SYN_FINAL_LINE.format(args.bias, picked["val"] * 100, picked["co"] * 100, picked["c"] * 100, picked["o"] * 100,
+    # "Val acc" is the LAST epoch's val_acc_o, as in the reference (train_causal.py:55-57), not the best one
+    log(_SYN_FINAL_LINE.format(args.bias, val_acc_o * 100, picked["co"] * 100, picked["c"] * 100, picked["o"] * 100,
                                picked["epoch"]))
     return model, history
 

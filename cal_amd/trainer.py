@@ -167,6 +167,8 @@ class CausalTrainer:
     # ------------------------------------------------------------------ pieces
     def check_status(self):
         """Synchronising check that no step since the last call flagged its batch as invalid (StepEngine.check_status)."""
+        if self.p2p is not None:
+            self.p2p.check()
         if self.engine is not None:
             self.engine.check_status()
 
@@ -383,6 +385,8 @@ class CausalTrainer:
     def step_sequence(self, batches) -> torch.Tensor:
         """len(batches) consecutive train steps (in this order) as one graph launch; returns the device stats tensor
         of the LAST step.  The captured sequence is cached per tuple of batch objects."""
+        if self.p2p is not None:
+            self.p2p.check()
         if not self.can_sequence() or not all(self._use_device_perm(b.num_graphs) for b in batches):
             stats = None
             for b in batches:
@@ -454,6 +458,8 @@ class CausalTrainer:
     def step(self, batch, perm: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One train step on a device-resident batch; returns the device stats
         tensor [loss, c_loss, o_loss, co_loss, correct_o] (no host sync)."""
+        if self.p2p is not None:
+            self.p2p.check()          # an exchange that timed out left the parameters untouched: say so before stepping on (host-mapped word, no sync)
         nb = batch.num_graphs
         dev = perm is None and self._use_device_perm(nb)
         if perm is None and not dev:

@@ -198,11 +198,22 @@ CAL_API int cal_engine_set_perm_rng(void* engine, uint64_t seed, uint64_t* count
 CAL_API int cal_engine_adam_ticked(void* engine, void* stream);
 CAL_API int cal_engine_set_grad_scale(void* engine, float scale);
 /* the same exchange WITHOUT a collective library (the ~0.5 MB bucket is latency-bound): every rank shares one
- * region (cal_engine_p2p_region_bytes, zero-initialised) with the others through IPC / xGMI peer mappings;
- * cal_engine_p2p_adam is ONE launch that publishes the bucket, waits for every rank's flag, sums in rank order and applies
- * Adam.  peer_bases[r] / peer_devices[r]: rank r's region as mapped in this process and the device that owns it. */
+ * region (cal_engine_p2p_region_bytes, from cal_p2p_alloc: FINE-GRAINED device memory, zero-initialised -- coarse-grained
+ * hipMalloc memory is not visible across devices inside a running kernel) with the others through IPC / xGMI peer mappings
+ * (cal_p2p_export -> 64-byte handle -> cal_p2p_open in the peer process); cal_engine_p2p_adam is ONE launch that publishes the
+ * bucket, waits for every rank's flag, sums in rank order and applies Adam.  peer_bases[r] / peer_devices[r]: rank r's region as
+ * mapped in this process and the device that owns it.  If a peer's flag does not arrive within the timeout
+ * (cal_engine_p2p_set_timeout, polls) NO parameter is updated in that or any later launch, status bit 64 is set and
+ * cal_engine_p2p_status (a host-mapped word, no synchronisation) returns 64. */
+CAL_API int cal_p2p_alloc(int64_t bytes, void** out);
+CAL_API int cal_p2p_free(void* region);
+CAL_API int cal_p2p_export(void* region, void* handle64);
+CAL_API int cal_p2p_open(const void* handle64, void** out);
+CAL_API int cal_p2p_close(void* mapped);
 CAL_API int64_t cal_engine_p2p_region_bytes(void* engine);
 CAL_API int cal_engine_p2p_bind(void* engine, void* const* peer_bases, const int64_t* peer_devices, int64_t world, int64_t rank);
+CAL_API int cal_engine_p2p_set_timeout(void* engine, int64_t max_polls);
+CAL_API int64_t cal_engine_p2p_status(void* engine);
 CAL_API int cal_engine_p2p_adam(void* engine, void* stream);
 /* backward from an external d loss / d log-probs [3,B,C] of the last training-mode forward (autograd surface) */
 CAL_API int cal_engine_backward_from(void* engine, const float* x0, const int64_t* batch,

@@ -149,6 +149,71 @@ def test_one_shot_peer_memory_exchange_equals_the_all_reduce(use_graph):
         assert np.array_equal(got[0][s][1], ref[0][s][1]), s                     # == all-reduce + Adam
 
 
+def _timeout_worker(rank, world, port, sd, q):
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from cal_amd import model as M
+        from cal_amd.p2p import P2PTimeout
+        from cal_amd.trainer import CausalTrainer
+        from tests.helpers import ref_batch
+        m = M.CausalGCN(10, 4, _margs())
+        m.load_state_dict(sd)
+        m = m.cuda()
+        trn = CausalTrainer(m, _margs(), lr=1e-2, use_graph=False, world_size=world, p2p_exchange=True)
+        out = None
+        if rank == 0:                # rank 1 never publishes: rank 0's wait must run out
+            trn.p2p.set_timeout(2000)
+            b = ref_batch(list(range(8))).to("cuda")
+            trn.reserve_for([b])
+            before = trn.flat_p.detach().cpu().numpy().copy()
+            m1 = trn.engine.exp_avg.detach().cpu().numpy().copy()
+            trn.step(b, perm=torch.arange(b.num_graphs - 1, -1, -1, device="cuda"))
+            torch.cuda.synchronize()
+            after = trn.flat_p.detach().cpu().numpy().copy()
+            m1b = trn.engine.exp_avg.detach().cpu().numpy().copy()
+            grad_nonzero = bool(trn.flat_g.abs().max().item() > 0)
+            raised = False
+            try:
+                trn.step(b, perm=torch.arange(b.num_graphs - 1, -1, -1, device="cuda"))
+            except P2PTimeout:
+                raised = True
+            out = (np.array_equal(before, after), np.array_equal(m1, m1b), grad_nonzero, raised, int(trn.p2p.status()))
+        dist.barrier()
+        q.put((rank, out, None))
+        dist.destroy_process_group()
+    except Exception as exc:
+        import traceback
+        q.put((rank, None, traceback.format_exc() + repr(exc)))
+
+
+def test_peer_memory_exchange_timeout_leaves_the_parameters_untouched():
+    """A peer that never publishes (round-3 review / advisor): the in-kernel wait runs out, EVERY workgroup of the launch skips
+    the Adam update (consensus through the region's sticky abort word), parameters and moments keep their bits, the
+    host-mapped status word turns 64 and the trainer's next step raises instead of training on."""
+    from oracle import cal_oracle as O
+    torch.manual_seed(14)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=2)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timeout_worker, args=(r, 2, port, {k: v.clone() for k, v in sd.items()}, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, out, err = q.get(timeout=600)
+        assert err is None, err
+        res[rank] = out
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    same_p, same_m, grad_nonzero, raised, status = res[0]
+    assert grad_nonzero and same_p and same_m and raised and status == 64
+
+
 def _nccl_worker(port, sd, q):
     try:
         import torch.distributed as dist

@@ -132,6 +132,41 @@ def test_fused_epoch_and_statement_loop_leave_the_same_optimizer_state():
         assert torch.allclose(a, b_, atol=1e-7 + 1e-3 * float(b_.abs().max()), rtol=1e-2), k
 
 
+def test_optimizer_restore_after_the_bind_reaches_the_fused_step():
+    """``optimizer.load_state_dict()`` between two fused epochs (round-3 advisor): the restored moments are fresh tensors, the
+    engine must adopt them (``Binding.rehome``) instead of stepping on with its own -- the second epoch after a restore of the
+    post-epoch-1 state must reproduce the uninterrupted second epoch bit for bit, and after a restore of a ZEROED state it
+    must differ from it."""
+    from cal_amd.device_data import DeviceDataset, DeviceLoader
+    from cal_amd.train_causal import train_causal_epoch
+    gs = _graphs(64, seed=7)
+    torch.manual_seed(2)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=2)
+    args = _args(layers=2, hidden=64, with_random=False)
+    outs = {}
+    for kind in ("straight", "restored", "zeroed"):
+        m = _model("CausalGCN", {k: v.clone() for k, v in sd.items()}, args)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        loader = DeviceLoader(DeviceDataset(gs), 32, shuffle=False)
+        train_causal_epoch(m, opt, loader, torch.device(DEV), args)
+        assert getattr(opt, "_cal_binding", None) is not None
+        if kind != "straight":
+            st = copy.deepcopy(opt.state_dict())
+            if kind == "zeroed":
+                for s_ in st["state"].values():
+                    s_["exp_avg"].zero_(); s_["exp_avg_sq"].zero_()
+            opt.load_state_dict(st)
+            p0 = next(iter(m.parameters()))
+            assert opt.state[p0]["exp_avg"].data_ptr() != m._engine.exp_avg.data_ptr()        # fresh tensors, not the engine's
+        train_causal_epoch(m, opt, loader, torch.device(DEV), args)
+        p0 = next(iter(m.parameters()))
+        assert opt.state[p0]["exp_avg"].data_ptr() == m._engine.exp_avg.data_ptr()            # re-homed
+        assert {float(opt.state[p]["step"]) for p in m.parameters()} == {4.0}
+        outs[kind] = torch.cat([p.detach().flatten().cpu() for p in m.parameters()])
+    assert torch.equal(outs["straight"], outs["restored"])
+    assert not torch.equal(outs["straight"], outs["zeroed"])
+
+
 def test_lr_scheduler_reaches_the_fused_step():
     """CosineAnnealingLR rewrites param_groups[0]['lr'] (train_causal.py:22,29); the next fused epoch must use it: two
     models, one stepped with lr = 0 after the schedule, stay / move accordingly."""
@@ -202,6 +237,8 @@ def test_train_causal_syn_log_lines_and_device_loader():
     assert re.match(pat, lines[1]), lines[1]
     assert re.match(r"^syd: BIAS:\[0\.90\] \| Val acc:\[\d+\.\d{2}\] Test acc:\[co:\d+\.\d{2},c:\d+\.\d{2},o:\d+\.\d{2}\] at epoch:\[\d\]$", lines[2]), lines[2]
     assert lines[0][-11:] in ("lr:0.000500", "lr:0.000501") and lines[1].endswith("lr:0.000001")   # cosine: midpoint, then eta_min
+    # "Val acc" of the final line is the LAST epoch's val_acc_o (train_causal.py:55-57), not the best epoch's
+    assert "Val acc:[%.2f]" % (history[-1]["val_acc_o"] * 100) in lines[2]
     assert getattr(model, "_engine", None) is not None
     for h in history:
         assert abs(h["loss"] - (0.5 * h["loss_c"] + h["loss_o"] + 0.5 * h["loss_co"])) < 1e-5

@@ -85,6 +85,40 @@ def test_packed_step_equals_oracle_and_unpacked_step(name, kind, nfeat, batch, h
         assert torch.allclose(a, c, atol=2e-5 + 1e-4 * float(c.abs().max()), rtol=1e-3), k
 
 
+def test_causalgin_train_step_above_512_units_matches_oracle():
+    """More than 512 units of <= 64-node graphs (one graph per workgroup, B = 600): the per-graph BACKWARD does not apply
+    (T <= 512), so the training forward must take the node-level GINConv chain too -- the fused forward leaves only gt1, the
+    node-level backward reads gagg / gy (round-3 advisor finding).  Step vs the oracle (model.py:188-194,236-264)."""
+    from cal_amd import synth
+    from cal_amd.data import Batch
+    batch, hidden, layers, nfeat = 600, 64, 2, 109
+    gs = synth.tu_like(batch, kind="mutag", seed=11)
+    b, bd = Batch.from_data_list(gs), Batch.from_data_list(gs).to(DEV)
+    torch.manual_seed(8)
+    sd = O.init_state("CausalGIN", nfeat, 2, hidden=hidden, layers=layers, heads=4)
+    perm = torch.randperm(batch)
+    tr = O.CpuTrainer("CausalGIN", {k: v.clone() for k, v in sd.items()}, 2, lr=1e-3, layers=layers, heads=4)
+    loss, lc, lo, lco, logits = tr.step(b.x, b.edge_index, b.batch, b.y, perm=perm)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    tr64 = O.CpuTrainer("CausalGIN", sd64, 2, lr=1e-3, layers=layers, heads=4)
+    tr64.step(b.x.double(), b.edge_index, b.batch, b.y, perm=perm)
+    for round_ in range(2):          # twice: stale workspace of the first step must not help the second
+        m, eng = _engine("CausalGIN", {k: v.clone() for k, v in sd.items()}, _args(hidden=hidden, layers=layers), nfeat, 2, tiles=False)
+        stats = eng.train_step(bd, perm.to(DEV), adam=False).cpu().numpy()
+        eng.check_status()
+        assert eng._tiles[1] == 0
+        lp = eng.buffer("logp", 3 * batch * 2).view(3, batch, 2).cpu().clone()
+        for r, t in zip(logits, lp):
+            assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+        assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+        for k, p in m.named_parameters():
+            g32, g64 = tr.sd[k].grad, tr64.sd[k].grad
+            if g32 is not None:
+                e_gpu = (p.grad.cpu().double() - g64).abs().max().item()
+                e_cpu = (g32.double() - g64).abs().max().item()
+                assert e_gpu <= 4 * e_cpu + 1e-5 * max(1.0, g64.abs().max().item()), (k, e_gpu, e_cpu)
+
+
 def test_tiles_with_empty_and_edgeless_graphs():
     """A tile may hold a graph without nodes (its pooled row is zero, model.py:115 with no rows) or without edges."""
     from cal_amd import synth
