@@ -158,8 +158,8 @@ struct Engine {
     unsigned long long perm_seed; unsigned long long* perm_ctr;   // device draw of the random-intervention permutation (mode bit 16)
     int64_t* perm_dev;          // [capB] the permutation drawn by the step itself
     P2PArgs p2p; int p2p_on;    // one-shot peer-memory gradient exchange (cal_engine_p2p_bind)
-    int* p2p_host_status = nullptr;   // host-mapped word k_p2p_adam sets when an exchange timed out (cal_engine_p2p_status)
-    int p2p_max_polls = 1 << 22;
+    int* p2p_host_status;             // host-mapped word k_p2p_adam sets when an exchange timed out (cal_engine_p2p_status)
+    int p2p_max_polls;                // bound of k_p2p_adam's flag wait (cal_engine_create: 2^22; cal_engine_p2p_set_timeout)
     float grad_scale;           // gradient factor inside Adam (1 / world_size after a sum all-reduce)
     // parameter offsets (floats into P / G)
     int o_feat_w;
@@ -249,6 +249,7 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     e->F = (int)F; e->H = (int)H; e->C = (int)C; e->L = (int)L;
     e->loop_w = 1.f;
     e->grad_scale = 1.f;
+    e->p2p_max_polls = 1 << 22;
     e->nbn = (int)L + 9;
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { set_error("cal_engine_create: side stream"); delete e; return nullptr; }
     for (int i = 0; i < 24; ++i) {
