@@ -1,0 +1,307 @@
+// Microbenchmark (round 4): the config-5 aggregation  out = D^-1/2 (A_w + I) D^-1/2 x  (gcn_conv.py:92-104) on 32 BA(m=2)
+// graphs of 5000 nodes, H = 256 -- what bounds the gather, and what an LDS-resident column slice buys.
+//   V0  wave per row, 16 B per lane, neighbours 4 at a time + serial remainder (the structure of k_espmm)
+//   V1  wave per row, the row's slots loaded by ONE coalesced instruction (lane l <- slot l), ids / coefficients broadcast
+//       with v_readlane (SGPR addresses), exactly deg gathers issued back to back
+//   V2  workgroup = (graph, 4-column slice): the slice of ALL the graph's rows staged in LDS once (coalesced from a
+//       column-blocked layout [H/4][N][4], or 16 B pieces of the row-major matrix), pre-scaled by deg^-1/2; lane per row walks
+//       the row's CSR slots (16-bit local ids + slot-ordered weights, streamed from L2) against LDS; hub rows by whole waves
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/micro/gather_lds.hip -o scripts/micro/gather_lds
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+constexpr int H = 256;
+
+// ---------------------------------------------------------------- V0
+__global__ void __launch_bounds__(256) k_v0(const int* __restrict__ ptr, const int* __restrict__ nbr, const int* __restrict__ eid,
+                                            const float* __restrict__ w, const float* __restrict__ dis, const float* __restrict__ h,
+                                            float* __restrict__ out, int N) {
+    const int per = gridDim.x >> 3;
+    const int bxr = (int)blockIdx.x < 8 * per ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int i = bxr * 4 + (threadIdx.x >> 6), c = (threadIdx.x & 63) * 4;
+    if (i >= N) return;
+    const int p0 = ptr[i], p1 = ptr[i + 1];
+    const float di = dis[i];
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto fma4 = [&](float cf, const float4& v) { acc.x = fmaf(cf, v.x, acc.x); acc.y = fmaf(cf, v.y, acc.y); acc.z = fmaf(cf, v.z, acc.z); acc.w = fmaf(cf, v.w, acc.w); };
+    int s = p0;
+    for (; s + 4 <= p1; s += 4) {
+        const int j0 = nbr[s], j1 = nbr[s + 1], j2 = nbr[s + 2], j3 = nbr[s + 3];
+        float c0 = dis[j0] * w[eid[s]], c1 = dis[j1] * w[eid[s + 1]], c2 = dis[j2] * w[eid[s + 2]], c3 = dis[j3] * w[eid[s + 3]];
+        const float4 h0 = *(const float4*)(h + (size_t)j0 * H + c), h1 = *(const float4*)(h + (size_t)j1 * H + c);
+        const float4 h2 = *(const float4*)(h + (size_t)j2 * H + c), h3 = *(const float4*)(h + (size_t)j3 * H + c);
+        fma4(c0, h0); fma4(c1, h1); fma4(c2, h2); fma4(c3, h3);
+    }
+    for (; s < p1; ++s) {
+        const int j = nbr[s];
+        fma4(dis[j] * w[eid[s]], *(const float4*)(h + (size_t)j * H + c));
+    }
+    fma4(di, *(const float4*)(h + (size_t)i * H + c));
+    acc.x *= di; acc.y *= di; acc.z *= di; acc.w *= di;
+    *(float4*)(out + (size_t)i * H + c) = acc;
+}
+
+// ---------------------------------------------------------------- V1
+template <int NB>
+__device__ __forceinline__ void v1_batch(float4& acc, const float* __restrict__ h, int jl, float cl, int q, int c) {
+    float4 v[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int j = __builtin_amdgcn_readlane(jl, q + u);
+        v[u] = *(const float4*)(h + (size_t)j * H + c);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cl), q + u));
+        acc.x = fmaf(cf, v[u].x, acc.x); acc.y = fmaf(cf, v[u].y, acc.y); acc.z = fmaf(cf, v[u].z, acc.z); acc.w = fmaf(cf, v[u].w, acc.w);
+    }
+}
+template <int RPW>       // rows per wave, processed one after the other (amortises nothing; kept 1)
+__global__ void __launch_bounds__(256) k_v1(const int* __restrict__ ptr, const int* __restrict__ nbr, const int* __restrict__ eid,
+                                            const float* __restrict__ w, const float* __restrict__ dis, const float* __restrict__ h,
+                                            float* __restrict__ out, int N) {
+    const int per = gridDim.x >> 3;
+    const int bxr = (int)blockIdx.x < 8 * per ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, c = lane * 4;
+    const int i = __builtin_amdgcn_readfirstlane(bxr * 4 + (threadIdx.x >> 6));
+    if (i >= N) return;
+    const int p0 = ptr[i], p1 = ptr[i + 1];
+    const float di = dis[i];
+    const float4 hs = *(const float4*)(h + (size_t)i * H + c);      // the self row goes out with the first round
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int base = p0; base < p1; base += 64) {
+        const int s = min(base + lane, p1 - 1);
+        const int jl = nbr[s];
+        const float cl = dis[jl] * w[eid[s]];
+        const int cnt = min(64, p1 - base);
+        int q = 0;
+        for (; q + 8 <= cnt; q += 8) v1_batch<8>(acc, h, jl, cl, q, c);
+        switch (cnt - q) {
+            case 7: v1_batch<7>(acc, h, jl, cl, q, c); break;
+            case 6: v1_batch<6>(acc, h, jl, cl, q, c); break;
+            case 5: v1_batch<5>(acc, h, jl, cl, q, c); break;
+            case 4: v1_batch<4>(acc, h, jl, cl, q, c); break;
+            case 3: v1_batch<3>(acc, h, jl, cl, q, c); break;
+            case 2: v1_batch<2>(acc, h, jl, cl, q, c); break;
+            case 1: v1_batch<1>(acc, h, jl, cl, q, c); break;
+            default: break;
+        }
+    }
+    acc.x = fmaf(di, hs.x, acc.x); acc.y = fmaf(di, hs.y, acc.y); acc.z = fmaf(di, hs.z, acc.z); acc.w = fmaf(di, hs.w, acc.w);
+    acc.x *= di; acc.y *= di; acc.z *= di; acc.w *= di;
+    *(float4*)(out + (size_t)i * H + c) = acc;
+}
+
+// ---------------------------------------------------------------- V2
+// gptr[g] .. gptr[g+1]: node range of graph g.  nbr16: slot -> LOCAL source id (16 bit); ws: slot-ordered edge weight.
+// BLK_IN / BLK_OUT: column-blocked [H/4][N][4] layouts instead of row-major [N][H].
+constexpr int V2_MAXN = 5000;        // rows of one graph resident in LDS (4 columns x 4 B)
+constexpr int V2_HUB = 16;           // rows with more slots than this are left to whole waves
+template <int NT, bool BLK_IN, bool BLK_OUT>
+__global__ void __launch_bounds__(NT) k_v2(const int* __restrict__ gptr, const int* __restrict__ ptr, const unsigned short* __restrict__ nbr16,
+                                           const float* __restrict__ ws, const float* __restrict__ dis, const float* __restrict__ h,
+                                           float* __restrict__ out, int N, int B, int* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) float4 xs[V2_MAXN];
+    __shared__ int hub[NT / 4];
+    __shared__ int nhub;
+    constexpr int NS = H / 4;
+    // all slices of a graph on ONE XCD, back to back: workgroup b -> XCD b % 8, sequence q = b / 8 on it
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int g = (q / NS) * 8 + xcd, sl = q % NS;
+    if (g >= B) return;
+    const int n0 = gptr[g], n = gptr[g + 1] - n0;
+    if (n > V2_MAXN || n <= 0) { if (threadIdx.x == 0 && n > V2_MAXN) atomicOr(status, 1); return; }
+    if (threadIdx.x == 0) nhub = 0;
+    // A. the slice of every row of the graph, scaled by deg^-1/2 of the row
+    for (int r = threadIdx.x; r < n; r += NT) {
+        const float4 v = BLK_IN ? *(const float4*)(h + ((size_t)sl * N + n0 + r) * 4) : *(const float4*)(h + (size_t)(n0 + r) * H + sl * 4);
+        const float d = dis[n0 + r];
+        xs[r] = make_float4(v.x * d, v.y * d, v.z * d, v.w * d);
+    }
+    __syncthreads();
+    // B. lane per row
+    for (int r = threadIdx.x; r < n; r += NT) {
+        const int i = n0 + r;
+        const int p0 = ptr[i], p1 = ptr[i + 1];
+        if (p1 - p0 > V2_HUB) { const int k = atomicAdd(&nhub, 1); if (k < NT / 4) hub[k] = r; else atomicOr(status, 2); continue; }
+        float4 acc = xs[r];          // self loop (weight 1)
+        for (int s = p0; s < p1; s += 4) {
+            int j[4]; float cf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int su = min(s + u, p1 - 1); j[u] = nbr16[su]; cf[u] = s + u < p1 ? ws[su] : 0.f; }
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = xs[j[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x = fmaf(cf[u], v[u].x, acc.x); acc.y = fmaf(cf[u], v[u].y, acc.y); acc.z = fmaf(cf[u], v[u].z, acc.z); acc.w = fmaf(cf[u], v[u].w, acc.w); }
+        }
+        const float d = dis[i];
+        acc.x *= d; acc.y *= d; acc.z *= d; acc.w *= d;
+        if (BLK_OUT) *(float4*)(out + ((size_t)sl * N + i) * 4) = acc; else *(float4*)(out + (size_t)i * H + sl * 4) = acc;
+    }
+    __syncthreads();
+    // C. hub rows: one wave per row, lanes stride over the slots
+    const int nh = min(nhub, NT / 4), wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = wv; k < nh; k += NT / 64) {
+        const int r = hub[k], i = n0 + r;
+        const int p0 = ptr[i], p1 = ptr[i + 1];
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = p0 + lane; s < p1; s += 64) {
+            const float cf = ws[s];
+            const float4 v = xs[nbr16[s]];
+            acc.x = fmaf(cf, v.x, acc.x); acc.y = fmaf(cf, v.y, acc.y); acc.z = fmaf(cf, v.z, acc.z); acc.w = fmaf(cf, v.w, acc.w);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64); acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (lane == 0) {
+            const float4 sv = xs[r];
+            const float d = dis[i];
+            acc.x = (acc.x + sv.x) * d; acc.y = (acc.y + sv.y) * d; acc.z = (acc.z + sv.z) * d; acc.w = (acc.w + sv.w) * d;
+            if (BLK_OUT) *(float4*)(out + ((size_t)sl * N + i) * 4) = acc; else *(float4*)(out + (size_t)i * H + sl * 4) = acc;
+        }
+    }
+}
+
+// row-major <-> column-blocked (what a GEMM epilogue / a consumer's staging would do for free)
+__global__ void k_to_blocked(const float* __restrict__ a, float* __restrict__ b, int N) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)N * (H / 4)) return;
+    const int i = (int)(t / (H / 4)), sl = (int)(t % (H / 4));
+    *(float4*)(b + ((size_t)sl * N + i) * 4) = *(const float4*)(a + (size_t)i * H + sl * 4);
+}
+__global__ void k_from_blocked(const float* __restrict__ b, float* __restrict__ a, int N) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)N * (H / 4)) return;
+    const int i = (int)(t / (H / 4)), sl = (int)(t % (H / 4));
+    *(float4*)(a + (size_t)i * H + sl * 4) = *(const float4*)(b + ((size_t)sl * N + i) * 4);
+}
+
+// ---------------------------------------------------------------- host
+struct Graphs {
+    int N, B; int64_t E;
+    std::vector<int> gptr, ptr, nbr, eid; std::vector<unsigned short> nbr16; std::vector<float> w, ws, dis;
+};
+static Graphs make(int B, int n, unsigned seed) {
+    std::mt19937 rng(seed);
+    Graphs G; G.B = B; G.N = B * n;
+    std::vector<std::pair<int, int>> edges;      // directed, global ids (dst <- src both ways)
+    for (int g = 0; g < B; ++g) {
+        std::vector<int> rep;                    // preferential attachment: node ids repeated by degree
+        const int m = 2, base = g * n;
+        std::vector<int> targets = {0, 1};
+        for (int v = m; v < n; ++v) {
+            for (int t : targets) { edges.push_back({base + v, base + t}); edges.push_back({base + t, base + v}); rep.push_back(t); rep.push_back(v); }
+            targets.clear();
+            while ((int)targets.size() < m) {
+                const int t = rep[rng() % rep.size()];
+                if (std::find(targets.begin(), targets.end(), t) == targets.end()) targets.push_back(t);
+            }
+        }
+    }
+    std::shuffle(edges.begin(), edges.end(), rng);                   // edge ids in no particular order
+    G.E = (int64_t)edges.size();
+    G.w.resize(G.E);
+    for (auto& x : G.w) x = 0.05f + (rng() % 1000) * 0.0009f;         // attention weights in (0, 1)
+    G.ptr.assign(G.N + 1, 0);
+    for (auto& e : edges) G.ptr[e.first + 1]++;                       // by destination = .first
+    for (int i = 0; i < G.N; ++i) G.ptr[i + 1] += G.ptr[i];
+    G.nbr.resize(G.E); G.eid.resize(G.E); G.nbr16.resize(G.E); G.ws.resize(G.E);
+    std::vector<int> fill(G.ptr.begin(), G.ptr.end() - 1);
+    for (int64_t e = 0; e < G.E; ++e) { const int s = fill[edges[e].first]++; G.nbr[s] = edges[e].second; G.eid[s] = (int)e; }
+    for (int i = 0; i < G.N; ++i)
+        for (int s = G.ptr[i]; s < G.ptr[i + 1]; ++s) { G.nbr16[s] = (unsigned short)(G.nbr[s] - (i / n) * n); G.ws[s] = G.w[G.eid[s]]; }
+    G.gptr.resize(B + 1);
+    for (int g = 0; g <= B; ++g) G.gptr[g] = g * n;
+    // weighted degree by SOURCE (gcn_conv.py:65-66) + the added loop
+    std::vector<double> deg(G.N, 1.0);
+    for (int64_t e = 0; e < G.E; ++e) deg[edges[e].second] += G.w[e];
+    G.dis.resize(G.N);
+    for (int i = 0; i < G.N; ++i) G.dis[i] = (float)(1.0 / std::sqrt(deg[i]));
+    return G;
+}
+template <class T> T* dev(const std::vector<T>& v) { T* p; CK(hipMalloc(&p, v.size() * sizeof(T))); CK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice)); return p; }
+
+template <class F> float timeit(F f, int reps = 20) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipDeviceSynchronize());
+    float best = 1e9f, tot = 0.f;
+    for (int i = 0; i < reps; ++i) { CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); best = std::min(best, ms); tot += ms; }
+    printf("  [%7.1f us best, %7.1f us mean]", best * 1e3f, tot / reps * 1e3f);
+    return best * 1e3f;
+}
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 32, n = argc > 2 ? atoi(argv[2]) : 5000;
+    Graphs G = make(B, n, 7);
+    const int N = G.N;
+    int maxdeg = 0, nh = 0;
+    for (int i = 0; i < N; ++i) { const int d = G.ptr[i + 1] - G.ptr[i]; maxdeg = std::max(maxdeg, d); nh += d > V2_HUB; }
+    printf("B %d  n %d  N %d  E %lld  max degree %d  rows above %d slots: %d (%.2f / graph)\n", B, n, N, (long long)G.E, maxdeg, V2_HUB, nh, (double)nh / B);
+    const double alg = 2.0 * N * H * 4 + (double)(G.E + N) * 8 + (N + 1) * 4.0;
+    std::vector<float> hx((size_t)N * H);
+    std::mt19937 rng(3);
+    for (auto& v : hx) v = (int)(rng() % 2001 - 1000) * 1e-3f;
+    int *d_gptr = dev(G.gptr), *d_ptr = dev(G.ptr), *d_nbr = dev(G.nbr), *d_eid = dev(G.eid);
+    unsigned short* d_n16 = dev(G.nbr16);
+    float *d_w = dev(G.w), *d_ws = dev(G.ws), *d_dis = dev(G.dis), *d_h = dev(hx);
+    float *d_hb, *d_out, *d_outb, *d_tmp;
+    int* d_status;
+    CK(hipMalloc(&d_hb, (size_t)N * H * 4)); CK(hipMalloc(&d_out, (size_t)N * H * 4)); CK(hipMalloc(&d_outb, (size_t)N * H * 4)); CK(hipMalloc(&d_tmp, (size_t)N * H * 4));
+    CK(hipMalloc(&d_status, 4)); CK(hipMemset(d_status, 0, 4));
+    const int tb = (int)(((size_t)N * (H / 4) + 255) / 256);
+    hipLaunchKernelGGL(k_to_blocked, dim3(tb), dim3(256), 0, 0, d_h, d_hb, N);
+    // CPU reference on graph 0 and the last graph
+    auto cpu_row = [&](int i, std::vector<float>& o) {
+        o.assign(H, 0.f);
+        std::vector<double> a(H, 0.0);
+        for (int s = G.ptr[i]; s < G.ptr[i + 1]; ++s) { const int j = G.nbr[s]; const double cf = (double)G.dis[j] * G.ws[s]; for (int c = 0; c < H; ++c) a[c] += cf * hx[(size_t)j * H + c]; }
+        for (int c = 0; c < H; ++c) o[c] = (float)((a[c] + (double)G.dis[i] * hx[(size_t)i * H + c]) * G.dis[i]);
+    };
+    std::vector<float> got((size_t)N * H);
+    auto check = [&](const char* name, const float* dptr) {
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(got.data(), dptr, got.size() * 4, hipMemcpyDeviceToHost));
+        double worst = 0.0; std::vector<float> o;
+        for (int i = 0; i < N; i += (i < 5000 || i >= N - 5000) ? 1 : 97) { cpu_row(i, o); for (int c = 0; c < H; ++c) worst = std::max(worst, (double)std::fabs(o[c] - got[(size_t)i * H + c])); }
+        int st = 0; CK(hipMemcpy(&st, d_status, 4, hipMemcpyDeviceToHost));
+        printf("  max |err| %.2e  status %d  %s\n", worst, st, worst < 1e-4 && st == 0 ? "ok" : "MISMATCH");
+    };
+    auto report = [&](const char* name, float us) { printf("  %-46s %6.1f us  %5.0f GB/s algorithmic  %4.1f %% of 8 TB/s\n", name, us, alg / us * 1e-3, alg / us * 1e-3 / 80.0); };
+    printf("algorithmic bytes %.1f MB\n", alg * 1e-6);
+
+    float us;
+    CK(hipMemset(d_out, 0, (size_t)N * H * 4));
+    us = timeit([&] { hipLaunchKernelGGL(k_v0, dim3((N + 3) / 4), dim3(256), 0, 0, d_ptr, d_nbr, d_eid, d_w, d_dis, d_h, d_out, N); });
+    report("V0 wave/row, 4-batches + serial remainder", us); check("v0", d_out);
+    CK(hipMemset(d_out, 0, (size_t)N * H * 4));
+    us = timeit([&] { hipLaunchKernelGGL((k_v1<1>), dim3((N + 3) / 4), dim3(256), 0, 0, d_ptr, d_nbr, d_eid, d_w, d_dis, d_h, d_out, N); });
+    report("V1 wave/row, slot preload + readlane, exact", us); check("v1", d_out);
+
+    const int nwg = ((B + 7) / 8) * 8 * (H / 4);
+#define RUN_V2(NT, BI, BO, label) do { \
+        CK(hipMemset(d_out, 0, (size_t)N * H * 4)); CK(hipMemset(d_outb, 0, (size_t)N * H * 4)); \
+        us = timeit([&] { hipLaunchKernelGGL((k_v2<NT, BI, BO>), dim3(nwg), dim3(NT), 0, 0, d_gptr, d_ptr, d_n16, d_ws, d_dis, BI ? d_hb : d_h, BO ? d_outb : d_out, N, B, d_status); }); \
+        report(label, us); \
+        if (BO) { hipLaunchKernelGGL(k_from_blocked, dim3(tb), dim3(256), 0, 0, d_outb, d_tmp, N); check(label, d_tmp); } else check(label, d_out); } while (0)
+    RUN_V2(1024, true, true, "V2 LDS slice, 1024 thr, blocked in / blocked out");
+    RUN_V2(512, true, true, "V2 LDS slice,  512 thr, blocked in / blocked out");
+    RUN_V2(1024, false, true, "V2 LDS slice, 1024 thr, row-major in / blocked out");
+    RUN_V2(1024, true, false, "V2 LDS slice, 1024 thr, blocked in / row-major out");
+    RUN_V2(1024, false, false, "V2 LDS slice, 1024 thr, row-major in / row-major out");
+    RUN_V2(512, false, false, "V2 LDS slice,  512 thr, row-major in / row-major out");
+    // layout conversion alone (what a producer / consumer would otherwise absorb)
+    us = timeit([&] { hipLaunchKernelGGL(k_to_blocked, dim3(tb), dim3(256), 0, 0, d_h, d_hb, N); });
+    printf("  row-major -> blocked copy alone: %.1f us\n", us);
+    return 0;
+}
