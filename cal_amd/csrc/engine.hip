@@ -565,6 +565,9 @@ int with_g(int H, F f) {
 
 int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// k_espmm launch: lanes per row from the width, per-edge weights / output statistics from the branch (both branches alike)
+int launch_espmm(hipStream_t st, const CSR& csr, const SpmmBranch2& bb, int nbranch, int relu, float loop_w, int N, int H, int rpb);
+
 #define RC0(x) do { int rc0_ = (x); if (rc0_) return rc0_; } while (0)
 // weight-gradient GEMM (TN) with split-K slabs when the reduction axis is long
 int grad_gemm(Ctx& c, GemmArgs& a, int nbatch, float** dst, FinishArgs& fa, size_t& slab_off) {
@@ -656,6 +659,20 @@ struct ProfScope {
 #define PROF_LAUNCH(kernel, grid, block, shmem, stream, ...) do { \
         if (g_prof_cur) { hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, g_prof_cur->r.e0, g_prof_cur->r.e1, 0, __VA_ARGS__); g_prof_cur->used = true; } \
         else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); } while (0)
+
+int launch_espmm(hipStream_t st, const CSR& csr, const SpmmBranch2& bb, int nbranch, int relu, float loop_w, int N, int H, int rpb) {
+    const bool wt = bb.b[0].w != nullptr, stt = bb.b[0].st_sum.on();
+    if (wt != (bb.b[nbranch - 1].w != nullptr) || stt != bb.b[nbranch - 1].st_sum.on() || rpb % 4 != 0 || H > 256) { set_error("k_espmm: branches differ in kind"); return 2; }
+    const dim3 grid(cdiv(N, rpb), nbranch);
+    return with_g(H, [&](auto g) {
+        constexpr int G = decltype(g)::value;
+        if (wt && stt) PROF_LAUNCH((k_espmm<4, G, true, true>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
+        else if (wt) PROF_LAUNCH((k_espmm<4, G, true, false>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
+        else if (stt) PROF_LAUNCH((k_espmm<4, G, false, true>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
+        else PROF_LAUNCH((k_espmm<4, G, false, false>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
+        return 0;
+    });
+}
 
 // per-graph fused convolution (engine_gconv.hpp): needs the batch's per-graph bounds from the host
 bool use_gc(const Ctx& c) {
@@ -856,11 +873,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             float* yy = e->gy + (size_t)(i - 1) * NH;
             {
                 SpmmBranch br{hin, agg, nullptr, nullptr, e->ones, Acc(), Acc()};
-                RC(with_g(H, [&](auto g) {
-                    constexpr int G = decltype(g)::value;
-                    hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gd, SpmmBranch2{{br, br}}, 0, 1.0f, N, H, spmm_rpb(H, false));
-                    return 0;
-                }));
+                RC(launch_espmm(st, gd, SpmmBranch2{{br, br}}, 1, 0, 1.0f, N, H, spmm_rpb(H, false)));
                 CAL_CHECK_LAUNCH("k_espmm(gin)"); STAGE();
             }
             {
@@ -955,11 +968,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         if (wst) { br.st_sum = spmm_acc(c, bn_stsum(c, i + 1), H, rpb); br.st_sq = spmm_acc(c, bn_stsq(c, i + 1), H, rpb); }
         {
             ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0, true);
-            RC(with_g(H, [&](auto g) {
-                constexpr int G = decltype(g)::value;
-                PROF_LAUNCH((k_espmm<4, G>), dim3(cdiv(N, rpb), 1), dim3(256), 0, st, gd, SpmmBranch2{{br, br}}, 1, e->loop_w, N, H, rpb);
-                return 0;
-            }));
+            RC(launch_espmm(st, gd, SpmmBranch2{{br, br}}, 1, 1, e->loop_w, N, H, rpb));
         }
         CAL_CHECK_LAUNCH("k_espmm"); STAGE();
         RC(flush_finals(c)); STAGE();
@@ -1034,11 +1043,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     if (!gc) {
         SpmmBranch b0{e->zco, e->hco, e->P + e->o_cb, e->att, e->dis_co, Acc(), Acc()};
         SpmmBranch b1{e->zco + NH, e->hco + NH, e->P + e->o_ob, e->att + E, e->dis_co + N, Acc(), Acc()};
-        RC(with_g(H, [&](auto g) {
-            constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 2), dim3(256), 0, st, gd, SpmmBranch2{{b0, b1}}, 1, e->loop_w, N, H, spmm_rpb(H, false));
-            return 0;
-        }));
+        RC(launch_espmm(st, gd, SpmmBranch2{{b0, b1}}, 2, 1, e->loop_w, N, H, spmm_rpb(H, false)));
         CAL_CHECK_LAUNCH("k_espmm(co)"); STAGE();
     }
     // 9. add-pool (model.py:115-116)
@@ -1312,11 +1317,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     if (!gcb) {
         SpmmBranch b0{e->dZco, e->dzco, nullptr, e->att, e->dis_co, Acc(), Acc()};
         SpmmBranch b1{e->dZco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, Acc(), Acc()};
-        RC(with_g(H, [&](auto g) {
-            constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 2), dim3(256), 0, st, gs, SpmmBranch2{{b0, b1}}, 0, e->loop_w, N, H, spmm_rpb(H, false));
-            return 0;
-        }));
+        RC(launch_espmm(st, gs, SpmmBranch2{{b0, b1}}, 2, 0, e->loop_w, N, H, spmm_rpb(H, false)));
         CAL_CHECK_LAUNCH("k_espmm(co,T)"); STAGE();
     }
     const float* x = e->h + (size_t)L * NH;
@@ -1564,11 +1565,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             }
             {
                 SpmmBranch br{e->dXh, e->z, nullptr, nullptr, e->ones, Acc(), Acc()};                // d h_{i-1}
-                RC(with_g(H, [&](auto g) {
-                    constexpr int G = decltype(g)::value;
-                    hipLaunchKernelGGL((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, SpmmBranch2{{br, br}}, 0, 1.0f, N, H, spmm_rpb(H, false));
-                    return 0;
-                }));
+                RC(launch_espmm(st, gs, SpmmBranch2{{br, br}}, 1, 0, 1.0f, N, H, spmm_rpb(H, false)));
                 CAL_CHECK_LAUNCH("k_espmm(gin,T)"); STAGE();
             }
             {
@@ -1702,11 +1699,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         } else {
             SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
             ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0, true);
-            RC(with_g(H, [&](auto g) {
-                constexpr int G = decltype(g)::value;
-                PROF_LAUNCH((k_espmm<4, G>), dim3(cdiv(N, spmm_rpb(H, false)), 1), dim3(256), 0, st, gs, SpmmBranch2{{br, br}}, 0, e->loop_w, N, H, spmm_rpb(H, false));
-                return 0;
-            }));
+            RC(launch_espmm(st, gs, SpmmBranch2{{br, br}}, 1, 0, e->loop_w, N, H, spmm_rpb(H, false)));
             CAL_CHECK_LAUNCH("k_espmm(T)");
         }
         STAGE();
@@ -2024,7 +2017,7 @@ CAL_EXPORT int cal_p2p_alloc(int64_t bytes, void** out) {
     if (rc != hipSuccess || !p) { (void)hipGetLastError(); set_error("cal_p2p_alloc: hipExtMallocWithFlags(fine-grained, %lld bytes): %s", (long long)bytes, hipGetErrorString(rc)); return 3; }
     rc = hipMemset(p, 0, (size_t)bytes);
     if (rc == hipSuccess) rc = hipDeviceSynchronize();
-    if (rc != hipSuccess) { (void)hipGetLastError(); hipFree(p); set_error("cal_p2p_alloc: zeroing failed: %s", hipGetErrorString(rc)); return 3; }
+    if (rc != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); set_error("cal_p2p_alloc: zeroing failed: %s", hipGetErrorString(rc)); return 3; }
     *out = p;
     return 0;
 }

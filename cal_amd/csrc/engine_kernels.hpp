@@ -214,85 +214,128 @@ struct SpmmBranch {
 
 struct SpmmBranch2 { SpmmBranch b[2]; };
 
-template <int VEC, int G>
+// Round 4: one WAVE per row.  The row's CSR slots are fetched by ONE coalesced instruction (lane l <- slot base + l: neighbour
+// id, then deg^-1/2 of the neighbour and the edge weight in the same lanes), and every gather address / coefficient is
+// broadcast out of those registers (v_readlane -> SGPR base addresses when a wave's 64 lanes cover the row, G = 64; ds_bpermute
+// when 64 / G lane groups each take another neighbour of the SAME row, partial sums added across the groups at the end): a row
+// costs rowptr -> {nbr, eid} -> {dis, w} -> EXACTLY deg feature gathers issued back to back, eight (x 64 / G) in flight.  The
+// per-lane form it replaces (four clamped-free neighbours at a time, then a serial remainder loop in which every neighbour was a
+// dependent nbr -> {dis, h} chain) left the degree-2..3 rows of BA / molecule graphs on ~8 dependent round trips:
+// scripts/micro/gather_lds.hip, profiles/r4/micro_gather_lds.txt: 128 -> 101 us at config 5 (32 BA graphs of 5000 nodes, H = 256).
+template <int NB, int G>
+__device__ __forceinline__ void espmm_batch(Vec<4>& acc, const float* __restrict__ h, int H, int jl, float cl, int q, int cnt, int gi, int c) {
+    constexpr int SPLIT = 64 / G;
+    Vec<4> v[NB];
+    float cf[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        int j;
+        if constexpr (SPLIT == 1) {
+            j = __builtin_amdgcn_readlane(jl, q + u);
+            cf[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cl), q + u));
+        } else {
+            const int slot = q + u * SPLIT + gi;             // this lane group's neighbour of the batch
+            const int src = min(slot, cnt - 1) << 2;
+            j = __builtin_amdgcn_ds_bpermute(src, jl);
+            const float cc = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, cl)));
+            cf[u] = slot < cnt ? cc : 0.f;
+        }
+        v[u] = Vec<4>::ld(h + (size_t)j * H + c);          // (unconditional: a guarded load is its own basic block behind a vmcnt(0))
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) v[u].pin();
+#pragma unroll
+    for (int u = 0; u < NB; ++u) acc.fma(cf[u], v[u]);
+}
+
+// WT: per-edge weights (the two causal branches; their load rides with deg^-1/2 of the neighbour), ST: column statistics of the
+// output for the next BatchNorm (8 fp64 accumulators per lane: without them the kernel keeps 8 waves per SIMD)
+template <int VEC, int G, bool WT, bool ST>
 __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch2 bb, int relu,
                                                float loop_w, int N, int H, int rows_per_block) {
-    __shared__ double lds[2][256 * (VEC == 4 ? 4 : 1)];
-    constexpr int RPB = 256 / G;
+    static_assert(VEC == 4 && G >= 8 && G <= 64, "16 B per lane, 8..64 lanes per row");
+    __shared__ double lds[ST ? 2 : 1][ST ? 256 * 4 : 1];
+    constexpr int SPLIT = 64 / G;
     warm_kernargs<sizeof(CSR) + sizeof(SpmmBranch2) + 32>();
     const SpmmBranch& br = bb.b[blockIdx.y];            // indexed in the kernel-argument segment: one set of scalar loads
-    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gi = lane / G, l = lane % G, c = l * VEC;
     // XCD-contiguous row blocks: workgroups are dealt to the 8 XCDs round-robin, and a row's neighbours live in its
     // own graph (block-diagonal batch).  Workgroup w therefore takes row block (w % 8) * (blocks / 8) + w / 8 -- each
     // XCD walks one contiguous eighth of the rows, so the ~5 gathers of every feature row hit ONE L2 instead of being
     // spread over eight (big batches: the gather volume E'*H*4 is 2.4x the algorithmic bytes and it was all fabric traffic)
-    // (Measured and rejected: sweeping the columns in 2 / 4 windows per ~graph-sized row chunk so that a window of the
-    // graph's features fits the 4 MB L2 -- 151 -> 158 / 166 us at config 5: the kernel is not bound by gather traffic.)
     const int per = gridDim.x >> 3;
     const int bxr = (int)blockIdx.x < 8 * per ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int rbeg = bxr * rows_per_block, rend = min(N, rbeg + rows_per_block);
     using V = Vec<VEC>;
-    const bool want = br.st_sum.on();
+    const bool cok = c < H;
+    const int cld = cok ? c : 0;                       // lanes beyond the row width read column 0 and store nothing
     BLK_CLK(0);
-    for (int c = l * VEC; c - l * VEC < H; c += G * VEC) {
-        const bool cok = c < H;
-        double s1[VEC], s2[VEC];
+    double s1[VEC], s2[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
-        for (int i = rbeg + grp; i < rend; i += RPB) {
-            if (!cok) continue;
-            const int p0 = g.ptr[i], p1 = g.ptr[i + 1];
-            const float di = br.dis[i];
-            V acc = V::zero();
-            int s = p0;
-            for (; s + 4 <= p1; s += 4) {
-                const int j0 = g.nbr[s], j1 = g.nbr[s + 1], j2 = g.nbr[s + 2], j3 = g.nbr[s + 3];
-                float c0 = br.dis[j0], c1 = br.dis[j1], c2 = br.dis[j2], c3 = br.dis[j3];
-                if (br.w) {
-                    c0 *= br.w[g.eid[s]]; c1 *= br.w[g.eid[s + 1]]; c2 *= br.w[g.eid[s + 2]]; c3 *= br.w[g.eid[s + 3]];
-                }
-                V h0 = V::ld(br.h + (size_t)j0 * H + c), h1 = V::ld(br.h + (size_t)j1 * H + c);
-                V h2 = V::ld(br.h + (size_t)j2 * H + c), h3 = V::ld(br.h + (size_t)j3 * H + c);
-                acc.fma(c0, h0); acc.fma(c1, h1); acc.fma(c2, h2); acc.fma(c3, h3);
+    for (int j = 0; j < VEC; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
+    for (int iw = rbeg + wv; iw < rend; iw += 4) {
+        const int i = __builtin_amdgcn_readfirstlane(iw);
+        const int p0 = g.ptr[i], p1 = g.ptr[i + 1];
+        const float di = br.dis[i];
+        const V hs = V::ld(br.h + (size_t)i * H + cld);      // the row's own features go out with the first round
+        V acc = V::zero();
+        for (int base = p0; base < p1; base += 64) {
+            const int s = min(base + lane, p1 - 1);
+            int jl = g.nbr[s], el = WT ? g.eid[s] : 0;
+            asm volatile("" : "+v"(jl), "+v"(el));            // both ids requested before either is used
+            float cl = br.dis[jl];
+            if constexpr (WT) cl *= br.w[el];
+            const int cnt = min(64, p1 - base);
+            int q = 0;
+            for (; q + 8 * SPLIT <= cnt; q += 8 * SPLIT) espmm_batch<8, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld);
+            switch ((cnt - q + SPLIT - 1) / SPLIT) {          // (8 only when 64 / G > 1: 7 * SPLIT < cnt - q < 8 * SPLIT)
+                case 8: espmm_batch<8, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
+                case 7: espmm_batch<7, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
+                case 6: espmm_batch<6, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
+                case 5: espmm_batch<5, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
+                case 4: espmm_batch<4, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
+                case 3: espmm_batch<3, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
+                case 2: espmm_batch<2, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
+                case 1: espmm_batch<1, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
+                default: break;
             }
-            for (; s < p1; ++s) {
-                const int j = g.nbr[s];
-                float cf = br.dis[j];
-                if (br.w) cf *= br.w[g.eid[s]];
-                acc.fma(cf, V::ld(br.h + (size_t)j * H + c));
+        }
+        if constexpr (SPLIT > 1) {
+#pragma unroll
+            for (int off = G; off < 64; off <<= 1) {
+                acc.v.x += __shfl_xor(acc.v.x, off, 64); acc.v.y += __shfl_xor(acc.v.y, off, 64);
+                acc.v.z += __shfl_xor(acc.v.z, off, 64); acc.v.w += __shfl_xor(acc.v.w, off, 64);
             }
-            acc.fma(di * loop_w, V::ld(br.h + (size_t)i * H + c));
-            acc.scale(di);
-            if (br.bias) acc.add(V::ld(br.bias + c));
-            if (relu) acc.relu();
+        }
+        acc.fma(di * loop_w, hs);
+        acc.scale(di);
+        if (br.bias) acc.add(V::ld(br.bias + cld));
+        if (relu) acc.relu();
+        if (gi == 0 && cok) {
             acc.st(br.out + (size_t)i * H + c);
-            if (want) {
+            if constexpr (ST) {
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) { double v = acc.get(j); s1[j] += v; s2[j] += v * v; }
             }
         }
-        if (want) {
-            // the block's column sums: row groups of a wave by shuffle, the four waves through LDS, one lane per column
-            // (2 x 2 barriers; eight block_col_atomic calls were 16 barriers with 32 lanes adding serially: 6 of the
-            //  kernel's 14 us at 7.5 k rows)
-            double* L = &lds[0][0];
-            const int wv = threadIdx.x >> 6, ncol = G * VEC, cbase = c - l * VEC;
+    }
+    if constexpr (ST) {
+        // the block's column sums: the four waves through LDS, one lane per column (2 x 2 barriers)
+        double* L = &lds[0][0];
+        const int ncol = G * VEC;
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if (gi == 0) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    double v = cok ? (pass ? s2[j] : s1[j]) : 0.0;
-                    if (G < 64) for (int off = G; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-                    if ((threadIdx.x & 63) < G) L[wv * ncol + l * VEC + j] = v;
-                }
-                __syncthreads();
-                if ((int)threadIdx.x < ncol && cbase + (int)threadIdx.x < H) {
-                    const int q = threadIdx.x;
-                    const double t = (L[q] + L[ncol + q]) + (L[2 * ncol + q] + L[3 * ncol + q]);
-                    (pass ? br.st_sq : br.st_sum).add(cbase + q, t);
-                }
-                __syncthreads();
+                for (int j = 0; j < VEC; ++j) L[wv * ncol + l * VEC + j] = cok ? (pass ? s2[j] : s1[j]) : 0.0;
             }
+            __syncthreads();
+            if ((int)threadIdx.x < ncol && (int)threadIdx.x < H) {
+                const int qq = threadIdx.x;
+                const double t = (L[qq] + L[ncol + qq]) + (L[2 * ncol + qq] + L[3 * ncol + qq]);
+                (pass ? br.st_sq : br.st_sum).add(qq, t);
+            }
+            __syncthreads();
         }
     }
     BLK_CLK(1);

@@ -172,6 +172,164 @@ __global__ void __launch_bounds__(NT) k_v2(const int* __restrict__ gptr, const i
     }
 }
 
+// ---------------------------------------------------------------- V1b: as V1 with slot-ordered coefficients cs[s] = dis[nbr[s]] * w[eid[s]]
+// (one E'-sized pass per step and branch): three dependent rounds per row (ptr -> {nbr, cs} -> h) instead of four
+__global__ void __launch_bounds__(256) k_v1b(const int* __restrict__ ptr, const int* __restrict__ nbr, const float* __restrict__ cs,
+                                             const float* __restrict__ dis, const float* __restrict__ h, float* __restrict__ out, int N) {
+    const int per = gridDim.x >> 3;
+    const int bxr = (int)blockIdx.x < 8 * per ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, c = lane * 4;
+    const int i = __builtin_amdgcn_readfirstlane(bxr * 4 + (threadIdx.x >> 6));
+    if (i >= N) return;
+    const int p0 = ptr[i], p1 = ptr[i + 1];
+    const float di = dis[i];
+    const float4 hs = *(const float4*)(h + (size_t)i * H + c);
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int base = p0; base < p1; base += 64) {
+        const int s = min(base + lane, p1 - 1);
+        const int jl = nbr[s];
+        const float cl = cs[s];
+        const int cnt = min(64, p1 - base);
+        int q = 0;
+        for (; q + 8 <= cnt; q += 8) v1_batch<8>(acc, h, jl, cl, q, c);
+        switch (cnt - q) {
+            case 7: v1_batch<7>(acc, h, jl, cl, q, c); break;
+            case 6: v1_batch<6>(acc, h, jl, cl, q, c); break;
+            case 5: v1_batch<5>(acc, h, jl, cl, q, c); break;
+            case 4: v1_batch<4>(acc, h, jl, cl, q, c); break;
+            case 3: v1_batch<3>(acc, h, jl, cl, q, c); break;
+            case 2: v1_batch<2>(acc, h, jl, cl, q, c); break;
+            case 1: v1_batch<1>(acc, h, jl, cl, q, c); break;
+            default: break;
+        }
+    }
+    acc.x = fmaf(di, hs.x, acc.x); acc.y = fmaf(di, hs.y, acc.y); acc.z = fmaf(di, hs.z, acc.z); acc.w = fmaf(di, hs.w, acc.w);
+    acc.x *= di; acc.y *= di; acc.z *= di; acc.w *= di;
+    *(float4*)(out + (size_t)i * H + c) = acc;
+}
+// V1c: persistent waves (grid = CUs x 8 workgroups), every wave walks rows i, i + stride, ...; the NEXT row's pointers and slots
+// are requested before the current row's gathers are consumed (software pipeline over rows)
+__global__ void __launch_bounds__(256) k_v1c(const int* __restrict__ ptr, const int* __restrict__ nbr, const float* __restrict__ cs,
+                                             const float* __restrict__ dis, const float* __restrict__ h, float* __restrict__ out, int N, int rows_per_wave) {
+    const int lane = threadIdx.x & 63, c = lane * 4;
+    // XCD-contiguous: workgroup b on XCD b % 8 walks the b / 8-th stripe of that XCD's eighth of the rows
+    const int wpx = (gridDim.x >> 3) * 4;                         // waves per XCD
+    const int xcd = blockIdx.x & 7, wq = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    const int per_x = (N + 7) / 8;
+    const int xbeg = xcd * per_x, xend = min(N, xbeg + per_x);
+    int i = __builtin_amdgcn_readfirstlane(xbeg + wq);
+    if (i >= xend) return;
+    int p0 = ptr[i], p1 = ptr[i + 1];
+    int s = min(p0 + lane, max(p1 - 1, p0));
+    int jl = p1 > p0 ? nbr[s] : 0; float cl = p1 > p0 ? cs[s] : 0.f;
+    for (; i < xend; i += wpx) {
+        const int inext = i + wpx;
+        const bool more = inext < xend;
+        const int q0 = more ? ptr[inext] : 0, q1 = more ? ptr[inext + 1] : 0;
+        const float di = dis[i];
+        const float4 hs = *(const float4*)(h + (size_t)i * H + c);
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        int base = p0;
+        while (true) {
+            const int cnt = min(64, p1 - base);
+            int q = 0;
+            for (; q + 8 <= cnt; q += 8) v1_batch<8>(acc, h, jl, cl, q, c);
+            switch (cnt - q) {
+                case 7: v1_batch<7>(acc, h, jl, cl, q, c); break;
+                case 6: v1_batch<6>(acc, h, jl, cl, q, c); break;
+                case 5: v1_batch<5>(acc, h, jl, cl, q, c); break;
+                case 4: v1_batch<4>(acc, h, jl, cl, q, c); break;
+                case 3: v1_batch<3>(acc, h, jl, cl, q, c); break;
+                case 2: v1_batch<2>(acc, h, jl, cl, q, c); break;
+                case 1: v1_batch<1>(acc, h, jl, cl, q, c); break;
+                default: break;
+            }
+            base += 64;
+            if (base >= p1) break;
+            s = min(base + lane, p1 - 1); jl = nbr[s]; cl = cs[s];
+        }
+        // next row's slots go out before this row's tail
+        int njl = 0; float ncl = 0.f;
+        if (more && q1 > q0) { const int sn = min(q0 + lane, q1 - 1); njl = nbr[sn]; ncl = cs[sn]; }
+        acc.x = fmaf(di, hs.x, acc.x); acc.y = fmaf(di, hs.y, acc.y); acc.z = fmaf(di, hs.z, acc.z); acc.w = fmaf(di, hs.w, acc.w);
+        acc.x *= di; acc.y *= di; acc.z *= di; acc.w *= di;
+        *(float4*)(out + (size_t)i * H + c) = acc;
+        p0 = q0; p1 = q1; jl = njl; cl = ncl;
+    }
+}
+
+// ---------------------------------------------------------------- V2s: the LDS slice with a SELL-64 slot stream
+// Rows of a graph are cut into virtual rows of <= 16 slots (a hub row = several), sorted by slot count; chunk = 64 virtual rows,
+// slot k of the 64 rows contiguous (sidx 16-bit local source, sw coefficient incl. the source's deg^-1/2): every load of the
+// stream is one coalesced instruction.  Partial sums of multi-segment rows meet in an LDS scratch, summed in segment order.
+struct Sell {
+    const int* cptr;              // [B+1] chunk range of graph g
+    const int* cbase;             // [chunks] first slot of the chunk
+    const int* cwidth;            // [chunks] slots per lane
+    const int* vrow;              // [chunks*64] local row of the virtual row (-1: padding) | segment << 16 ... see host
+    const int* vseg;              // [chunks*64] -1: the row has one segment (write directly); else index into the scratch
+    const unsigned short* sidx;
+    const float* sw;
+    const int* hptr;              // [B+1] multi-segment rows of graph g
+    const int* hrow;              // [.] local row
+    const int* hseg0;             // [.] first scratch index, segments consecutive
+    const int* hnseg;             // [.]
+};
+constexpr int V2S_SCR = 1024;      // scratch entries (virtual rows of multi-segment rows) per graph
+template <int NT, bool BLK_IN, bool BLK_OUT>
+__global__ void __launch_bounds__(NT) k_v2s(const int* __restrict__ gptr, const Sell S, const float* __restrict__ dis, const float* __restrict__ h,
+                                            float* __restrict__ out, int N, int B, int* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) float4 xs[V2_MAXN];
+    __shared__ __attribute__((aligned(16))) float4 scr[V2S_SCR];
+    constexpr int NS = H / 4;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int g = (q / NS) * 8 + xcd, sl = q % NS;
+    if (g >= B) return;
+    const int n0 = gptr[g], n = gptr[g + 1] - n0;
+    if (n > V2_MAXN || n <= 0) { if (threadIdx.x == 0 && n > V2_MAXN) atomicOr(status, 1); return; }
+    for (int r = threadIdx.x; r < n; r += NT)
+        xs[r] = BLK_IN ? *(const float4*)(h + ((size_t)sl * N + n0 + r) * 4) : *(const float4*)(h + (size_t)(n0 + r) * H + sl * 4);
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c0 = S.cptr[g], c1 = S.cptr[g + 1];
+    for (int ch = c0 + wv; ch < c1; ch += NT / 64) {
+        const int base = S.cbase[ch], W = S.cwidth[ch];
+        const int r = S.vrow[ch * 64 + lane], sg = S.vseg[ch * 64 + lane];
+        float4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < W; k += 4) {
+            int j[4]; float cf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int ku = min(k + u, W - 1); j[u] = S.sidx[base + ku * 64 + lane]; cf[u] = k + u < W ? S.sw[base + ku * 64 + lane] : 0.f; }
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = xs[j[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc.x = fmaf(cf[u], v[u].x, acc.x); acc.y = fmaf(cf[u], v[u].y, acc.y); acc.z = fmaf(cf[u], v[u].z, acc.z); acc.w = fmaf(cf[u], v[u].w, acc.w); }
+        }
+        if (r >= 0) {
+            if (sg >= 0) scr[sg] = acc;
+            else {
+                const int i = n0 + r;
+                const float d = dis[i];
+                const float4 sv = xs[r];
+                acc.x = (acc.x + d * sv.x) * d; acc.y = (acc.y + d * sv.y) * d; acc.z = (acc.z + d * sv.z) * d; acc.w = (acc.w + d * sv.w) * d;
+                if (BLK_OUT) *(float4*)(out + ((size_t)sl * N + i) * 4) = acc; else *(float4*)(out + (size_t)i * H + sl * 4) = acc;
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = S.hptr[g] + threadIdx.x; k < S.hptr[g + 1]; k += NT) {
+        const int r = S.hrow[k], s0 = S.hseg0[k], ns = S.hnseg[k];
+        float4 acc = scr[s0];
+        for (int t = 1; t < ns; ++t) { const float4 v = scr[s0 + t]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        const int i = n0 + r;
+        const float d = dis[i];
+        const float4 sv = xs[r];
+        acc.x = (acc.x + d * sv.x) * d; acc.y = (acc.y + d * sv.y) * d; acc.z = (acc.z + d * sv.z) * d; acc.w = (acc.w + d * sv.w) * d;
+        if (BLK_OUT) *(float4*)(out + ((size_t)sl * N + i) * 4) = acc; else *(float4*)(out + (size_t)i * H + sl * 4) = acc;
+    }
+}
+
 // row-major <-> column-blocked (what a GEMM epilogue / a consumer's staging would do for free)
 __global__ void k_to_blocked(const float* __restrict__ a, float* __restrict__ b, int N) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -300,6 +458,66 @@ int main(int argc, char** argv) {
     RUN_V2(1024, true, false, "V2 LDS slice, 1024 thr, blocked in / row-major out");
     RUN_V2(1024, false, false, "V2 LDS slice, 1024 thr, row-major in / row-major out");
     RUN_V2(512, false, false, "V2 LDS slice,  512 thr, row-major in / row-major out");
+    // ---- V1b / V1c
+    std::vector<float> cs(G.E);
+    for (int64_t t = 0; t < G.E; ++t) cs[t] = G.dis[G.nbr[t]] * G.ws[t];
+    float* d_cs = dev(cs);
+    CK(hipMemset(d_out, 0, (size_t)N * H * 4));
+    us = timeit([&] { hipLaunchKernelGGL(k_v1b, dim3((N + 3) / 4), dim3(256), 0, 0, d_ptr, d_nbr, d_cs, d_dis, d_h, d_out, N); });
+    report("V1b = V1 + slot-ordered coefficients", us); check("v1b", d_out);
+    for (int wgs : {2048, 4096}) {
+        CK(hipMemset(d_out, 0, (size_t)N * H * 4));
+        us = timeit([&] { hipLaunchKernelGGL(k_v1c, dim3(wgs), dim3(256), 0, 0, d_ptr, d_nbr, d_cs, d_dis, d_h, d_out, N, 0); });
+        char nm[96]; snprintf(nm, sizeof nm, "V1c persistent waves (%d wgs), next row prefetched", wgs);
+        report(nm, us); check("v1c", d_out);
+    }
+    // ---- V2s: SELL-64 stream of virtual rows (<= 16 slots), sorted by width inside each graph
+    {
+        std::vector<int> cptr(B + 1, 0), cbase, cwidth, vrow, vseg, hptr(B + 1, 0), hrow, hseg0, hnseg;
+        std::vector<unsigned short> sidx; std::vector<float> sw;
+        int64_t real = 0;
+        for (int g = 0; g < B; ++g) {
+            struct VR { int r, p0, len, seg; };
+            std::vector<VR> vr;
+            int nscr = 0;
+            for (int r = 0; r < n; ++r) {
+                const int i = g * n + r, p0 = G.ptr[i], d = G.ptr[i + 1] - p0;
+                if (d <= V2_HUB) vr.push_back({r, p0, d, -1});
+                else {
+                    const int ns = (d + V2_HUB - 1) / V2_HUB;
+                    hrow.push_back(r); hseg0.push_back(nscr); hnseg.push_back(ns);
+                    for (int t = 0; t < ns; ++t) vr.push_back({r, p0 + t * V2_HUB, std::min(V2_HUB, d - t * V2_HUB), nscr++});
+                }
+            }
+            if (nscr > V2S_SCR) { printf("scratch too small: %d\n", nscr); return 1; }
+            hptr[g + 1] = (int)hrow.size();
+            std::stable_sort(vr.begin(), vr.end(), [](const VR& a, const VR& b) { return a.len > b.len; });
+            for (size_t k = 0; k < vr.size(); k += 64) {
+                const int W = vr[k].len;
+                cbase.push_back((int)sidx.size()); cwidth.push_back(W);
+                sidx.resize(sidx.size() + (size_t)W * 64, 0); sw.resize(sw.size() + (size_t)W * 64, 0.f);
+                for (int l = 0; l < 64; ++l) {
+                    if (k + l < vr.size()) {
+                        const VR& v = vr[k + l];
+                        vrow.push_back(v.r); vseg.push_back(v.seg);
+                        for (int t = 0; t < v.len; ++t) { sidx[cbase.back() + t * 64 + l] = G.nbr16[v.p0 + t]; sw[cbase.back() + t * 64 + l] = cs[v.p0 + t]; real++; }
+                    } else { vrow.push_back(-1); vseg.push_back(-1); }
+                }
+            }
+            cptr[g + 1] = (int)cbase.size();
+        }
+        printf("SELL-64: %zu chunks, %zu padded slots for %lld real (%.2fx), %zu multi-segment rows\n", cbase.size(), sidx.size(), (long long)real, (double)sidx.size() / real, hrow.size());
+        Sell S{dev(cptr), dev(cbase), dev(cwidth), dev(vrow), dev(vseg), dev(sidx), dev(sw), dev(hptr), dev(hrow), dev(hseg0), dev(hnseg)};
+#define RUN_V2S(NT, BI, BO, label) do { \
+        CK(hipMemset(d_out, 0, (size_t)N * H * 4)); CK(hipMemset(d_outb, 0, (size_t)N * H * 4)); \
+        us = timeit([&] { hipLaunchKernelGGL((k_v2s<NT, BI, BO>), dim3(nwg), dim3(NT), 0, 0, d_gptr, S, d_dis, BI ? d_hb : d_h, BO ? d_outb : d_out, N, B, d_status); }); \
+        report(label, us); \
+        if (BO) { hipLaunchKernelGGL(k_from_blocked, dim3(tb), dim3(256), 0, 0, d_outb, d_tmp, N); check(label, d_tmp); } else check(label, d_out); } while (0)
+        RUN_V2S(1024, true, true, "V2s SELL LDS slice, 1024 thr, blocked / blocked");
+        RUN_V2S(512, true, true, "V2s SELL LDS slice,  512 thr, blocked / blocked");
+        RUN_V2S(1024, false, false, "V2s SELL LDS slice, 1024 thr, row-major / row-major");
+        RUN_V2S(1024, true, false, "V2s SELL LDS slice, 1024 thr, blocked / row-major");
+    }
     // layout conversion alone (what a producer / consumer would otherwise absorb)
     us = timeit([&] { hipLaunchKernelGGL(k_to_blocked, dim3(tb), dim3(256), 0, 0, d_h, d_hb, N); });
     printf("  row-major -> blocked copy alone: %.1f us\n", us);
