@@ -541,6 +541,270 @@ __global__ void __launch_bounds__(256) k_gat_bwd_src(const int* __restrict__ row
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4: the H = 256, K = 4 (head dim 64) layer -- PyG's default heads = 4 (model.py:319) at BASELINE config 5's width -- with
+// one WAVE per row and the row's slots in LANES.  The kernels above issue one memory instruction per slot AND per quantity
+// (nbr, eid, a_src, the z / g row, the d(raw logit) store: ~45 per row in the backward), every one of them 16+ cycles of the
+// CU's address path whatever it moves: at config 5 they are bound by memory-instruction issue, not by bytes.  Here lane t of the
+// wave owns slot t of the row (edges, then the node's own loop): its neighbour id, edge id, the FOUR heads' a_src / a_dst / max /
+// denominator / d(raw logit) travel as one coalesced or one 16 B-per-lane instruction per 64 slots, the per-slot-per-head
+// arithmetic (logit, exp, dropout hash, softmax backward) runs lane-parallel, and only the feature-row gathers remain per
+// slot: their row address comes out of the slot lanes by v_readlane (an SGPR base), their coefficient by four v_readlane and a
+// select on the lane's head, the per-head dot products go back into the slot lane by v_readlane + a select on the lane id.  Exactly deg + 1 row
+// gathers, eight in flight.  (scripts/micro/gather_lds.hip: the same restructuring of the plain aggregation, 128 -> 101 us.)
+// ------------------------------------------------------------------------------------------------------------------------
+namespace gw {
+constexpr int K = 4, D = 64, H = 256;
+__device__ __forceinline__ float rdl(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+__device__ __forceinline__ float sel4(float a0, float a1, float a2, float a3, int k) { return k == 0 ? a0 : (k == 1 ? a1 : (k == 2 ? a2 : a3)); }
+__device__ __forceinline__ float wave_sum(float v) {       // every lane gets the total of the 64
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float comp(const float4& v, int h) { return h == 0 ? v.x : (h == 1 ? v.y : (h == 2 ? v.z : v.w)); }
+
+template <int NB, bool DROP>
+__device__ __forceinline__ void fwd_batch(Vec<4>& acc, float& m, float& lsum, const float* __restrict__ z, const Vec<4>& att_s, float ad,
+                                          float slope, int jl, const float (&kl)[4], int q, int c, int k) {
+    Vec<4> zv[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) zv[u] = Vec<4>::ld(z + (size_t)__builtin_amdgcn_readlane(jl, q + u) * H + c);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) zv[u].pin();
+    float e[NB], mn = m;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) { e[u] = lrelu(ad + row16_sum(zv[u].dot(att_s)), slope) * GAT_LOG2E; mn = fmaxf(mn, e[u]); }
+    const float sc = exp2f(m - mn);                 // one rescale of the running softmax per batch
+    lsum *= sc;
+    acc.scale(sc);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const float pe = exp2f(e[u] - mn);
+        lsum += pe;
+        const float kq = DROP ? sel4(rdl(kl[0], q + u), rdl(kl[1], q + u), rdl(kl[2], q + u), rdl(kl[3], q + u), k) : 1.f;
+        acc.fma(pe * kq, zv[u]);
+    }
+    m = mn;
+}
+}  // namespace gw
+
+#define GW_SWITCH(REM, CALL) switch (REM) { case 7: CALL(7); break; case 6: CALL(6); break; case 5: CALL(5); break; case 4: CALL(4); break; \
+                                            case 3: CALL(3); break; case 2: CALL(2); break; case 1: CALL(1); break; default: break; }
+
+// GATConv forward, one pass (a_src of a neighbour recomputed from the z row the aggregation fetches, online edge softmax)
+template <bool DROP>
+__global__ void __launch_bounds__(256) k_gat_fwd_w(const int* __restrict__ rowptr, const int* __restrict__ nbr, const int* __restrict__ eid,
+                                                   const float* __restrict__ z, const float* __restrict__ att, const float* __restrict__ bias,
+                                                   int relu, float slope, float p, uint64_t seed, int64_t E, float* __restrict__ out,
+                                                   float* __restrict__ adst, float* __restrict__ asrc, float* __restrict__ mx,
+                                                   float* __restrict__ den, int N, const uint64_t* __restrict__ ctr) {
+    using namespace gw;
+    using V = Vec<4>;
+    seed = step_seed(seed, ctr);
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(xcd_block() * 4 + (int)(threadIdx.x >> 6));
+    if (i >= N) return;
+    const int c = lane * 4, k = lane >> 4, d = c & (D - 1);
+    const int s0 = rowptr[i], s1 = rowptr[i + 1];
+    const V zi = V::ld(z + (size_t)i * H + c);
+    const V att_d = V::ld(att + k * 2 * D + d), att_s = V::ld(att + k * 2 * D + D + d);
+    const float inv_keep = DROP ? 1.f / (1.f - p) : 1.f;
+    const float ad = row16_sum(zi.dot(att_d)), as_i = row16_sum(zi.dot(att_s));
+    float m = lrelu(ad + as_i, slope) * GAT_LOG2E, lsum = 1.f;          // the node's own loop starts the running softmax
+    V acc = zi;
+    if (DROP) acc.scale(keep_scale(seed, E + i, k, K, p, inv_keep));
+    for (int base = s0; base < s1; base += 64) {
+        const int sl = min(base + lane, s1 - 1);
+        int jl = nbr[sl], el = DROP ? eid[sl] : 0;
+        asm volatile("" : "+v"(jl), "+v"(el));
+        float kl[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) kl[h] = keep_scale(seed, el, h, K, p, inv_keep);      // this lane's slot, the four heads
+        }
+        const int cnt = min(64, s1 - base);
+        int q = 0;
+        for (; q + 8 <= cnt; q += 8) fwd_batch<8, DROP>(acc, m, lsum, z, att_s, ad, slope, jl, kl, q, c, k);
+#define GW_CALL(NB) fwd_batch<NB, DROP>(acc, m, lsum, z, att_s, ad, slope, jl, kl, q, c, k)
+        GW_SWITCH(cnt - q, GW_CALL)
+#undef GW_CALL
+    }
+    const float dn = lsum + 1e-16f;
+    acc.scale(1.f / dn);
+    if (bias) acc.add(V::ld(bias + c));
+    if (relu) acc.relu();
+    acc.st(out + (size_t)i * H + c);
+    // per-(node, head) scalars for the backward: the four heads' values as ONE 16 B store each
+    const float mo = m * (1.f / GAT_LOG2E);
+    const float4 a4 = make_float4(rdl(ad, 0), rdl(ad, 16), rdl(ad, 32), rdl(ad, 48)), s4 = make_float4(rdl(as_i, 0), rdl(as_i, 16), rdl(as_i, 32), rdl(as_i, 48));
+    const float4 m4 = make_float4(rdl(mo, 0), rdl(mo, 16), rdl(mo, 32), rdl(mo, 48)), d4 = make_float4(rdl(dn, 0), rdl(dn, 16), rdl(dn, 32), rdl(dn, 48));
+    if (lane < 4) {
+        float* dst = lane == 0 ? adst : (lane == 1 ? asrc : (lane == 2 ? mx : den));
+        const float4 v = lane == 0 ? a4 : (lane == 1 ? s4 : (lane == 2 ? m4 : d4));
+        *reinterpret_cast<float4*>(dst + (size_t)i * K) = v;
+    }
+}
+
+// Backward over the by-destination CSR: d(raw logit) of every slot -> draw[id, 0:4], their row sums -> dadst[i, 0:4].
+// Slot t of the row = edge s0 + t (t < deg) or the node's own loop (t = deg).  Rows of <= 64 slots (all but a few hubs of a BA
+// graph) are ONE sweep: dalpha of the slots stays in the slot lanes until S = sum alpha dalpha is known; longer rows sweep twice
+// (the second sweep gathers the z rows again instead of parking dalpha in memory).
+template <bool DROP>
+__global__ void __launch_bounds__(256) k_gat_bwd_dst_w(const int* __restrict__ rowptr, const int* __restrict__ nbr, const int* __restrict__ eid,
+                                                       const float* __restrict__ z, const float* __restrict__ adst, const float* __restrict__ asrc,
+                                                       const float* __restrict__ mx, const float* __restrict__ den, const float* __restrict__ gout,
+                                                       float slope, float p, uint64_t seed, int64_t E, float* __restrict__ draw,
+                                                       float* __restrict__ dadst, int N, const uint64_t* __restrict__ ctr) {
+    using namespace gw;
+    using V = Vec<4>;
+    seed = step_seed(seed, ctr);
+    const int lane = threadIdx.x & 63;
+    const int i = __builtin_amdgcn_readfirstlane(xcd_block() * 4 + (int)(threadIdx.x >> 6));
+    if (i >= N) return;
+    const int c = lane * 4;
+    const int s0 = rowptr[i], s1 = rowptr[i + 1];
+    const int deg = s1 - s0, nsl = deg + 1;
+    const V gi = V::ld(gout + (size_t)i * H + c);
+    const float4 ad4 = ld4(adst + (size_t)i * K), m4 = ld4(mx + (size_t)i * K), dn4 = ld4(den + (size_t)i * K);     // uniform addresses
+    const float inv_keep = DROP ? 1.f / (1.f - p) : 1.f;
+    float al[4], da[4], raw[4];
+    int idl = 0;
+    bool valid = false;
+    // one chunk of <= 64 slots: ids and a_src lane-parallel, dalpha through the z gathers, then alpha / dalpha of this lane's slot
+    auto chunk = [&](int base) {
+        const int t = base + lane;
+        valid = t < nsl;
+        int jl = i, el = 0;
+        if (deg > 0) {
+            const int se = s0 + min(t, deg - 1);
+            jl = nbr[se]; el = eid[se];
+            asm volatile("" : "+v"(jl), "+v"(el));
+            if (t >= deg) jl = i;
+        }
+        idl = t < deg ? el : (int)E + i;
+        const float4 as4 = ld4(asrc + (size_t)jl * K);
+        float dal[4] = {0.f, 0.f, 0.f, 0.f};
+        const int cnt = min(64, nsl - base);
+        auto batch = [&](auto nbc, int q) {
+            constexpr int NB = decltype(nbc)::value;
+            V zv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) zv[u] = V::ld(z + (size_t)__builtin_amdgcn_readlane(jl, q + u) * H + c);
+#pragma unroll
+            for (int u = 0; u < NB; ++u) zv[u].pin();
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const float dot = row16_sum(gi.dot(zv[u]));             // <g_i, z_j> per head, in every lane of the head
+                const bool mine = lane == q + u;                        // ... and into the slot's lane (one compare, four selects)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) dal[h] = mine ? rdl(dot, 16 * h) : dal[h];
+            }
+        };
+        int q = 0;
+        for (; q + 8 <= cnt; q += 8) batch(std::integral_constant<int, 8>(), q);
+#define GW_CALL(NB) batch(std::integral_constant<int, NB>(), q)
+        GW_SWITCH(cnt - q, GW_CALL)
+#undef GW_CALL
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            raw[h] = comp(ad4, h) + comp(as4, h);
+            al[h] = valid ? exp2f((lrelu(raw[h], slope) - comp(m4, h)) * GAT_LOG2E) / comp(dn4, h) : 0.f;
+            da[h] = dal[h] * (DROP ? keep_scale(seed, idl, h, K, p, inv_keep) : 1.f);
+        }
+    };
+    float S[4] = {0.f, 0.f, 0.f, 0.f}, rowsum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto finish = [&]() {
+        float de[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { de[h] = al[h] * (da[h] - S[h]) * (raw[h] > 0.f ? 1.f : slope); rowsum[h] += wave_sum(de[h]); }
+        if (valid) *reinterpret_cast<float4*>(draw + (size_t)idl * K) = make_float4(de[0], de[1], de[2], de[3]);
+    };
+    if (nsl <= 64) {
+        chunk(0);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) S[h] = wave_sum(al[h] * da[h]);
+        finish();
+    } else {
+        for (int base = 0; base < nsl; base += 64) {
+            chunk(base);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) S[h] += wave_sum(al[h] * da[h]);
+        }
+        for (int base = 0; base < nsl; base += 64) { chunk(base); finish(); }
+    }
+    if (lane == 0) *reinterpret_cast<float4*>(dadst + (size_t)i * K) = make_float4(rowsum[0], rowsum[1], rowsum[2], rowsum[3]);
+}
+
+// Backward over the by-source CSR: dz[j] = sum_slots alpha~ g[dst] + dadst[j] att_dst + dasrc[j] att_src, dasrc[j] = sum_slots d(raw logit)
+template <bool DROP>
+__global__ void __launch_bounds__(256) k_gat_bwd_src_w(const int* __restrict__ rowptr, const int* __restrict__ nbr, const int* __restrict__ eid,
+                                                       const float* __restrict__ att, const float* __restrict__ adst, const float* __restrict__ asrc,
+                                                       const float* __restrict__ mx, const float* __restrict__ den, const float* __restrict__ gout,
+                                                       const float* __restrict__ dadst, const float* __restrict__ draw, float* __restrict__ dasrc,
+                                                       float slope, float p, uint64_t seed, int64_t E, float* __restrict__ dz, int N,
+                                                       const uint64_t* __restrict__ ctr) {
+    using namespace gw;
+    using V = Vec<4>;
+    seed = step_seed(seed, ctr);
+    const int lane = threadIdx.x & 63;
+    const int j = __builtin_amdgcn_readfirstlane(xcd_block() * 4 + (int)(threadIdx.x >> 6));
+    if (j >= N) return;
+    const int c = lane * 4, k = lane >> 4, d = c & (D - 1);
+    const int s0 = rowptr[j], s1 = rowptr[j + 1];
+    const int deg = s1 - s0, nsl = deg + 1;
+    const float4 as4 = ld4(asrc + (size_t)j * K);
+    const float inv_keep = DROP ? 1.f / (1.f - p) : 1.f;
+    V acc = V::zero();
+    float das[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < nsl; base += 64) {
+        const int t = base + lane;
+        const bool valid = t < nsl;
+        int il = j, el = 0;
+        if (deg > 0) {
+            const int se = s0 + min(t, deg - 1);
+            il = nbr[se]; el = eid[se];
+            asm volatile("" : "+v"(il), "+v"(el));
+            if (t >= deg) il = j;
+        }
+        const int idl = t < deg ? el : (int)E + j;
+        const float4 ad4 = ld4(adst + (size_t)il * K), m4 = ld4(mx + (size_t)il * K), dn4 = ld4(den + (size_t)il * K);
+        const float4 dr4 = ld4(draw + (size_t)idl * K);
+        float at[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const float a = exp2f((lrelu(comp(ad4, h) + comp(as4, h), slope) - comp(m4, h)) * GAT_LOG2E) / comp(dn4, h);
+            at[h] = valid ? a * (DROP ? keep_scale(seed, idl, h, K, p, inv_keep) : 1.f) : 0.f;
+            das[h] += valid ? comp(dr4, h) : 0.f;
+        }
+        const int cnt = min(64, nsl - base);
+        auto batch = [&](auto nbc, int q) {
+            constexpr int NB = decltype(nbc)::value;
+            V gv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) gv[u] = V::ld(gout + (size_t)__builtin_amdgcn_readlane(il, q + u) * H + c);
+#pragma unroll
+            for (int u = 0; u < NB; ++u) gv[u].pin();
+#pragma unroll
+            for (int u = 0; u < NB; ++u) acc.fma(sel4(rdl(at[0], q + u), rdl(at[1], q + u), rdl(at[2], q + u), rdl(at[3], q + u), k), gv[u]);
+        };
+        int q = 0;
+        for (; q + 8 <= cnt; q += 8) batch(std::integral_constant<int, 8>(), q);
+#define GW_CALL(NB) batch(std::integral_constant<int, NB>(), q)
+        GW_SWITCH(cnt - q, GW_CALL)
+#undef GW_CALL
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) das[h] = wave_sum(das[h]);
+    if (lane == 0) *reinterpret_cast<float4*>(dasrc + (size_t)j * K) = make_float4(das[0], das[1], das[2], das[3]);
+    acc.fma(dadst[(size_t)j * K + k], V::ld(att + k * 2 * D + d));
+    acc.fma(sel4(das[0], das[1], das[2], das[3], k), V::ld(att + k * 2 * D + D + d));
+    acc.st(dz + (size_t)j * H + c);
+}
+#undef GW_SWITCH
+
 // partial sums for d att: part[blk, k, 0:D] = sum_v dadst[v,k] z[v,k,:], part[blk, k, D:2D] = sum_v dasrc[v,k] z[v,k,:]
 __global__ void __launch_bounds__(256) k_gat_datt_part(const float* __restrict__ z, const float* __restrict__ dadst,
                                                        const float* __restrict__ dasrc, float* __restrict__ part,
@@ -634,6 +898,15 @@ int gat_forward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t
     CAL_REQUIRE(p >= 0.f && p < 1.f, "dropout p must be in [0,1)");
     int64_t H = K * D;
     bool vec_ok = (D % 4 == 0) && aligned16(z) && aligned16(out) && (!bias || aligned16(bias));
+    if (vec_ok && K == 4 && D == 64 && aligned16(att) && aligned16(adst) && aligned16(asrc) && aligned16(mx) && aligned16(den)) {
+        // H = 256, four heads: one wave per row, slots in lanes (k_gat_fwd_w)
+        if (p > 0.f) hipLaunchKernelGGL((k_gat_fwd_w<true>), dim3(cdiv(N, 4)), dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, att, bias, relu,
+                                        slope, p, seed, E, out, adst, asrc, mx, den, (int)N, ctr);
+        else hipLaunchKernelGGL((k_gat_fwd_w<false>), dim3(cdiv(N, 4)), dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, att, bias, relu,
+                                slope, p, seed, E, out, adst, asrc, mx, den, (int)N, ctr);
+        CAL_CHECK_LAUNCH("k_gat_fwd_w");
+        return 0;
+    }
     if (vec_ok && pow2(D / 4) && aligned16(att) && D / 4 <= 64) {
         // scores + online edge softmax + aggregation in one pass (a head's lanes sit inside one row group)
         CAL_DISPATCH_VG((int)H, true, {
@@ -699,6 +972,23 @@ int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_
     if (N > 0) {
         bool vec_ok = (D % 4 == 0) && pow2(D / 4) && aligned16(z) && aligned16(gout) && aligned16(dz) && aligned16(att);
         CAL_REQUIRE(vec_ok || pow2(D), "head dim must be a power of two (or 4 * a power of two)");
+        const bool wave_rows = vec_ok && K == 4 && D == 64 && aligned16(adst) && aligned16(asrc) && aligned16(mx) && aligned16(den) &&
+                               aligned16(draw) && E + N < (1ll << 31);
+        if (wave_rows) {
+            const dim3 grid(cdiv(N, 4));
+            if (p > 0.f) {
+                hipLaunchKernelGGL((k_gat_bwd_dst_w<true>), grid, dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, adst, asrc, mx, den, gout,
+                                   slope, p, seed, E, draw, dadst, (int)N, ctr);
+                hipLaunchKernelGGL((k_gat_bwd_src_w<true>), grid, dim3(256), 0, stream, rowptr_src, nbr_src, eid_src, att, adst, asrc, mx, den, gout,
+                                   dadst, draw, dasrc, slope, p, seed, E, dz, (int)N, ctr);
+            } else {
+                hipLaunchKernelGGL((k_gat_bwd_dst_w<false>), grid, dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, adst, asrc, mx, den, gout,
+                                   slope, p, seed, E, draw, dadst, (int)N, ctr);
+                hipLaunchKernelGGL((k_gat_bwd_src_w<false>), grid, dim3(256), 0, stream, rowptr_src, nbr_src, eid_src, att, adst, asrc, mx, den, gout,
+                                   dadst, draw, dasrc, slope, p, seed, E, dz, (int)N, ctr);
+            }
+            CAL_CHECK_LAUNCH("k_gat_bwd_w");
+        } else {
         CAL_DISPATCH_VG((int)H, vec_ok, {
             hipLaunchKernelGGL((k_gat_bwd_dst_c<VEC, G>), dim3(cdiv(N, 256 / G)), dim3(256), 0, stream, rowptr_dst, nbr_dst,
                                eid_dst, z, adst, asrc, mx, den, gout, slope, p, seed, E, draw, dadst, (int)N, (int)K, (int)D, ctr);
@@ -709,6 +999,7 @@ int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_
                                eid_src, att, adst, asrc, mx, den, gout, dadst, draw, dasrc, slope, p, seed, E, dz, (int)N, (int)K, (int)D, ctr);
         });
         CAL_CHECK_LAUNCH("k_gat_bwd_src");
+        }
         int threads = (int)(H > 256 ? 256 : ((H + 63) / 64) * 64);
         hipLaunchKernelGGL(k_gat_datt_part, dim3(nb), dim3(threads), 0, stream, z, dadst, dasrc, part, (int)N, (int)K, (int)D, rpb);
         CAL_CHECK_LAUNCH("k_gat_datt_part");

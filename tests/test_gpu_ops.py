@@ -221,6 +221,52 @@ def test_gat_aggregate_fwd_bwd(relu, p_drop):
         assert torch.allclose(bd.grad.cpu(), bias.grad, atol=2e-4, rtol=1e-3), name
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+def test_gat_h256_four_heads_hub_rows_and_isolated_nodes(p_drop):
+    """The H = 256 / 4-head kernels keep a row's slots in the lanes of ONE wave: rows of more than 64 slots (hubs: two sweeps in the
+    by-destination backward, several 64-slot chunks everywhere), rows with no edge at all (only the added loop, GATConv's
+    add_self_loops), an input self loop (dropped) and a directed edge, all against the oracle's GATConv (model.py:340,390)."""
+    from cal_amd import ops
+    from cal_amd.data import Batch, Data
+    g = torch.Generator().manual_seed(21)
+    ds = []
+    for n, hub_deg in ((200, 150), (90, 70), (5, 0)):
+        src, dst = [], []
+        for v in range(1, hub_deg + 1):                      # star around node 0, both directions
+            src += [0, v]; dst += [v, 0]
+        extra = torch.randint(1 if hub_deg else 0, n - 1, (2, 3 * n // 2), generator=g)   # (node n - 1 stays isolated)
+        keep = extra[0] != extra[1]
+        src += extra[0][keep].tolist(); dst += extra[1][keep].tolist()
+        src += [2] if n > 3 else []; dst += [2] if n > 3 else []                            # an input self loop
+        ei = torch.tensor([src, dst], dtype=torch.long)
+        ei = torch.unique(ei, dim=1)
+        ds.append(Data(x=torch.randn(n, 256, generator=g), edge_index=ei, y=torch.zeros(1, dtype=torch.long)))
+    b = Batch.from_data_list(ds)
+    K, D, H = 4, 64, 256
+    pl = _plan(b)
+    deg_dst = (pl.rowptr_dst[1:] - pl.rowptr_dst[:-1]).cpu()
+    assert int(deg_dst.max()) > 128 and int((deg_dst > 63).sum()) >= 2 and int((deg_dst == 0).sum()) >= 2
+    z = (b.x * 0.5).clone().requires_grad_(True)
+    att = (torch.randn(1, K, 2 * D, generator=g) * 0.3).requires_grad_(True)
+    bias = torch.randn(H, generator=g).requires_grad_(True)
+    seed, mask = 77, None
+    if p_drop > 0:
+        full = ops.gat_dropout_mask(seed, pl, K, p_drop).cpu()
+        row, col = b.edge_index
+        keep_e = (row != col).nonzero().view(-1)
+        mask = torch.cat([full[keep_e], full[pl.E:]], 0)
+    ref = torch.relu(O.gat_conv(z, b.edge_index, torch.eye(H), att, bias, K, 0.2, p_drop, p_drop > 0, mask))
+    gout = torch.randn(ref.shape, generator=g)
+    ref.backward(gout)
+    zd, ad, bd = (t.detach().to(DEV).requires_grad_(True) for t in (z, att, bias))
+    out = ops.gat_aggregate(zd, ad, bd, pl, K, 0.2, p_drop, seed, True)
+    out.backward(gout.to(DEV))
+    assert torch.allclose(out.detach().cpu(), ref.detach(), atol=5e-5, rtol=1e-4)
+    assert torch.allclose(zd.grad.cpu(), z.grad, atol=1e-4, rtol=1e-3)
+    assert torch.allclose(ad.grad.cpu(), att.grad, atol=1e-3, rtol=1e-3)
+    assert torch.allclose(bd.grad.cpu(), bias.grad, atol=2e-4, rtol=1e-3)
+
+
 def _big_plan(N, deg, seed=0):
     from cal_amd.plan import GraphPlan
     g = torch.Generator().manual_seed(seed)
