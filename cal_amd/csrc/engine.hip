@@ -661,9 +661,16 @@ struct ProfScope {
         else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); } while (0)
 
 int launch_espmm(hipStream_t st, const CSR& csr, const SpmmBranch2& bb, int nbranch, int relu, float loop_w, int N, int H, int rpb) {
-    const bool wt = bb.b[0].w != nullptr, stt = bb.b[0].st_sum.on();
-    if (wt != (bb.b[nbranch - 1].w != nullptr) || stt != bb.b[nbranch - 1].st_sum.on() || rpb % 4 != 0 || H > 256) { set_error("k_espmm: branches differ in kind"); return 2; }
+    const bool wt = bb.b[0].w != nullptr, stt = bb.b[0].st_sum.on(), sd = bb.b[0].sd_z != nullptr;
+    if (wt != (bb.b[nbranch - 1].w != nullptr) || stt != bb.b[nbranch - 1].st_sum.on() || sd != (bb.b[nbranch - 1].sd_z != nullptr) || rpb % 4 != 0 || H > 256) {
+        set_error("k_espmm: branches differ in kind"); return 2;
+    }
     const dim3 grid(cdiv(N, rpb), nbranch);
+    if (sd) {       // transposed weighted aggregation + SDDMM (espmm_sddmm_ok: H = 256)
+        if (!wt || stt || group_for(H, 4) != 64 || H != 256) { set_error("k_espmm: the fused SDDMM is built for weighted branches of width 256"); return 2; }
+        PROF_LAUNCH((k_espmm<4, 64, true, false, true>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
+        return 0;
+    }
     return with_g(H, [&](auto g) {
         constexpr int G = decltype(g)::value;
         if (wt && stt) PROF_LAUNCH((k_espmm<4, G, true, true>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
@@ -872,7 +879,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             float* t1 = e->gt1 + (size_t)(i - 1) * NH;
             float* yy = e->gy + (size_t)(i - 1) * NH;
             {
-                SpmmBranch br{hin, agg, nullptr, nullptr, e->ones, Acc(), Acc()};
+                SpmmBranch br{hin, agg, nullptr, nullptr, e->ones, Acc(), Acc(), nullptr, nullptr, nullptr};
                 RC(launch_espmm(st, gd, SpmmBranch2{{br, br}}, 1, 0, 1.0f, N, H, spmm_rpb(H, false)));
                 CAL_CHECK_LAUNCH("k_espmm(gin)"); STAGE();
             }
@@ -962,7 +969,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         a.p[0].A = e->h + (size_t)(i - 1) * NH; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->z;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, i, N, 1);
         { ProfScope ps(st, 0, 2.0 * N * H * H); RC(fwd_gemm(c, false, a, 1)); } STAGE();
-        SpmmBranch br{e->z, e->h + (size_t)i * NH, e->P + e->o_conv_b[i - 1], nullptr, e->dis_unit, Acc(), Acc()};
+        SpmmBranch br{e->z, e->h + (size_t)i * NH, e->P + e->o_conv_b[i - 1], nullptr, e->dis_unit, Acc(), Acc(), nullptr, nullptr, nullptr};
         const bool wst = c.training && i < L;
         const int rpb = spmm_rpb(H, wst, N);
         if (wst) { br.st_sum = spmm_acc(c, bn_stsum(c, i + 1), H, rpb); br.st_sq = spmm_acc(c, bn_stsq(c, i + 1), H, rpb); }
@@ -1041,8 +1048,8 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     }
     // 8. h_k = relu(A_hat_k z_k + b_k)
     if (!gc) {
-        SpmmBranch b0{e->zco, e->hco, e->P + e->o_cb, e->att, e->dis_co, Acc(), Acc()};
-        SpmmBranch b1{e->zco + NH, e->hco + NH, e->P + e->o_ob, e->att + E, e->dis_co + N, Acc(), Acc()};
+        SpmmBranch b0{e->zco, e->hco, e->P + e->o_cb, e->att, e->dis_co, Acc(), Acc(), nullptr, nullptr, nullptr};
+        SpmmBranch b1{e->zco + NH, e->hco + NH, e->P + e->o_ob, e->att + E, e->dis_co + N, Acc(), Acc(), nullptr, nullptr, nullptr};
         RC(launch_espmm(st, gd, SpmmBranch2{{b0, b1}}, 2, 1, e->loop_w, N, H, spmm_rpb(H, false)));
         CAL_CHECK_LAUNCH("k_espmm(co)"); STAGE();
     }
@@ -1307,7 +1314,12 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         }
         return 0;
     };
-    if (!gcb) {
+    // At width 256 (one wave per row) the SDDMM rides on the transposed aggregation of P5: that kernel gathers dZ_k[dst] for
+    // every out-edge of a source row anyway, so gn_e = <dZ_k[dst_e], z_k[src_e]> costs it one more row (z_k[src]) and a wave
+    // reduction per slot instead of a second pass over both matrices (k_sddmm2: 265 us per step at config 5).  Input self-loop
+    // edges have no slot: their gn entry is never read (k_normbwd_* skip them like the plan does).
+    const bool sd_fused = !gcb && H == 256;
+    if (!gcb && !sd_fused) {
         hipLaunchKernelGGL(k_sddmm2, dim3(cdiv(E + N, 32), 2), dim3(256), 0, st, e->row32, e->col32, e->dZco, e->dZco + NH, e->zco,
                            e->zco + NH, e->gn, e->gself, N, E, H);
         CAL_CHECK_LAUNCH("k_sddmm2"); STAGE();
@@ -1315,10 +1327,15 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     }
     // P5. dz_k = A_hat_k^T dZ_k
     if (!gcb) {
-        SpmmBranch b0{e->dZco, e->dzco, nullptr, e->att, e->dis_co, Acc(), Acc()};
-        SpmmBranch b1{e->dZco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, Acc(), Acc()};
+        SpmmBranch b0{e->dZco, e->dzco, nullptr, e->att, e->dis_co, Acc(), Acc(), nullptr, nullptr, nullptr};
+        SpmmBranch b1{e->dZco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, Acc(), Acc(), nullptr, nullptr, nullptr};
+        if (sd_fused) {
+            b0.sd_z = e->zco; b0.sd_gn = e->gn; b0.sd_gself = e->gself;
+            b1.sd_z = e->zco + NH; b1.sd_gn = e->gn + E; b1.sd_gself = e->gself + N;
+        }
         RC(launch_espmm(st, gs, SpmmBranch2{{b0, b1}}, 2, 0, e->loop_w, N, H, spmm_rpb(H, false)));
         CAL_CHECK_LAUNCH("k_espmm(co,T)"); STAGE();
+        if (sd_fused) RC(norm_bwd(nullptr, nullptr));
     }
     const float* x = e->h + (size_t)L * NH;
     // P5-P7 fused per graph: dz_k stays in LDS; dX'_k arrives as one partial per output-column slice
@@ -1564,7 +1581,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                 RC(fwd_gemm(c, false, a, 1)); STAGE();
             }
             {
-                SpmmBranch br{e->dXh, e->z, nullptr, nullptr, e->ones, Acc(), Acc()};                // d h_{i-1}
+                SpmmBranch br{e->dXh, e->z, nullptr, nullptr, e->ones, Acc(), Acc(), nullptr, nullptr, nullptr};                // d h_{i-1}
                 RC(launch_espmm(st, gs, SpmmBranch2{{br, br}}, 1, 0, 1.0f, N, H, spmm_rpb(H, false)));
                 CAL_CHECK_LAUNCH("k_espmm(gin,T)"); STAGE();
             }
@@ -1697,7 +1714,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             fa.st[fa.nst++] = SlabTask{part, e->G + e->o_conv_att[i - 1], 2 * H, nparts};
             slab_off += need;
         } else {
-            SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc()};
+            SpmmBranch br{e->dZ, dzi, nullptr, nullptr, e->dis_unit, Acc(), Acc(), nullptr, nullptr, nullptr};
             ProfScope ps(st, 1, 2.0 * N * H * 4 + (double)(c.E + N) * 8 + (N + 1) * 4.0, true);
             RC(launch_espmm(st, gs, SpmmBranch2{{br, br}}, 1, 0, e->loop_w, N, H, spmm_rpb(H, false)));
             CAL_CHECK_LAUNCH("k_espmm(T)");

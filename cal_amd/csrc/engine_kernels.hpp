@@ -210,6 +210,11 @@ struct SpmmBranch {
     const float* dis;      // deg^-1/2 per node
     Acc st_sum;            // column statistics of the output (next BatchNorm) or off
     Acc st_sq;
+    // SDDMM riding on the TRANSPOSED aggregation (k_espmm<.., SD = true>, by-source CSR: the gathered rows are dOut[dst]):
+    // gn[eid] = <dOut[dst_e], z[src_e]>, gself[v] = <dOut[v], z[v]> -- the gradient w.r.t. the edge weights (gcn_conv.py:63-70,97)
+    const float* sd_z;     // z = x' W of this branch (the forward aggregation's input), or null
+    float* sd_gn;          // [E] by edge id
+    float* sd_gself;       // [N]
 };
 
 struct SpmmBranch2 { SpmmBranch b[2]; };
@@ -222,9 +227,11 @@ struct SpmmBranch2 { SpmmBranch b[2]; };
 // per-lane form it replaces (four clamped-free neighbours at a time, then a serial remainder loop in which every neighbour was a
 // dependent nbr -> {dis, h} chain) left the degree-2..3 rows of BA / molecule graphs on ~8 dependent round trips:
 // scripts/micro/gather_lds.hip, profiles/r4/micro_gather_lds.txt: 128 -> 101 us at config 5 (32 BA graphs of 5000 nodes, H = 256).
-template <int NB, int G>
-__device__ __forceinline__ void espmm_batch(Vec<4>& acc, const float* __restrict__ h, int H, int jl, float cl, int q, int cnt, int gi, int c) {
+template <int NB, int G, bool SD = false>
+__device__ __forceinline__ void espmm_batch(Vec<4>& acc, const float* __restrict__ h, int H, int jl, float cl, int q, int cnt, int gi, int c,
+                                            const Vec<4>* zj = nullptr, float* gdot = nullptr, int lane = 0) {
     constexpr int SPLIT = 64 / G;
+    static_assert(!SD || SPLIT == 1, "the fused SDDMM needs the whole wave on one row");
     Vec<4> v[NB];
     float cf[NB];
 #pragma unroll
@@ -246,11 +253,26 @@ __device__ __forceinline__ void espmm_batch(Vec<4>& acc, const float* __restrict
     for (int u = 0; u < NB; ++u) v[u].pin();
 #pragma unroll
     for (int u = 0; u < NB; ++u) acc.fma(cf[u], v[u]);
+    if constexpr (SD) {
+        // <gathered row, own z row>: the wave's 64 partial dots summed (DPP row sums + two cross-row exchanges), parked in the
+        // slot's lane; the lanes write gn[eid] once per 64 slots
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            float d = v[u].dot(*zj);
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x128, 0xf, 0xf, false));
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x124, 0xf, 0xf, false));
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x122, 0xf, 0xf, false));
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x121, 0xf, 0xf, false));
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            *gdot = lane == q + u ? d : *gdot;
+        }
+    }
 }
 
 // WT: per-edge weights (the two causal branches; their load rides with deg^-1/2 of the neighbour), ST: column statistics of the
 // output for the next BatchNorm (8 fp64 accumulators per lane: without them the kernel keeps 8 waves per SIMD)
-template <int VEC, int G, bool WT, bool ST>
+template <int VEC, int G, bool WT, bool ST, bool SD = false>
 __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch2 bb, int relu,
                                                float loop_w, int N, int H, int rows_per_block) {
     static_assert(VEC == 4 && G >= 8 && G <= 64, "16 B per lane, 8..64 lanes per row");
@@ -278,27 +300,41 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch2 bb
         const int p0 = g.ptr[i], p1 = g.ptr[i + 1];
         const float di = br.dis[i];
         const V hs = V::ld(br.h + (size_t)i * H + cld);      // the row's own features go out with the first round
+        V zj = V::zero();
+        if constexpr (SD) { zj = V::ld(br.sd_z + (size_t)i * H + cld); if (!cok) zj = V::zero(); }
         V acc = V::zero();
         for (int base = p0; base < p1; base += 64) {
             const int s = min(base + lane, p1 - 1);
-            int jl = g.nbr[s], el = WT ? g.eid[s] : 0;
+            int jl = g.nbr[s], el = (WT || SD) ? g.eid[s] : 0;
+            float gdot = 0.f;
             asm volatile("" : "+v"(jl), "+v"(el));            // both ids requested before either is used
             float cl = br.dis[jl];
             if constexpr (WT) cl *= br.w[el];
             const int cnt = min(64, p1 - base);
             int q = 0;
-            for (; q + 8 * SPLIT <= cnt; q += 8 * SPLIT) espmm_batch<8, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld);
+            for (; q + 8 * SPLIT <= cnt; q += 8 * SPLIT) espmm_batch<8, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane);
             switch ((cnt - q + SPLIT - 1) / SPLIT) {          // (8 only when 64 / G > 1: 7 * SPLIT < cnt - q < 8 * SPLIT)
-                case 8: espmm_batch<8, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
-                case 7: espmm_batch<7, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
-                case 6: espmm_batch<6, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
-                case 5: espmm_batch<5, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
-                case 4: espmm_batch<4, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
-                case 3: espmm_batch<3, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
-                case 2: espmm_batch<2, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
-                case 1: espmm_batch<1, G>(acc, br.h, H, jl, cl, q, cnt, gi, cld); break;
+                case 8: espmm_batch<8, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
+                case 7: espmm_batch<7, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
+                case 6: espmm_batch<6, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
+                case 5: espmm_batch<5, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
+                case 4: espmm_batch<4, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
+                case 3: espmm_batch<3, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
+                case 2: espmm_batch<2, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
+                case 1: espmm_batch<1, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
                 default: break;
             }
+            if constexpr (SD) { if (lane < cnt) br.sd_gn[el] = gdot; }
+        }
+        if constexpr (SD) {
+            float d = hs.dot(zj);                              // gself: the row's own loop
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x128, 0xf, 0xf, false));
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x124, 0xf, 0xf, false));
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x122, 0xf, 0xf, false));
+            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x121, 0xf, 0xf, false));
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            if (lane == 0) br.sd_gself[i] = d;
         }
         if constexpr (SPLIT > 1) {
 #pragma unroll
