@@ -591,6 +591,7 @@ __device__ __forceinline__ void fwd_batch(Vec<4>& acc, float& m, float& lsum, co
 }
 }  // namespace gw
 
+constexpr int FWD_NB = 4;      // z rows in flight per wave in the forward (8: 100 VGPRs, 4 waves per SIMD)
 #define GW_SWITCH(REM, CALL) switch (REM) { case 7: CALL(7); break; case 6: CALL(6); break; case 5: CALL(5); break; case 4: CALL(4); break; \
                                             case 3: CALL(3); break; case 2: CALL(2); break; case 1: CALL(1); break; default: break; }
 
@@ -623,12 +624,12 @@ __global__ void __launch_bounds__(256) k_gat_fwd_w(const int* __restrict__ rowpt
         float kl[4] = {1.f, 1.f, 1.f, 1.f};
         if (DROP) {
 #pragma unroll
-            for (int h = 0; h < 4; ++h) kl[h] = keep_scale(seed, el, h, K, p, inv_keep);      // this lane's slot, the four heads
+            for (int h = 0; h < 4; ++h) { kl[h] = keep_scale(seed, el, h, K, p, inv_keep); __builtin_amdgcn_sched_barrier(0); }   // this lane's slot, the four heads, ONE hash at a time (interleaved: +30 VGPRs)
         }
         const int cnt = min(64, s1 - base);
         int q = 0;
-        for (; q + 8 <= cnt; q += 8) fwd_batch<8, DROP>(acc, m, lsum, z, att_s, ad, slope, jl, kl, q, c, k);
-#define GW_CALL(NB) fwd_batch<NB, DROP>(acc, m, lsum, z, att_s, ad, slope, jl, kl, q, c, k)
+        for (; q + FWD_NB <= cnt; q += FWD_NB) fwd_batch<FWD_NB, DROP>(acc, m, lsum, z, att_s, ad, slope, jl, kl, q, c, k);
+#define GW_CALL(NB) fwd_batch<(NB < FWD_NB ? NB : 1), DROP>(acc, m, lsum, z, att_s, ad, slope, jl, kl, q, c, k)
         GW_SWITCH(cnt - q, GW_CALL)
 #undef GW_CALL
     }
@@ -713,6 +714,7 @@ __global__ void __launch_bounds__(256) k_gat_bwd_dst_w(const int* __restrict__ r
             raw[h] = comp(ad4, h) + comp(as4, h);
             al[h] = valid ? exp2f((lrelu(raw[h], slope) - comp(m4, h)) * GAT_LOG2E) / comp(dn4, h) : 0.f;
             da[h] = dal[h] * (DROP ? keep_scale(seed, idl, h, K, p, inv_keep) : 1.f);
+            if (DROP) __builtin_amdgcn_sched_barrier(0);
         }
     };
     float S[4] = {0.f, 0.f, 0.f, 0.f}, rowsum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -778,6 +780,7 @@ __global__ void __launch_bounds__(256) k_gat_bwd_src_w(const int* __restrict__ r
             const float a = exp2f((lrelu(comp(ad4, h) + comp(as4, h), slope) - comp(m4, h)) * GAT_LOG2E) / comp(dn4, h);
             at[h] = valid ? a * (DROP ? keep_scale(seed, idl, h, K, p, inv_keep) : 1.f) : 0.f;
             das[h] += valid ? comp(dr4, h) : 0.f;
+            if (DROP) __builtin_amdgcn_sched_barrier(0);
         }
         const int cnt = min(64, nsl - base);
         auto batch = [&](auto nbc, int q) {

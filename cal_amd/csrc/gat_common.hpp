@@ -5,17 +5,20 @@
 
 namespace cal {
 
-__device__ __forceinline__ uint32_t mix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return (uint32_t)(x >> 32);
+// 32-bit finaliser (two multiply-xorshift rounds).  Round 4: the 64-bit splitmix used before cost three 64-bit multiplies per
+// decision -- ~12 quarter-rate v_mul_lo/hi_u32, ~250 cycles per wave -- and every row needs (slots + 1) x heads of them: the
+// training-mode GAT kernels spent more VALU time hashing than on the softmax.  Keys are (slot id * K + head) < 2^32.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21F0AAADu;
+    x ^= x >> 15; x *= 0x735A2D97u;
+    x ^= x >> 15;
+    return x;
 }
 // Counter-based keep decision for (edge slot id, head): reproducible in the backward.
 __device__ __forceinline__ float keep_scale(uint64_t seed, int64_t id, int k, int K, float p, float inv_keep) {
     if (p <= 0.f) return 1.f;
-    uint32_t r = mix64(seed ^ (uint64_t)(id * K + k) * 0xD6E8FEB86659FD93ull);
+    const uint32_t key = (uint32_t)(id * K + k);
+    const uint32_t r = mix32(mix32(key + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
     return ((float)r * (1.0f / 4294967296.0f)) >= p ? inv_keep : 0.f;
 }
 

@@ -37,16 +37,17 @@ void set_error(const char* fmt, ...) {
 inline float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 
 // counter-based attention-dropout keep decision: bit-identical to cal_amd/csrc/gat_common.hpp
-inline uint32_t mix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return (uint32_t)(x >> 32);
+inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21F0AAADu;
+    x ^= x >> 15; x *= 0x735A2D97u;
+    x ^= x >> 15;
+    return x;
 }
+// counter-based attention-dropout decision: the same function as the device's (cal_amd/csrc/gat_common.hpp)
 inline float keep_scale(uint64_t seed, int64_t id, int k, int K, float p, float inv_keep) {
     if (p <= 0.f) return 1.f;
-    const uint32_t r = mix64(seed ^ (uint64_t)(id * K + k) * 0xD6E8FEB86659FD93ull);
+    const uint32_t key = (uint32_t)(id * K + k);
+    const uint32_t r = mix32(mix32(key + (uint32_t)seed) ^ (uint32_t)(seed >> 32));
     return ((float)r * (1.0f / 4294967296.0f)) >= p ? inv_keep : 0.f;
 }
 
