@@ -77,6 +77,72 @@ def test_flat_bucket_allreduce_world2():
     assert torch.allclose(g0, (ref[0] + ref[1]) / 2, atol=1e-6)
 
 
+def _model_worker(rank, world, port, q):
+    """CausalGCN itself (operator path on libcalhost.so: CPU tensors) through the flat bucket + one all-reduce."""
+    import argparse
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cal_amd import model as M
+        from cal_amd.train_causal import causal_loss
+        from cal_amd.trainer import flatten_parameters
+        from oracle import cal_oracle as O
+        from tests.helpers import ref_batch
+        args = argparse.Namespace(layers=2, hidden=32, with_random=True, without_node_attention=False, without_edge_attention=False,
+                                  fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
+        torch.manual_seed(3)
+        sd = O.init_state("CausalGCN", 10, 4, hidden=32, layers=2)
+        m = M.CausalGCN(10, 4, args)
+        m.load_state_dict(sd)
+        m.train()
+        flat_p, flat_g = flatten_parameters(m)
+        b = ref_batch(list(range(6 * rank, 6 * rank + 6)))
+        perm = torch.arange(b.num_graphs - 1, -1, -1)
+        flat_g.zero_()
+        c, o, co = m(b, eval_random=True, perm=perm)
+        loss, *_ = causal_loss(c, o, co, b.y, 4, args)
+        loss.backward()
+        local = flat_g.clone()
+        dist.all_reduce(flat_g)
+        flat_g.mul_(1.0 / world)
+        opt = torch.optim.Adam([flat_p], lr=1e-2)
+        flat_p.grad = flat_g
+        opt.step()
+        # the oracle's gradient on this rank's shard (train_causal.py:173-192 per replica)
+        tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-2, layers=2)
+        tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+        ref = torch.cat([(tr.sd[k].grad if tr.sd[k].grad is not None else torch.zeros_like(tr.sd[k])).reshape(-1) for k, _ in m.named_parameters()])
+        q.put((rank, local.numpy().copy(), flat_g.numpy().copy(), flat_p.detach().numpy().copy(), ref.numpy().copy(), None))
+    except Exception as exc:
+        import traceback
+        q.put((rank, None, None, None, None, traceback.format_exc() + repr(exc)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_causalgcn_replicas_exchange_the_flat_bucket_world2():
+    """The N > 1 path on the MODEL (round-3 review: the bucket test ran a toy net): two gloo ranks, each a CausalGCN replica on
+    its own shard through the host library, one all-reduce of the flat gradient, mean, Adam -- local gradients equal the
+    oracle's on the shard, the exchanged bucket is their mean, replicas end bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for r in res:
+        assert r[5] is None, r[5]
+    (l0, g0, p0, r0), (l1, g1, p1, r1) = [tuple(torch.from_numpy(a) for a in r[1:5]) for r in res]
+    assert torch.allclose(l0, r0, atol=2e-5, rtol=1e-3) and torch.allclose(l1, r1, atol=2e-5, rtol=1e-3)      # local == oracle on the shard
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)                                                      # replicas identical
+    assert torch.allclose(g0, 0.5 * (l0 + l1), atol=1e-7)                                                   # the bucket holds the mean
+
+
 def test_loader_shards_are_disjoint_and_cover():
     from cal_amd.data import DataLoader
     from tests.helpers import ref_graphs
