@@ -666,10 +666,13 @@ int launch_espmm(hipStream_t st, const CSR& csr, const SpmmBranch2& bb, int nbra
         set_error("k_espmm: branches differ in kind"); return 2;
     }
     const dim3 grid(cdiv(N, rpb), nbranch);
-    if (sd) {       // transposed weighted aggregation + SDDMM (espmm_sddmm_ok: H = 256)
-        if (!wt || stt || group_for(H, 4) != 64 || H != 256) { set_error("k_espmm: the fused SDDMM is built for weighted branches of width 256"); return 2; }
-        PROF_LAUNCH((k_espmm<4, 64, true, false, true>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
-        return 0;
+    if (sd) {       // transposed weighted aggregation + SDDMM
+        if (!wt || stt) { set_error("k_espmm: the fused SDDMM is built for the weighted branches without statistics"); return 2; }
+        return with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            PROF_LAUNCH((k_espmm<4, G, true, false, true>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
+            return 0;
+        });
     }
     return with_g(H, [&](auto g) {
         constexpr int G = decltype(g)::value;
@@ -1314,28 +1317,18 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         }
         return 0;
     };
-    // At width 256 (one wave per row) the SDDMM rides on the transposed aggregation of P5: that kernel gathers dZ_k[dst] for
-    // every out-edge of a source row anyway, so gn_e = <dZ_k[dst_e], z_k[src_e]> costs it one more row (z_k[src]) and a wave
-    // reduction per slot instead of a second pass over both matrices (k_sddmm2: 265 us per step at config 5).  Input self-loop
-    // edges have no slot: their gn entry is never read (k_normbwd_* skip them like the plan does).
-    const bool sd_fused = !gcb && H == 256;
-    if (!gcb && !sd_fused) {
-        hipLaunchKernelGGL(k_sddmm2, dim3(cdiv(E + N, 32), 2), dim3(256), 0, st, e->row32, e->col32, e->dZco, e->dZco + NH, e->zco,
-                           e->zco + NH, e->gn, e->gself, N, E, H);
-        CAL_CHECK_LAUNCH("k_sddmm2"); STAGE();
-        RC(norm_bwd(nullptr, nullptr));
-    }
-    // P5. dz_k = A_hat_k^T dZ_k
+    // P5. dz_k = A_hat_k^T dZ_k with the SDDMM riding on it, then P2-P4 on its output.  The transposed aggregation gathers
+    // dZ_k[dst] for every out-edge of a source row anyway, so gn_e = <dZ_k[dst_e], z_k[src_e]> costs it one more row (z_k[src]) and a
+    // lane-group reduction per slot instead of a second pass over both matrices (the separate SDDMM kernel of rounds 1-3: 265 us per
+    // step at config 5).  Input self-loop edges have no slot: their gn entry is never read (k_normbwd_* skip them like the plan does).
     if (!gcb) {
         SpmmBranch b0{e->dZco, e->dzco, nullptr, e->att, e->dis_co, Acc(), Acc(), nullptr, nullptr, nullptr};
         SpmmBranch b1{e->dZco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, Acc(), Acc(), nullptr, nullptr, nullptr};
-        if (sd_fused) {
-            b0.sd_z = e->zco; b0.sd_gn = e->gn; b0.sd_gself = e->gself;
-            b1.sd_z = e->zco + NH; b1.sd_gn = e->gn + E; b1.sd_gself = e->gself + N;
-        }
+        b0.sd_z = e->zco; b0.sd_gn = e->gn; b0.sd_gself = e->gself;
+        b1.sd_z = e->zco + NH; b1.sd_gn = e->gn + E; b1.sd_gself = e->gself + N;
         RC(launch_espmm(st, gs, SpmmBranch2{{b0, b1}}, 2, 0, e->loop_w, N, H, spmm_rpb(H, false)));
         CAL_CHECK_LAUNCH("k_espmm(co,T)"); STAGE();
-        if (sd_fused) RC(norm_bwd(nullptr, nullptr));
+        RC(norm_bwd(nullptr, nullptr));
     }
     const float* x = e->h + (size_t)L * NH;
     // P5-P7 fused per graph: dz_k stays in LDS; dX'_k arrives as one partial per output-column slice

@@ -227,11 +227,26 @@ struct SpmmBranch2 { SpmmBranch b[2]; };
 // per-lane form it replaces (four clamped-free neighbours at a time, then a serial remainder loop in which every neighbour was a
 // dependent nbr -> {dis, h} chain) left the degree-2..3 rows of BA / molecule graphs on ~8 dependent round trips:
 // scripts/micro/gather_lds.hip, profiles/r4/micro_gather_lds.txt: 128 -> 101 us at config 5 (32 BA graphs of 5000 nodes, H = 256).
+// sum over the G lanes (8..64, a power of two) of a lane group; every lane of the group gets the total
+template <int G>
+__device__ __forceinline__ float group_dot_sum(float d) {
+    if constexpr (G >= 16) {
+        d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x128, 0xf, 0xf, false));   // row_ror:8
+        d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x124, 0xf, 0xf, false));
+        d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x122, 0xf, 0xf, false));
+        d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x121, 0xf, 0xf, false));
+        if constexpr (G >= 32) d += __shfl_xor(d, 16, 64);
+        if constexpr (G >= 64) d += __shfl_xor(d, 32, 64);
+    } else {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    }
+    return d;
+}
 template <int NB, int G, bool SD = false>
 __device__ __forceinline__ void espmm_batch(Vec<4>& acc, const float* __restrict__ h, int H, int jl, float cl, int q, int cnt, int gi, int c,
                                             const Vec<4>* zj = nullptr, float* gdot = nullptr, int lane = 0) {
     constexpr int SPLIT = 64 / G;
-    static_assert(!SD || SPLIT == 1, "the fused SDDMM needs the whole wave on one row");
     Vec<4> v[NB];
     float cf[NB];
 #pragma unroll
@@ -254,18 +269,18 @@ __device__ __forceinline__ void espmm_batch(Vec<4>& acc, const float* __restrict
 #pragma unroll
     for (int u = 0; u < NB; ++u) acc.fma(cf[u], v[u]);
     if constexpr (SD) {
-        // <gathered row, own z row>: the wave's 64 partial dots summed (DPP row sums + two cross-row exchanges), parked in the
+        // <gathered row, own z row>: the G lanes' partial dots summed (DPP row sums, cross-row exchanges), parked in the
         // slot's lane; the lanes write gn[eid] once per 64 slots
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            float d = v[u].dot(*zj);
-            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x128, 0xf, 0xf, false));
-            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x124, 0xf, 0xf, false));
-            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x122, 0xf, 0xf, false));
-            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x121, 0xf, 0xf, false));
-            d += __shfl_xor(d, 16, 64);
-            d += __shfl_xor(d, 32, 64);
-            *gdot = lane == q + u ? d : *gdot;
+            float d = group_dot_sum<G>(v[u].dot(*zj));
+            if constexpr (SPLIT == 1) *gdot = lane == q + u ? d : *gdot;
+            else {
+                // lane L holds slot L: in this batch that is element (L - q) / SPLIT of lane group (L - q) % SPLIT
+                const int rel = lane - q;
+                const float dv = __shfl(d, (rel & (SPLIT - 1)) * G, 64);
+                *gdot = (rel >= 0 && rel / SPLIT == u) ? dv : *gdot;
+            }
         }
     }
 }
@@ -327,13 +342,7 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch2 bb
             if constexpr (SD) { if (lane < cnt) br.sd_gn[el] = gdot; }
         }
         if constexpr (SD) {
-            float d = hs.dot(zj);                              // gself: the row's own loop
-            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x128, 0xf, 0xf, false));
-            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x124, 0xf, 0xf, false));
-            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x122, 0xf, 0xf, false));
-            d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x121, 0xf, 0xf, false));
-            d += __shfl_xor(d, 16, 64);
-            d += __shfl_xor(d, 32, 64);
+            const float d = group_dot_sum<G>(cok ? hs.dot(zj) : 0.f);      // gself: the row's own loop
             if (lane == 0) br.sd_gself[i] = d;
         }
         if constexpr (SPLIT > 1) {
@@ -936,33 +945,6 @@ __global__ void __launch_bounds__(256) k_pool_bwd_relu(const float* __restrict__
         for (int j = 0; j < VEC; ++j)
             block_col_atomic(cs[j], l * VEC + j, grp, RPB, G * VEC, cok, db, c + j, lds);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// SDDMM for both branches: gn[br,e] = <dZ_br[col_e], z_br[row_e]>, gself[br,v] = <dZ_br[v], z_br[v]>
-// ------------------------------------------------------------------------------------------------
-// 8 lanes per item; items 0..E-1 are the input edges (self loops skipped), E..E+N-1 the added loops.
-__global__ void __launch_bounds__(256) k_sddmm2(const int* __restrict__ row32, const int* __restrict__ col32,
-                                                const float* __restrict__ dzc, const float* __restrict__ dzo,
-                                                const float* __restrict__ zc, const float* __restrict__ zo,
-                                                float* __restrict__ gn, float* __restrict__ gself, int N, int64_t E, int H) {
-    const int brn = blockIdx.y;
-    const float* dz = brn ? dzo : dzc;
-    const float* z = brn ? zo : zc;
-    const int64_t item = (int64_t)blockIdx.x * 32 + threadIdx.x / 8;
-    const int l = threadIdx.x % 8;
-    if (item >= E + N) return;
-    int r, c;
-    if (item < E) { r = row32[item]; c = col32[item]; if (r == c) return; }
-    else { r = c = (int)(item - E); }
-    float p = 0.f;
-    for (int k = l * 4; k < H; k += 32) {
-        const float4 a = *reinterpret_cast<const float4*>(dz + (size_t)c * H + k);
-        const float4 b = *reinterpret_cast<const float4*>(z + (size_t)r * H + k);
-        p = fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, fmaf(a.x, b.x, p))));
-    }
-    p = group_sum<8>(p);
-    if (l == 0) { if (item < E) gn[(size_t)brn * E + item] = p; else gself[(size_t)brn * N + (item - E)] = p; }
 }
 
 // d deg for both branches (gcn_conv.py:63-70 differentiated); 8 lanes per node

@@ -9,7 +9,7 @@ cp $(find /tmp/prof_$tag/$w -name "*kernel_stats.csv" | head -1) gpurun_out/$tag
 python - <<PY
 import csv
 rows=list(csv.DictReader(open("gpurun_out/$tag/rocprof_kernel_stats_$w.csv")))
-steps=$steps+3
+steps=$steps+3  # (+ capture warm-ups: per-kernel averages are exact, per-step sums approximate)
 tot=sum(float(r["TotalDurationNs"]) for r in rows)
 print("total per step %.1f us" % (tot/steps/1e3))
 for r in rows[:28]:
