@@ -330,8 +330,8 @@ def engine_roofline(trainer, batches, workload, iters=20):
         vals = [pmc.get(k, {}).get("bytes_per_launch") for k in keys]
         return int(sum(vals)) if vals and all(v is not None for v in vals) else None
     gat_traffic = {"gat_fwd": _sum_traffic(["k_gat_fwd"]), "gat_bwd": _sum_traffic(["k_gat_bwd_dst", "k_gat_bwd_src"])}
-    for key, label in (("gat_fwd", "GATConv forward: k_gat_fwd_fused (scores + online edge softmax + dropout + aggregation + bias + ReLU, one pass)"),
-                       ("gat_bwd", "GATConv backward: k_gat_bwd_dst_c / k_gat_bwd_src / k_gat_datt_part (alpha recomputed)")):
+    for key, label in (("gat_fwd", "GATConv forward: k_gat_fwd_w at H = 256 / 4 heads (one wave per row, slots in lanes), else k_gat_fwd_fused -- scores + online edge softmax + dropout + aggregation + bias + ReLU, one pass"),
+                       ("gat_bwd", "GATConv backward: k_gat_bwd_dst_w / k_gat_bwd_src_w at H = 256 / 4 heads (else k_gat_bwd_dst_c / k_gat_bwd_src) + k_gat_datt_part (alpha recomputed)")):
         if key in out:
             dur, work, per_step = out[key]
             ach = work / dur / 1e9

@@ -4,8 +4,8 @@
 tag=$1
 mkdir -p gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-# PMC traffic of the config-5 workloads first (two separate passes each), so that their bench lines carry roofline.traffic
-for w in ba5000_causalgat_h256_l3_bs32 ba5000_causalgcn_h256_l3_bs32; do
+# PMC traffic of every non-headline workload first (two separate passes each), so that their bench lines carry roofline.traffic
+for w in ba5000_causalgat_h256_l3_bs32 ba5000_causalgcn_h256_l3_bs32 spmotif_b0.9_causalgcn_nodenum15_bs32 mutaglike_causalgat_h128_l3_bs64 nci1like_causalgcn_h128_l3_bs512 spmotif_b0.9_causalgat_h128_l3_bs128 spmotif_b0.9_causalgin_h128_l3_bs128; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
         rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/prof_$tag/${w}_$ctr -o b -- python bench.py --workload $w --steps 6 --warmup 2 --batches 2 --no-e2e --no-cpu-baseline --no-roofline --mode eager --repeats 1 > /tmp/pmc_$w.log 2>&1
         python scripts/pmc_summary.py $(find /tmp/prof_$tag/${w}_$ctr -name "*counter_collection.csv" | head -1) $ctr > gpurun_out/$tag/pmc_${ctr}_$w.json
