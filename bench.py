@@ -449,18 +449,27 @@ def reference_loop(wl, margs, gs, steps=60):
         epoch()                                                   # warm-up epoch (workspace sizing, engine creation)
         sched.step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        last = None
-        for _ in range(n_epochs):
-            last = epoch()
-            sched.step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # (the cyclic garbage collector is off inside the timed region, as in Python's own timeit: one full collection of a
+        #  torch process is ~80 ms -- several hundred steps -- and when it fires depends on allocation counts, not on the loop)
+        import gc
+        gc.collect()
+        gc.disable()
+        try:
+            t0 = time.perf_counter()
+            last = None
+            for _ in range(n_epochs):
+                last = epoch()
+                sched.step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
         n_steps = n_epochs * per_epoch
         out[kind] = {"graphs_per_s": n_epochs * len(gs) / dt, "ms_per_step": 1e3 * dt / n_steps, "steps": n_steps,
                      "epoch_loss": float(last), "fused": bool(getattr(opt, "_cal_binding", None) is not None and kind != "module_surface")}
     out["note"] = ("train_causal_epoch (train_causal.py:162-200) over shuffled epochs of a %d-graph dataset, Adam object + " % len(gs) +
-                   "cosine schedule; intervention permutation from Python's RNG on the host as in model.py:147-152")
+                   "cosine schedule; intervention permutation from Python's RNG on the host as in model.py:147-152; host loader = "
+                   "DataLoader over a list (vectorised collate into pinned staging, cal_collate_host); gc off inside the timed regions")
     return out
 
 

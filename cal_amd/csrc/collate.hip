@@ -10,6 +10,7 @@
 // One workgroup per selected graph copies its rows / edges to the output offsets computed on the
 // host from the (host-resident) size arrays.
 #include "common.hpp"
+#include <cstring>
 
 #include <algorithm>
 #include <vector>
@@ -74,6 +75,29 @@ CAL_EXPORT int cal_randperm(int64_t* perm, int64_t B, uint64_t seed, uint64_t* c
     return 0;
 }
 
+
+// Batch assembly for HOST-resident datasets (the reference's own feed: DataLoader + Batch collate, train_causal.py:13-15,171-174):
+// the dataset is one concatenation (X [Ntot, F], EI [2, Etot] with edge ids LOCAL to their graph, node_ptr / edge_ptr [G + 1],
+// Y [G]); the mini-batch `idx` [B] is written into caller-owned (pinned) staging memory -- features, edge_index rebased by
+// the batch's node offsets, batch vector, labels -- with one memcpy per graph and attribute.  Python's per-graph torch.cat of
+// the same took ~1 ms for 128 SPMotif graphs, four GPU steps.  Host pointers, no device work.
+CAL_EXPORT int cal_collate_host(const float* X, const int64_t* EI, int64_t Etot, int64_t F, const int64_t* node_ptr,
+                                const int64_t* edge_ptr, const int64_t* Y, const int64_t* idx, int64_t B, float* xo,
+                                int64_t* eio, int64_t Eout, int64_t* batcho, int64_t* yo) {
+    CAL_REQUIRE(X && EI && node_ptr && edge_ptr && Y && idx && xo && eio && batcho && yo && B >= 0 && F > 0, "bad arguments");
+    int64_t no = 0, eo = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t g = idx[b], n0 = node_ptr[g], n = node_ptr[g + 1] - n0, e0 = edge_ptr[g], e = edge_ptr[g + 1] - e0;
+        CAL_REQUIRE(n >= 0 && e >= 0 && eo + e <= Eout, "cal_collate_host: offsets out of range");
+        memcpy(xo + (size_t)no * F, X + (size_t)n0 * F, (size_t)n * F * sizeof(float));
+        for (int64_t k = 0; k < e; ++k) { eio[eo + k] = EI[e0 + k] + no; eio[Eout + eo + k] = EI[Etot + e0 + k] + no; }
+        for (int64_t k = 0; k < n; ++k) batcho[no + k] = b;
+        yo[b] = Y[g];
+        no += n; eo += e;
+    }
+    CAL_REQUIRE(eo == Eout, "cal_collate_host: edge count mismatch");
+    return 0;
+}
 
 // Host-side helper of the small-graph packing (cal_engine_set_tiles): order the B graphs of a mini-batch so that consecutive
 // runs of them fill 64-node tiles.  A mini-batch is a SET of graphs (the loss is a mean over it, the intervention permutation

@@ -1923,6 +1923,17 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
     return rc == -12345 ? 0 : rc;
 }
 
+// The 3-term loss of train_causal.py:176-183 on log-probabilities logp [3, B, C] (heads c, o, co) with labels y [B]: out [4] =
+// {loss, c_loss, o_loss, co_loss}, and (dlogp non-null) d loss / d logp [3, B, C] -- what cal_engine_backward_from takes.
+// flag (may be null): bit 1 is set when a label lies outside [0, C).
+CAL_EXPORT int cal_causal_loss(const float* logp, const int64_t* y, int64_t B, int64_t C, float wc, float wo, float wco, float* out,
+                               float* dlogp, int32_t* flag, void* stream_) {
+    CAL_REQUIRE(logp && y && out && B > 0 && C > 0 && B * C < (1ll << 30), "bad arguments");
+    hipLaunchKernelGGL(k_causal_loss, dim3(1), dim3(256), 0, (hipStream_t)stream_, logp, y, (int)B, (int)C, wc, wo, wco, out, dlogp, (int*)flag);
+    CAL_CHECK_LAUNCH("k_causal_loss");
+    return 0;
+}
+
 // Per-graph bounds of the batches that follow (largest node count / stored-edge count of any single graph;
 // 0 = unknown).  With bounds that fit (engine_gconv.hpp) the step runs the per-graph fused convolutions; a
 // bound that turns out too small sets bit 3 of the status word and leaves that graph's outputs unwritten.

@@ -1297,4 +1297,42 @@ __global__ void __launch_bounds__(256) k_p2p_adam(const P2PArgs pa, const float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The reference's 3-term loss on given log-probabilities, and its gradient (train_causal.py:176-183):
+//   c_loss = KL(uniform || exp(c)) batchmean = -log C - sum(c) / (B C);  o_loss = NLL(o, y);  co_loss = NLL(co, y)
+//   loss = wc c_loss + wo o_loss + wco co_loss;   out = {loss, c_loss, o_loss, co_loss};
+//   dlogp [3, B, C] = d loss / d (c, o, co): -wc / (B C) everywhere | -wo / B at the label | -wco / B at the label.
+// One workgroup (B C is a few hundred to a few thousand): what a loop that keeps `model(data)` and `loss.backward()` as its
+// own statements would otherwise spend on ~20 tiny torch launches (cal_amd.train_causal.causal_loss).  Labels outside
+// [0, C) contribute nothing and raise status bit 1 of `flag` (torch's nll_loss asserts on the device).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_causal_loss(const float* __restrict__ logp, const int64_t* __restrict__ y, int B, int C,
+                                                     float wc, float wo, float wco, float* __restrict__ out,
+                                                     float* __restrict__ dlogp, int* __restrict__ flag) {
+    __shared__ double red[3][256];
+    const int t = threadIdx.x, BC = B * C;
+    double sc = 0.0, so = 0.0, sco = 0.0;
+    const float gc = -wc / (float)BC, go = -wo / (float)B, gco = -wco / (float)B;
+    for (int i = t; i < BC; i += 256) {
+        const int b = i / C, k = i - b * C;
+        const int64_t yb = y[b];
+        const bool hit = yb == (int64_t)k;
+        sc += (double)logp[i];
+        if (hit) { so += (double)logp[BC + i]; sco += (double)logp[2 * BC + i]; }
+        if (dlogp) { dlogp[i] = gc; dlogp[BC + i] = hit ? go : 0.f; dlogp[2 * BC + i] = hit ? gco : 0.f; }
+        if (k == 0 && (yb < 0 || yb >= C) && flag) atomicOr(flag, 1);
+    }
+    red[0][t] = sc; red[1][t] = so; red[2][t] = sco;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) { red[0][t] += red[0][t + s]; red[1][t] += red[1][t + s]; red[2][t] += red[2][t + s]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float cl = (float)(-log((double)C) - red[0][0] / (double)BC);
+        const float ol = (float)(-red[1][0] / (double)B), col = (float)(-red[2][0] / (double)B);
+        out[0] = wc * cl + wo * ol + wco * col; out[1] = cl; out[2] = ol; out[3] = col;
+    }
+}
+
 }  // namespace cal

@@ -394,6 +394,26 @@ class StepEngine:
         """Factor on the gradient inside Adam: 1 / world_size turns the all-reduced sum into the replicas' mean."""
         _lib.call("cal_engine_set_grad_scale", self._h, float(scale))
 
+    def perm_stage(self) -> "PermStage":
+        """The engine's pinned ring for host-drawn intervention permutations (model.py:147-152: Python's RNG on the host)."""
+        st = getattr(self, "_perm_stage", None)
+        if st is None:
+            st = self._perm_stage = PermStage(self.device)
+        return st
+
+    def grad_views(self):
+        """(parameters, their views into ``flat_g``) in parameter order -- built once: the autograd node hands these out as
+        ``p.grad`` after every backward."""
+        gv = getattr(self, "_grad_views", None)
+        if gv is None:
+            params = list(self.model.parameters())
+            views, off = [], 0
+            for p in params:
+                views.append(self.flat_g[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            gv = self._grad_views = (params, views)
+        return gv
+
     def backward_from(self, batch, dlogp: torch.Tensor):
         """Backward of the LAST training-mode ``forward`` of ``batch`` from an external
         gradient w.r.t. its three log-prob outputs (``dlogp`` [3, B, C]); fills ``flat_g``."""
@@ -403,6 +423,31 @@ class StepEngine:
         assert dlogp.shape == (3, B, self.C) and dlogp.dtype == torch.float32 and dlogp.is_cuda
         _lib.call("cal_engine_backward_from", self._h, _p(x.contiguous()), _p(batch.batch.contiguous()), _p(dlogp),
                   N, E, B, _stream())
+
+
+class PermStage:
+    """Pinned ring for the per-step intervention permutation (a pageable H2D copy would block the host on the GPU)."""
+
+    def __init__(self, device, n=1024, slots=8):
+        self.device = device
+        self.host = [torch.empty(n, dtype=torch.long).pin_memory() for _ in range(slots)]
+        self.dev = [torch.empty(n, dtype=torch.long, device=device) for _ in range(slots)]
+        self.ev = [None] * slots
+        self.i = 0
+
+    def put(self, perm):
+        n = perm.numel()
+        if n > self.host[0].numel():
+            return perm.to(self.device)
+        k, self.i = self.i, (self.i + 1) % len(self.host)
+        if self.ev[k] is not None:
+            self.ev[k].synchronize()
+        self.host[k][:n].copy_(perm)
+        d = self.dev[k][:n]
+        d.copy_(self.host[k][:n], non_blocking=True)
+        self.ev[k] = torch.cuda.Event()
+        self.ev[k].record()
+        return d
 
 
 class _EngineAutograd(torch.autograd.Function):
@@ -425,15 +470,13 @@ class _EngineAutograd(torch.autograd.Function):
             raise RuntimeError("cal_amd engine: another forward ran before this backward "
                                "(the engine keeps one step's activations)")
         B, C = eng._last_B, eng.C
-        z = torch.zeros(B, C, dtype=torch.float32, device=eng.device)
-        g = torch.stack([t if t is not None else z for t in (gc, go, gco)]).to(torch.float32)
+        g = _as_one_block(gc, go, gco, B, C)
+        if g is None:
+            z = torch.zeros(B, C, dtype=torch.float32, device=eng.device)
+            g = torch.stack([t if t is not None else z for t in (gc, go, gco)]).to(torch.float32)
         # p.grad tensors that already alias the flat buffer hold the gradients of an earlier backward (accumulation)
         # or in-place zeros (zero_grad(set_to_none=False)): backward_from overwrites the buffer, so keep them and add
-        params = list(eng.model.parameters())
-        views, off = [], 0
-        for p in params:
-            views.append(eng.flat_g[off:off + p.numel()].view(p.shape))
-            off += p.numel()
+        params, views = eng.grad_views()
         alias = [p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, views)]
         old = eng.flat_g.clone() if any(alias) else None
         eng.backward_from(ctx.batch, g)
@@ -448,6 +491,71 @@ class _EngineAutograd(torch.autograd.Function):
                 p.grad.add_(view)
             off += p.numel()
         return None, None, None, None
+
+
+def _as_one_block(gc, go, gco, B, C):
+    """The three output gradients as ONE contiguous [3, B, C] tensor without a copy when they are the three slices of one
+    (what ``fused_causal_loss`` hands back); else ``None``."""
+    if gc is None or go is None or gco is None:
+        return None
+    base = gc._base
+    if base is None or go._base is not base or gco._base is not base or base.dtype != torch.float32 or not base.is_contiguous():
+        return None
+    if base.numel() != 3 * B * C or not (gc.is_contiguous() and go.is_contiguous() and gco.is_contiguous()):
+        return None
+    p0, n = base.data_ptr(), 4 * B * C
+    if (gc.data_ptr(), go.data_ptr(), gco.data_ptr()) != (p0, p0 + n, p0 + 2 * n):
+        return None
+    return base.view(3, B, C)
+
+
+class _FusedCausalLoss(torch.autograd.Function):
+    """``loss, c_loss, o_loss, co_loss`` of train_causal.py:176-183 from the three log-prob outputs as ONE launch
+    (``cal_causal_loss``), with the gradient w.r.t. the log-probs produced in the same launch: a statement-by-statement loop
+    (model(data) -> loss -> backward -> step) then spends one kernel and one autograd node on the loss instead of ~20."""
+
+    @staticmethod
+    def forward(ctx, c_logs, o_logs, co_logs, y, wc, wo, wco):
+        B, C = c_logs.shape                              # (the three are consecutive [B, C] blocks of one buffer: fused_causal_loss)
+        out = torch.empty(4, dtype=torch.float32, device=c_logs.device)
+        dl = torch.empty(3, B, C, dtype=torch.float32, device=c_logs.device)
+        _lib.call("cal_causal_loss", _p(c_logs), _p(y), B, C, float(wc), float(wo), float(wco), _p(out), _p(dl), None, _stream())
+        ctx.dl, ctx.w = dl, (float(wc), float(wo), float(wco))
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_c, g_o, g_co):
+        dl = ctx.dl                                    # = d loss / d (c, o, co), the weights folded in
+        if g_c is None and g_o is None and g_co is None:
+            if g_loss is None:
+                return None, None, None, None, None, None, None
+            g = dl * g_loss                            # one launch; its three slices go to the model's node as one block
+            return g[0], g[1], g[2], None, None, None, None
+        # the per-term outputs are used differentiably too: d term_k / d head_k = dl[k] / w_k
+        gs = []
+        for k, (gt, w) in enumerate(zip((g_c, g_o, g_co), ctx.w)):
+            if w == 0.0:
+                raise RuntimeError("fused_causal_loss: a loss term with weight 0 is differentiated on its own; compute the loss with torch")
+            coef = (g_loss * w if g_loss is not None else 0.0) + (gt if gt is not None else 0.0)
+            gs.append(dl[k] / w * coef)
+        return gs[0], gs[1], gs[2], None, None, None, None
+
+
+def fused_causal_loss(c_logs, o_logs, co_logs, y, num_classes, wc, wo, wco):
+    """The fused form of the reference's loss when ``(c, o, co)`` are the three [B, C] slices of one contiguous float32 CUDA
+    tensor (what an engine-backed model returns); ``None`` otherwise (the caller then uses torch)."""
+    if not (torch.is_tensor(c_logs) and c_logs.is_cuda and c_logs.dtype == torch.float32 and c_logs.dim() == 2):
+        return None
+    B, C = c_logs.shape
+    if C != num_classes or y.numel() != B or not y.is_cuda or y.dtype != torch.long:
+        return None
+    base = c_logs._base
+    if base is None or o_logs._base is not base or co_logs._base is not base or not base.is_contiguous() or base.numel() != 3 * B * C:
+        return None
+    p0, n = base.data_ptr(), 4 * B * C
+    if (c_logs.data_ptr(), o_logs.data_ptr(), co_logs.data_ptr()) != (p0, p0 + n, p0 + 2 * n):
+        return None
+    return _FusedCausalLoss.apply(c_logs, o_logs, co_logs, y.view(-1).contiguous(), wc, wo, wco)
 
 
 def engine_forward_autograd(eng: "StepEngine", batch, perm):

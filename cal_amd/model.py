@@ -105,7 +105,7 @@ class _CausalBase(torch.nn.Module):
             from .engine import engine_forward_autograd
             if perm is None:
                 perm = self.intervention_index(int(data.num_graphs), eval_random)
-            perm = perm.to(x.device)
+            perm = perm.to(x.device) if perm.is_cuda else eng.perm_stage().put(perm)      # (pinned ring: a pageable H2D copy blocks the host)
             if self.training and torch.is_grad_enabled():
                 return engine_forward_autograd(eng, data, perm)
             eng.forward(data, perm, training=self.training)

@@ -58,6 +58,7 @@ class Binding:
         self._lr = None
         self.pending = 0                    # engine-side Adam steps not yet written to the optimizer's `step` counters
         self.engine_step = 0.0              # what the engine's device step counter holds
+        self.grads_mixed = False            # a step has seen gradients outside the engine's flat buffer
         self._views = []
         off = 0
         for p in params:
@@ -115,11 +116,13 @@ class Binding:
 
     def resync(self):
         """Before a run of engine-side steps: the optimizer may have been stepped the plain way in between (its own
-        counters moved; the moments are shared memory) or had a state dict loaded (``rehome``)."""
+        counters moved; the moments are shared memory) or had a state dict loaded (``rehome``).  The optimizer's per-parameter
+        ``step`` counters are brought up to date lazily (``flush``: state_dict(), a plain step, a re-bind) -- forty CPU tensor
+        increments per step were a third of ``EngineAdam.step()``'s host time."""
         self.rehome()
-        self.flush()
-        s = float(self.opt.state[self.params[0]]["step"])
+        s = float(self.opt.state[self.params[0]]["step"]) + self.pending
         if s != self.engine_step:
+            self.flush()
             self.engine.step_count.fill_(s)
             self.engine_step = s
         self.sync_hparams()
@@ -131,9 +134,13 @@ class Binding:
                 self.opt.state[p]["step"] += self.pending
             self.pending = 0
 
-    def grads_in_flat(self) -> bool:
+    def grads_in_flat(self, full: bool = True) -> bool:
+        """Every ``p.grad`` is the parameter's view of the engine's flat gradient buffer.  ``full=False`` probes the first and the
+        last parameter only (the engine's autograd node installs all views together; zero_grad / a foreign backward replace
+        them together)."""
         base = self.engine.flat_g.data_ptr()
-        for p, (off, _) in zip(self.params, self._views):
+        probe = zip(self.params, self._views) if full else ((self.params[0], self._views[0]), (self.params[-1], self._views[-1]))
+        for p, (off, _) in probe:
             if p.grad is None or p.grad.data_ptr() != base + 4 * off:
                 return False
         return True
@@ -207,9 +214,10 @@ class EngineAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         b = self._binding()
-        if b is None or not b.grads_in_flat():
+        if b is None or not b.grads_in_flat(full=False) or (b.grads_mixed and not b.grads_in_flat()):
             if b is not None:
                 b.flush()
+                b.grads_mixed = True                # some gradients live outside the flat buffer: check all of them from now on
             super().step()
             return loss                             # (the next engine-side step resyncs the device counter)
         b.resync()

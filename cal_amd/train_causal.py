@@ -53,7 +53,14 @@ def num_graphs(data):
 
 
 def causal_loss(c_logs, o_logs, co_logs, y, num_classes, args):
-    """train_causal.py:176-183."""
+    """train_causal.py:176-183.  The three heads of an engine-backed model arrive as consecutive blocks of one buffer: the four
+    values and the gradient w.r.t. the heads then come from ONE launch and one autograd node (``engine.fused_causal_loss``)
+    instead of ~20 small torch launches; anything else takes the torch formulation below."""
+    if c_logs.is_cuda:
+        from .engine import fused_causal_loss
+        res = fused_causal_loss(c_logs, o_logs, co_logs, y, num_classes, args.c, args.o, args.co)
+        if res is not None:
+            return res
     one_hot_target = y.view(-1)
     uniform_target = torch.ones_like(c_logs, dtype=torch.float) / num_classes
     c_loss = F.kl_div(c_logs, uniform_target, reduction="batchmean")
@@ -77,31 +84,6 @@ def _loader(dataset, batch_size, shuffle, device):
     return DataLoader(dataset, batch_size, shuffle=shuffle)
 
 
-class _PermStage:
-    """Pinned ring for the per-step intervention permutation (a pageable H2D copy would block the host on the GPU)."""
-
-    def __init__(self, device, n=1024, slots=8):
-        self.device = device
-        self.host = [torch.empty(n, dtype=torch.long).pin_memory() for _ in range(slots)]
-        self.dev = [torch.empty(n, dtype=torch.long, device=device) for _ in range(slots)]
-        self.ev = [None] * slots
-        self.i = 0
-
-    def put(self, perm):
-        n = perm.numel()
-        if n > self.host[0].numel():
-            return perm.to(self.device)
-        k, self.i = self.i, (self.i + 1) % len(self.host)
-        if self.ev[k] is not None:
-            self.ev[k].synchronize()
-        self.host[k][:n].copy_(perm)
-        d = self.dev[k][:n]
-        d.copy_(self.host[k][:n], non_blocking=True)
-        self.ev[k] = torch.cuda.Event()
-        self.ev[k].record()
-        return d
-
-
 def _fused_epoch(model, binding, loader, device, args):
     """The loop of train_causal.py:171-192 with its body as one engine call per mini-batch (module docstring)."""
     eng = binding.engine
@@ -113,9 +95,7 @@ def _fused_epoch(model, binding, loader, device, args):
     if device_perm and getattr(eng, "_perm_counter", None) is None:
         import random
         eng.set_perm_rng(random.getrandbits(63), torch.zeros(1, dtype=torch.int64, device=device))
-    stage = getattr(eng, "_perm_stage", None)
-    if stage is None:
-        stage = eng._perm_stage = _PermStage(device)
+    stage = eng.perm_stage()
     try:
         for data in loader:
             data = data.to(device)
@@ -195,8 +175,7 @@ def eval_acc_causal(model, loader, device, args):
             perm = None                                                        # identity (model.py:147-152 with the gate off)
             if shuffles:
                 if stage is None:
-                    stage = getattr(eng, "_perm_stage", None) or _PermStage(device)
-                    eng._perm_stage = stage
+                    stage = eng.perm_stage()
                 perm = stage.put(model.intervention_index(num_graphs(data), eval_random))
             eng.forward(data, perm, training=False)
             hits.add_(eng.buffer("stats", 8)[4:7])

@@ -129,6 +129,12 @@ CAL_API int cal_collate(const float* X, const int64_t* EI, int64_t sumE, int64_t
                         float* xo, int64_t* eio, int64_t Eout, int64_t* batcho, int64_t* yo, int64_t B,
                         void* stream);
 
+/* host-side batch assembly of a HOST-resident dataset (DataLoader / Batch collate, train_causal.py:13-15,171-174): X [Ntot, F],
+ * EI [2, Etot] (edge ids local to their graph), node_ptr / edge_ptr [G + 1], Y [G]; graphs idx [B] -> xo [N, F], eio [2, Eout]
+ * (rebased by the batch's node offsets), batcho [N], yo [B] in caller-owned staging memory.  Host pointers, no device work. */
+CAL_API int cal_collate_host(const float* X, const int64_t* EI, int64_t Etot, int64_t F, const int64_t* node_ptr,
+                             const int64_t* edge_ptr, const int64_t* Y, const int64_t* idx, int64_t B, float* xo,
+                             int64_t* eio, int64_t Eout, int64_t* batcho, int64_t* yo);
 /* host-side helper of the small-graph packing (cal_engine_set_tiles): first-fit-decreasing order of the B graphs of a
  * mini-batch under the tile bounds; order_out [B] positions, first_out [T + 1] first emitted graph of every tile; returns T
  * (-1: a graph exceeds a bound).  Host pointers, no device work. */
@@ -215,6 +221,11 @@ CAL_API int cal_engine_p2p_bind(void* engine, void* const* peer_bases, const int
 CAL_API int cal_engine_p2p_set_timeout(void* engine, int64_t max_polls);
 CAL_API int64_t cal_engine_p2p_status(void* engine);
 CAL_API int cal_engine_p2p_adam(void* engine, void* stream);
+/* the 3-term loss of train_causal.py:176-183 on log-probabilities logp [3,B,C] (heads c, o, co) and labels y [B]:
+ * out [4] = {loss, c_loss, o_loss, co_loss}; dlogp [3,B,C] (or null) = d loss / d logp, the input of cal_engine_backward_from.
+ * flag (or null): bit 1 set when a label is outside [0, C).  One launch. */
+CAL_API int cal_causal_loss(const float* logp, const int64_t* y, int64_t B, int64_t C, float wc, float wo, float wco, float* out,
+                            float* dlogp, int32_t* flag, void* stream);
 /* backward from an external d loss / d log-probs [3,B,C] of the last training-mode forward (autograd surface) */
 CAL_API int cal_engine_backward_from(void* engine, const float* x0, const int64_t* batch,
                                      const float* dlogp, int64_t N, int64_t E, int64_t B, void* stream);
