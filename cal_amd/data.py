@@ -223,22 +223,18 @@ class Batch(Data):
 
 
 class _StageSlot:
-    """One pinned (float, int64) buffer pair of the host loader's ring.  It may be handed to a new batch only when the batch
-    that last used it is gone or has been moved to the device AND that copy has run (event)."""
+    """One pinned (float, int64) buffer pair of the host loader's ring.  It is handed to a new batch only when the batch that
+    last used it is gone or has been moved to the device; the ring is walked round-robin, so the copy that last read a slot
+    was enqueued several batches ago and its event is waited for, not polled (hipEventQuery cost ~0.2 ms per call here)."""
 
     def __init__(self):
         self.fbuf = self.ibuf = None
         self.owner = None           # weakref to the Batch whose CPU tensors view the buffers
         self.event = None
 
-    def free(self) -> bool:
-        if self.owner is not None and self.owner() is not None and getattr(self.owner(), "_staged", None) is not None:
-            return False            # a live CPU batch still views the buffers
-        if self.event is not None:
-            if not self.event.query():
-                return False
-            self.event = None
-        return True
+    def held(self) -> bool:
+        o = self.owner() if self.owner is not None else None
+        return o is not None and getattr(o, "_staged", None) is not None        # a live CPU batch still views the buffers
 
     def moved(self, device):
         self.event = torch.cuda.Event()
@@ -280,17 +276,29 @@ class _HostConcat:
         self.no_self_loops = bool(self.EI.shape[1] == 0 or (self.EI[0] != self.EI[1]).all())
         self.pin = torch.cuda.is_available()
         self.ring = [_StageSlot() for _ in range(8)] if self.pin else []
+        self.ring_i = 0
         self.ok = True
 
     def _buffers(self, nf, ni):
-        for slot in self.ring:
-            if slot.free():
-                if slot.fbuf is None or slot.fbuf.numel() < nf:
-                    slot.fbuf = torch.empty(max(nf, 1 << 16), dtype=torch.float32).pin_memory()
-                if slot.ibuf is None or slot.ibuf.numel() < ni:
-                    slot.ibuf = torch.empty(max(ni, 1 << 16), dtype=torch.long).pin_memory()
-                return slot.fbuf[:nf], slot.ibuf[:ni], slot
-        return torch.empty(nf, dtype=torch.float32), torch.empty(ni, dtype=torch.long), None      # every slot busy: pageable
+        def cap(n):                 # pinned allocations cost ~1.5 ms each: a quarter of headroom, rounded up to a power of two
+            c = 1 << 16
+            while c < n + n // 4:
+                c <<= 1
+            return c
+        for _ in range(len(self.ring)):
+            slot = self.ring[self.ring_i]
+            self.ring_i = (self.ring_i + 1) % len(self.ring)
+            if slot.held():
+                continue
+            if slot.event is not None:
+                slot.event.synchronize()
+                slot.event = None
+            if slot.fbuf is None or slot.fbuf.numel() < nf:
+                slot.fbuf = torch.empty(cap(nf), dtype=torch.float32).pin_memory()
+            if slot.ibuf is None or slot.ibuf.numel() < ni:
+                slot.ibuf = torch.empty(cap(ni), dtype=torch.long).pin_memory()
+            return slot.fbuf[:nf], slot.ibuf[:ni], slot
+        return torch.empty(nf, dtype=torch.float32), torch.empty(ni, dtype=torch.long), None      # every slot held by a live batch: pageable
 
     def collate(self, idx) -> "Batch":
         import numpy as np
@@ -364,6 +372,23 @@ def shard_indices(n: int, shuffle: bool, rank: int, world_size: int, drop_last: 
     return idx
 
 
+_CONCATS = []        # [(dataset list, fingerprint, _HostConcat)]: the last few static datasets a DataLoader was built over
+
+
+def _concat_of(dataset):
+    """One ``_HostConcat`` per dataset list, kept across DataLoader objects (loops that build a new loader every epoch over the
+    same list would pay the concatenation -- ~30 ms for 5 000 graphs -- sixteen steps apart)."""
+    n = len(dataset)
+    fp = (n, id(dataset[0]) if n else 0, id(dataset[n // 2]) if n else 0, id(dataset[-1]) if n else 0)
+    for ds, f, hc in _CONCATS:
+        if ds is dataset and f == fp:
+            return hc
+    hc = _HostConcat(dataset)
+    _CONCATS.append((dataset, fp, hc))
+    del _CONCATS[:-4]
+    return hc
+
+
 class DataLoader:
     """``DataLoader(dataset, batch_size, shuffle)`` (train_causal.py:13-15).
 
@@ -393,7 +418,7 @@ class DataLoader:
 
     def _collate(self, chunk) -> Batch:
         if self._concat is None and isinstance(self.dataset, (list, tuple)):
-            self._concat = _HostConcat(self.dataset)
+            self._concat = _concat_of(self.dataset)
         if self._concat is not None and self._concat.ok:
             return self._concat.collate(chunk)
         return Batch.from_data_list([self.dataset[i] for i in chunk])

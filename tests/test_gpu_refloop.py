@@ -167,6 +167,51 @@ def test_optimizer_restore_after_the_bind_reaches_the_fused_step():
     assert not torch.equal(outs["straight"], outs["zeroed"])
 
 
+def test_fused_causal_loss_equals_the_torch_formulation():
+    """``causal_loss`` on the three heads of an engine-backed model is ONE launch and one autograd node (cal_causal_loss): its
+    four values and the parameter gradients behind ``loss.backward()`` equal the torch formulation of train_causal.py:176-183
+    (F.kl_div batchmean + two F.nll_loss) applied to the same heads -- also when the loss is scaled before backward and
+    when a single term is differentiated on its own."""
+    import torch.nn.functional as F
+    from cal_amd.data import Batch
+    from cal_amd.train_causal import causal_loss
+    gs = _graphs(24, seed=3)
+    bd = Batch.from_data_list(gs).to(DEV)
+    args = _args(layers=2, hidden=64)
+    torch.manual_seed(4)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=2)
+    perm = torch.randperm(24)
+
+    def torch_loss(c, o, co, y):
+        u = torch.ones_like(c) / 4
+        lc, lo, lco = F.kl_div(c, u, reduction="batchmean"), F.nll_loss(o, y), F.nll_loss(co, y)
+        return args.c * lc + args.o * lo + args.co * lco, lc, lo, lco
+
+    res = {}
+    for kind in ("fused", "torch", "fused_scaled", "torch_scaled", "fused_term", "torch_term"):
+        m = _model("CausalGCN", {k: v.clone() for k, v in sd.items()}, args)
+        m.train()
+        c, o, co = m(bd, eval_random=True, perm=perm)
+        if kind.startswith("fused"):
+            out = causal_loss(c, o, co, bd.y, 4, args)
+            assert type(out[0].grad_fn).__name__.startswith("_FusedCausalLoss"), type(out[0].grad_fn).__name__
+        else:
+            out = torch_loss(c, o, co, bd.y.view(-1))
+        if kind.endswith("scaled"):
+            (out[0] * 0.25).backward()
+        elif kind.endswith("term"):
+            (out[0] + 0.3 * out[2]).backward()
+        else:
+            out[0].backward()
+        res[kind] = ([float(t.detach()) for t in out], {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None})
+    for a, b in (("fused", "torch"), ("fused_scaled", "torch_scaled"), ("fused_term", "torch_term")):
+        assert np.allclose(res[a][0], res[b][0], atol=1e-6, rtol=1e-6), (a, res[a][0], res[b][0])
+        assert res[a][1].keys() == res[b][1].keys()
+        for k in res[a][1]:
+            ga, gb = res[a][1][k], res[b][1][k]
+            assert torch.allclose(ga, gb, atol=1e-6 + 1e-5 * float(gb.abs().max()), rtol=1e-4), (a, k)
+
+
 def test_lr_scheduler_reaches_the_fused_step():
     """CosineAnnealingLR rewrites param_groups[0]['lr'] (train_causal.py:22,29); the next fused epoch must use it: two
     models, one stepped with lr = 0 after the schedule, stay / move accordingly."""
