@@ -36,14 +36,13 @@ void set_error(const char* fmt, ...) {
 
 inline float lrelu(float v, float slope) { return v > 0.f ? v : slope * v; }
 
-// counter-based attention-dropout keep decision: bit-identical to cal_amd/csrc/gat_common.hpp
+// counter-based attention-dropout keep decision: bit-identical to cal_amd/csrc/gat_common.hpp (32-bit finaliser, round 4)
 inline uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x21F0AAADu;
     x ^= x >> 15; x *= 0x735A2D97u;
     x ^= x >> 15;
     return x;
 }
-// counter-based attention-dropout decision: the same function as the device's (cal_amd/csrc/gat_common.hpp)
 inline float keep_scale(uint64_t seed, int64_t id, int k, int K, float p, float inv_keep) {
     if (p <= 0.f) return 1.f;
     const uint32_t key = (uint32_t)(id * K + k);
