@@ -114,9 +114,13 @@ class Data:
         return [k for k, v in self.__dict__.items() if torch.is_tensor(v)]
 
     def to(self, device, non_blocking: bool = False):
-        for k in self._tensor_keys():
-            setattr(self, k, getattr(self, k).to(device, non_blocking=non_blocking))
-        if getattr(self, "_plan", None) is not None and self._plan.device != torch.device(device):
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        for k, v in self.__dict__.items():
+            if torch.is_tensor(v) and v.device != dev:         # (a device-resident loader's batch: nothing to move)
+                self.__dict__[k] = v.to(dev, non_blocking=non_blocking)
+        if getattr(self, "_plan", None) is not None and self._plan.device != dev:
             self._plan = None
         return self
 
