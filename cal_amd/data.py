@@ -237,8 +237,18 @@ class _StageSlot:
         self.event = None
 
     def held(self) -> bool:
+        """Some tensor still views the staging memory: the batch itself, or a CPU view a caller took from it before moving the
+        batch to the device (storage use counts; the owner weak reference alone when torch does not expose them)."""
         o = self.owner() if self.owner is not None else None
-        return o is not None and getattr(o, "_staged", None) is not None        # a live CPU batch still views the buffers
+        if o is not None and getattr(o, "_staged", None) is not None:
+            return True
+        try:
+            for buf in (self.fbuf, self.ibuf):
+                if buf is not None and torch._C._storage_Use_Count(buf.untyped_storage()._cdata) > 2:   # (2 = this tensor + the query)
+                    return True
+        except Exception:
+            pass
+        return False
 
     def moved(self, device):
         self.event = torch.cuda.Event()

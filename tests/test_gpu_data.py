@@ -76,3 +76,28 @@ def test_device_collate_back_to_back_without_syncs():
         ref = Batch.from_data_list([gs[i] for i in idx])
         assert torch.equal(out.edge_index.cpu(), ref.edge_index) and torch.equal(out.feat.cpu(), ref.feat)
         assert torch.equal(out.batch.cpu(), ref.batch) and torch.equal(out.y.cpu(), ref.y)
+
+
+def test_host_loader_pinned_ring_on_the_gpu_box():
+    """The host DataLoader's staging ring (pinned, two H2D copies per batch): batches moved to the GPU equal
+    ``Batch.from_data_list`` moved attribute by attribute, over more batches than the ring has slots; a CPU view a caller took
+    before ``to()`` keeps its slot out of the ring."""
+    import torch
+    from cal_amd import spmotif
+    from cal_amd.data import Batch, DataLoader
+    gs = spmotif.train_mix(200, bias=0.9, node_num=7, seed=5)
+    dl = DataLoader(gs, 8, shuffle=False)
+    it = iter(dl)
+    first = next(it)
+    assert first._staged is not None and first._staged[3] is not None and first.edge_index.is_pinned()
+    keep_ei, keep_y = first.edge_index, first.y
+    want_ei, want_y = keep_ei.clone(), keep_y.clone()
+    first = first.to("cuda")
+    assert first._staged is None and first.edge_index.is_cuda
+    for k, b in enumerate(it, start=1):
+        ref = Batch.from_data_list(gs[8 * k:8 * k + 8])
+        b = b.to("cuda")
+        for name in ("feat", "edge_index", "batch", "y", "ptr", "edge_ptr"):
+            assert torch.equal(getattr(b, name).cpu(), getattr(ref, name)), (k, name)
+    assert k == 24
+    assert torch.equal(keep_ei, want_ei) and torch.equal(keep_y, want_y)
