@@ -429,7 +429,7 @@ def reference_loop(wl, margs, gs, steps=60):
         else:
             loader = DataLoader(gs, wl["batch"], shuffle=True)
         per_epoch = len(loader)
-        n_epochs = max(1, -(-steps // per_epoch)) if kind != "module_surface" else max(1, steps // (2 * per_epoch))
+        n_epochs = max(1, -(-steps // per_epoch))
         if kind == "module_surface":
             def epoch():
                 model.train()
