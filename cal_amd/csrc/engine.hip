@@ -223,6 +223,9 @@ int gat_datt_parts(int64_t N);
 int plan_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
                int32_t* rowptr_src, int32_t* nbr_src, int32_t* eid_src, int32_t* row32, int32_t* col32, int32_t* work,
                int32_t* status, bool prezeroed, hipStream_t stream);
+int plan_rank(int64_t E, int64_t N, const int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst, const int32_t* rowptr_src,
+              int32_t* nbr_src, int32_t* eid_src, const int32_t* row32, const int32_t* col32, const int32_t* scratch,
+              hipStream_t stream);
 }
 
 extern "C" int64_t cal_gat_bwd_ws(int64_t N, int64_t E, int64_t K, int64_t D);
@@ -802,10 +805,12 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     // per-graph plan (engine_plan.hpp) when the host vouches for the batch layout
     const bool fast_plan = e->node_ptr && e->edge_ptr && B > 0 && e->max_nodes > 0 && e->max_nodes <= GP_T2 && e->max_edges <= GP_E2;
     const bool wide_plan = fast_plan && (e->max_nodes > GP_T || e->max_edges > GP_E);
-    const bool plan_stats = fast_plan && c.training && F <= 64;      // bn_feat's statistics ride in k_plan_graph
+    // ... and for graphs of up to 8192 nodes (config 5): one 1024-thread workgroup per graph, rows ranked from a global scratch
+    const bool big_plan = !fast_plan && e->node_ptr && e->edge_ptr && B > 0 && e->ntiles == 0 && e->max_nodes > 0 && e->max_nodes <= GPB_T;
+    const bool plan_stats = (fast_plan || big_plan) && c.training && F <= 64;      // bn_feat's statistics ride in the plan kernel
     // 0. zero the fp64 arena and the GraphPlan counters (one kernel, not memset nodes)
     {
-        const int64_t ni = fast_plan ? 0 : 4 * ((int64_t)N + 1);
+        const int64_t ni = (fast_plan || big_plan) ? 0 : 4 * ((int64_t)N + 1);
         hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256) + (c.draw_perm ? cdiv(B, ZP_EPB) : 0)), dim3(256), 0, st,
                            e->arena, (int64_t)e->arena_n, e->work, ni, e->status, (e->K > 0 && c.training) ? e->gat_ctr : nullptr,
                            c.draw_perm ? e->perm_dev : nullptr, B, e->perm_seed, e->perm_ctr, c.adam_in_finish ? e->step : nullptr);
@@ -818,6 +823,13 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
                            e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src, e->row32, e->col32,
                            e->gptr, e->eptr, e->dis_unit, e->status, plan_stats ? x0 : nullptr, F, bn_stsum(c, 0), bn_stsq(c, 0));
         CAL_CHECK_LAUNCH("k_plan_graph"); STAGE();
+    } else if (big_plan) {
+        int* scratch = e->work + 4 * ((size_t)e->capN + 1);
+        hipLaunchKernelGGL(k_plan_big, dim3(B, 2), dim3(1024), 0, st, edge_index, E, N, B, e->node_ptr, e->edge_ptr, batch, e->loop_w,
+                           e->rowptr_dst, e->rowptr_src, e->row32, e->col32, e->gptr, e->eptr, e->dis_unit, e->status, scratch,
+                           plan_stats ? x0 : nullptr, F, bn_stsum(c, 0), bn_stsq(c, 0));
+        CAL_CHECK_LAUNCH("k_plan_big"); STAGE();
+        RC(plan_rank(E, N, e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src, e->row32, e->col32, scratch, st)); STAGE();
     } else {
         RC(plan_build(edge_index, E, N, e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src,
                       e->row32, e->col32, e->work, e->status, true, st)); STAGE();

@@ -177,6 +177,149 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same per-graph GraphPlan for LARGE graphs (round 4; BASELINE config 5: 32 BA graphs of 5000 nodes / 20 000 edges per GPU),
+// where the LDS copies of k_plan_graph (six node arrays, six edge arrays) do not fit: one 1024-thread workgroup per (graph, CSR view)
+// keeps only its degree / cursor array in LDS (8192 ints), re-reads the endpoints it wrote to row32 / col32 and parks the
+// unordered rows in the global scratch of plan.hip's k_plan_rank, which then moves every slot to its rank by edge id inside its
+// row with 2 E threads.  Ranking inside this kernel was tried three ways and lost on the 32 CUs it occupies at config 5 (per
+// view: one lane per slot with the row looked up in col32 26 us; rows held in LDS as 16-bit ids and ordered in place by a lane
+// per row / a wave per hub row 17 + 93 us; by a lane per slot with a bisection of the row ends ~50 us) against 29 us for the
+// separate launch over all CUs.
+// Together they replace plan.hip's count -> scan -> fill (global atomics on 2 x 640 k counters: 62 + 10 + 105 us at config 5) +
+// k_gptr_dis.  Same outputs, same slot order, same status bits as k_plan_graph.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int GPB_T = 8192;               // nodes per graph
+__device__ __forceinline__ void plan_block_scan(int* __restrict__ a, int n, int* wave_tot) {
+    // exclusive scan of a[0..n) in place, a[n] = total; 1024 threads x 8 consecutive elements (n <= 8192), three barriers
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6, i0 = t * 8;
+    int v[8], tsum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = i0 + j < n ? a[i0 + j] : 0; tsum += v[j]; }
+    int x = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) wave_tot[wid] = x;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) { const int wt = wave_tot[w]; woff += w < wid ? wt : 0; tot += wt; }
+    int run = woff + x - tsum;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { if (i0 + j < n) a[i0 + j] = run; run += v[j]; }
+    if (t == 0) a[n] = tot;
+    __syncthreads();
+}
+__global__ void __launch_bounds__(1024) k_plan_big(const int64_t* __restrict__ ei, int64_t E, int N, int B,
+                                                   const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr,
+                                                   const int64_t* __restrict__ batch, float loop_w,
+                                                   int* __restrict__ ptr_dst, int* __restrict__ ptr_src,
+                                                   int* __restrict__ row32, int* __restrict__ col32, int* __restrict__ gptr,
+                                                   int* __restrict__ eptr, float* __restrict__ dis_unit, int* __restrict__ status,
+                                                   int* __restrict__ tmp, const float* __restrict__ x0, int F,
+                                                   double* __restrict__ st_sum, double* __restrict__ st_sq) {
+    // grid (graphs, 2 views): workgroup (b, 0) builds the by-destination rows of graph b (and row32 / col32, gptr / eptr, the
+    // checks), workgroup (b, 1) the by-source rows (and deg^-1/2, bn_feat's statistics); each reads the graph's edges itself
+    __shared__ int cnt[GPB_T + 1];                       // degree -> offsets -> cursors of this view
+    __shared__ int wave_tot[16];
+    __shared__ double part[2][1024];                     // per-lane partial column sums of the raw features
+    const int b = blockIdx.x, view = blockIdx.y, t = threadIdx.x;
+    const int g0 = (int)node_ptr[b], rows = (int)node_ptr[b + 1] - g0;
+    const int64_t e0 = edge_ptr[b];
+    const int m = (int)(edge_ptr[b + 1] - e0);
+    if (t == 0 && view == 0) {
+        gptr[b] = g0; eptr[b] = (int)e0;
+        if (b == B - 1) { gptr[B] = g0 + rows; eptr[B] = (int)(e0 + m); ptr_dst[N] = (int)(e0 + m); ptr_src[N] = (int)(e0 + m); }
+        if (b == B - 1 && (g0 + rows != N || e0 + m != E)) atomicOr(status, 2);
+        if (b == 0 && (g0 != 0 || e0 != 0)) atomicOr(status, 2);
+    }
+    if (rows < 0 || rows > GPB_T || m < 0) { if (t == 0) atomicOr(status, 8); return; }
+    int* tn = tmp + (view == 0 ? 0 : 2 * E);             // scratch of k_plan_rank: {tn_d, te_d, tn_s, te_s}
+    int* te = tn + E;
+    int* ptr_o = view == 0 ? ptr_dst : ptr_src;
+    for (int v = t; v <= rows; v += 1024) cnt[v] = 0;
+    if (view == 0) for (int v = t; v < rows; v += 1024) if (batch[g0 + v] != (int64_t)b) atomicOr(status, 2);
+    __syncthreads();
+    // degrees of this view (LDS atomics); view 0 also leaves the 32-bit endpoints
+    for (int s0 = t; s0 < m; s0 += 8 * 1024) {
+        int64_t rv[8], cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int64_t e = e0 + min(s0 + u * 1024, m - 1); rv[u] = ei[e]; cv[u] = ei[E + e]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int s = s0 + u * 1024;
+            if (s < m) {
+                int r = (int)(rv[u] - g0), c = (int)(cv[u] - g0);
+                const bool bad = r < 0 || r >= rows || c < 0 || c >= rows;
+                if (bad) { atomicOr(status, 1); r = 0; c = 0; }
+                if (r == c) atomicOr(status, bad ? 1 : 32);
+                if (view == 0) { row32[e0 + s] = g0 + r; col32[e0 + s] = g0 + c; }
+                atomicAdd(&cnt[view == 0 ? c : r], 1);
+            }
+        }
+    }
+    if (x0 && view == 1) {
+        // bn_feat's batch statistics (model.py:90; F <= 64): a lane's column is fixed (lanes a multiple of F), fp32 inside a
+        // round of eight, fp64 across rounds; the lanes park their pair in LDS and lane f < F adds the lanes of column f in
+        // order (fp64 LDS atomics from 1020 lanes onto 2 F addresses are ~100 serialised updates per address)
+        const int lanes = (1024 / F) * F, tot = rows * F;
+        double s1 = 0.0, s2 = 0.0;
+        if (t < lanes) {
+            for (int i0 = t; i0 < tot; i0 += 8 * lanes) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = x0[(size_t)g0 * F + min(i0 + u * lanes, tot - 1)];
+                float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const float vv = i0 + u * lanes < tot ? v[u] : 0.f; p1 += vv; p2 = fmaf(vv, vv, p2); }
+                s1 += (double)p1; s2 += (double)p2;
+            }
+        }
+        part[0][t] = s1; part[1][t] = s2;
+    }
+    __syncthreads();
+    if (x0 && view == 1 && t < 2 * F) {
+        const int f = t % F, which = t / F, lanes = (1024 / F) * F;
+        double tot = 0.0;
+        for (int k0 = f; k0 < lanes; k0 += 8 * F) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k0 + u * F < lanes ? part[which][k0 + u * F] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tot += v[u];
+        }
+        atomicAdd((which ? st_sq : st_sum) + f, tot);
+    }
+    if (view == 1)
+        for (int v = t; v < rows; v += 1024) {
+            const float d = (float)cnt[v] + loop_w;
+            dis_unit[g0 + v] = d == 0.f ? 0.f : 1.0f / sqrtf(d);
+        }
+    __syncthreads();
+    plan_block_scan(cnt, rows, wave_tot);
+    for (int v = t; v < rows; v += 1024) ptr_o[g0 + v] = (int)e0 + cnt[v];
+    __syncthreads();
+    // scatter into the rows (arbitrary order inside a row): the offsets become cursors; the unordered rows go to plan.hip's scratch
+    // and k_plan_rank (2 E threads) moves every slot to its rank by edge id inside its row
+    for (int s0 = t; s0 < m; s0 += 8 * 1024) {
+        int64_t rv[8], cv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int64_t e = e0 + min(s0 + u * 1024, m - 1); rv[u] = ei[e]; cv[u] = ei[E + e]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int sl = s0 + u * 1024;
+            if (sl < m) {
+                int r = (int)(rv[u] - g0), c = (int)(cv[u] - g0);
+                if (r < 0 || r >= rows || c < 0 || c >= rows) { r = 0; c = 0; }
+                const int p = atomicAdd(&cnt[view == 0 ? c : r], 1);
+                tn[e0 + p] = g0 + (view == 0 ? r : c); te[e0 + p] = (int)(e0 + sl);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Node attention + edge attention + weighted degrees of one graph in one kernel (k_node_att_fwd's fast path followed
 // by k_edge_att_deg, model.py:97-111, gcn_conv.py:63-68): an edge's two endpoints are in the same graph, so the edge
 // softmax reads the projections P[row] / Q[col] from LDS right after they are computed.

@@ -256,6 +256,19 @@ int plan_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* rowptr_
 }
 }  // namespace cal
 
+namespace cal {
+// the rank pass alone, behind a per-graph fill (engine_plan.hpp k_plan_big): scratch = 4 E ints {tn_d, te_d, tn_s, te_s}
+int plan_rank(int64_t E, int64_t N, const int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst, const int32_t* rowptr_src,
+              int32_t* nbr_src, int32_t* eid_src, const int32_t* row32, const int32_t* col32, const int32_t* scratch,
+              hipStream_t stream) {
+    if (E <= 0) return 0;
+    hipLaunchKernelGGL(k_plan_rank, dim3(cdiv(2 * E, 256)), dim3(256), 0, stream, row32, col32, rowptr_dst, scratch, scratch + E,
+                       nbr_dst, eid_dst, rowptr_src, scratch + 2 * E, scratch + 3 * E, nbr_src, eid_src, (int)N);
+    CAL_CHECK_LAUNCH("k_plan_rank");
+    return 0;
+}
+}  // namespace cal
+
 CAL_EXPORT int cal_plan_build(const int64_t* edge_index, int64_t E, int64_t N,
                               int32_t* rowptr_dst, int32_t* nbr_dst, int32_t* eid_dst,
                               int32_t* rowptr_src, int32_t* nbr_src, int32_t* eid_src,

@@ -415,3 +415,40 @@ def test_config5_full_per_gpu_batch_step_properties():
     m.load_state_dict(sd)                                           # running statistics back to their initial values
     stats2 = eng.train_step(bd, perm, adam=True).clone()
     assert torch.equal(stats1, stats2)
+
+
+def test_large_graph_plan_equals_the_generic_plan():
+    """k_plan_big (one workgroup per graph of up to 8192 nodes: BASELINE config 5's 5000-node graphs) against plan.hip's generic
+    count / scan / fill / rank on the same batch: both CSR views slot for slot (edge-id order inside a row), graph / edge
+    offsets, unit deg^-1/2, and the step that follows (bn_feat statistics ride in the plan kernel)."""
+    from cal_amd import model as M, synth
+    from cal_amd.data import Batch
+    from cal_amd.engine import StepEngine
+    gs = synth.ba_graphs(1, n=1500, seed=1) + synth.ba_graphs(1, n=5000, seed=2) + synth.ba_graphs(1, n=300, seed=3) + \
+        synth.ba_graphs(1, n=8192, seed=4)
+    bd = Batch.from_data_list(gs).to(DEV)
+    N, E, B = bd.feat.size(0), bd.edge_index.size(1), 4
+    args = _args(hidden=64, layers=1)
+    torch.manual_seed(2)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=1)
+    perm = torch.randperm(B).to(DEV)
+    got = {}
+    for kind in ("big", "generic"):
+        m = M.CausalGCN(10, 4, args)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        eng = StepEngine(m)
+        eng.fused = kind == "big"                      # (False: the batch layout is not handed to the engine -> generic plan)
+        stats = eng.train_step(bd, perm, adam=False).cpu().clone()
+        eng.check_status()
+        plan = {k: eng.buffer(k, n, torch.int32).cpu().clone() for k, n in
+                (("rowptr_dst", N + 1), ("nbr_dst", E), ("eid_dst", E), ("rowptr_src", N + 1), ("nbr_src", E), ("eid_src", E),
+                 ("gptr", B + 1), ("eptr", B + 1))}
+        plan["dis_unit"] = eng.buffer("dis_unit", N).cpu().clone()
+        got[kind] = (plan, stats, eng.buffer("logp", 3 * B * 4).cpu().clone())
+    for k in got["big"][0]:
+        assert torch.equal(got["big"][0][k], got["generic"][0][k]), k
+    deg = got["big"][0]["rowptr_dst"][1:] - got["big"][0]["rowptr_dst"][:-1]
+    assert int(deg.max()) > 64                          # hub rows are ranked too
+    assert torch.allclose(got["big"][1][:4], got["generic"][1][:4], atol=1e-5)
+    assert torch.allclose(got["big"][2], got["generic"][2], atol=1e-5)
