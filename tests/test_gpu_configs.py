@@ -424,10 +424,13 @@ def test_large_graph_plan_equals_the_generic_plan():
     from cal_amd import model as M, synth
     from cal_amd.data import Batch
     from cal_amd.engine import StepEngine
-    gs = synth.ba_graphs(1, n=1500, seed=1) + synth.ba_graphs(1, n=5000, seed=2) + synth.ba_graphs(1, n=300, seed=3) + \
-        synth.ba_graphs(1, n=8192, seed=4)
+    from cal_amd.data import Data
+    empty = Data(feat=torch.zeros(0, 10), edge_index=torch.zeros(2, 0, dtype=torch.long), y=torch.tensor([1]))
+    lone = Data(feat=torch.eye(10)[:3].clone(), edge_index=torch.zeros(2, 0, dtype=torch.long), y=torch.tensor([0]))
+    gs = synth.ba_graphs(1, n=1500, seed=1) + [empty] + synth.ba_graphs(1, n=5000, seed=2) + [lone] + \
+        synth.ba_graphs(1, n=300, seed=3) + synth.ba_graphs(1, n=8192, seed=4)        # (a graph without nodes, one without edges)
     bd = Batch.from_data_list(gs).to(DEV)
-    N, E, B = bd.feat.size(0), bd.edge_index.size(1), 4
+    N, E, B = bd.feat.size(0), bd.edge_index.size(1), len(gs)
     args = _args(hidden=64, layers=1)
     torch.manual_seed(2)
     sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=1)
