@@ -58,32 +58,38 @@ class DeviceDataset:
                 idx = idx[po[0]]
                 n, e = self.node_sizes[idx], self.edge_sizes[idx]
                 first = po[1].tolist()
-        noff = np.concatenate([[0], np.cumsum(n)])
-        eoff = np.concatenate([[0], np.cumsum(e)])
-        N, E = int(noff[-1]), int(eoff[-1])
         # small-graph packing: tiles of consecutive graphs for the engine's per-graph kernels (data.pack_tiles)
         if first is None and self.no_self_loops:
             first = pack_tiles(n, e)
         T1 = len(first) if first is not None else 0
-        # one pinned staging buffer for [sel | node offsets | edge offsets | tile first graph | tile node off | tile edge off]
+        # one pinned staging buffer for [sel | node offsets | edge offsets | tile first graph | tile node off | tile edge off],
+        # filled through its numpy view (no intermediate arrays / tensors)
         need = 3 * B + 2 + 3 * T1
         if not self._pin or self._pin[0][0].numel() < need:
-            self._pin = [[torch.empty(max(need, 4096), dtype=torch.long).pin_memory(), None] for _ in range(16)]
+            self._pin = []
+            for _ in range(16):
+                t = torch.empty(max(need, 4096), dtype=torch.long).pin_memory()
+                self._pin.append([t, None, t.numpy()])
         slot = self._pin[self._pin_i]
         self._pin_i = (self._pin_i + 1) % len(self._pin)
         if slot[1] is not None:
             slot[1].synchronize()                     # the copy that last used this buffer has run
-        host = slot[0][:need]
-        host[:B] = torch.from_numpy(np.ascontiguousarray(idx))
-        host[B:2 * B + 1] = torch.from_numpy(noff)
-        host[2 * B + 1:3 * B + 2] = torch.from_numpy(eoff)
+        host, hv = slot[0][:need], slot[2]
+        hv[:B] = idx
+        hv[B] = 0
+        np.cumsum(n, out=hv[B + 1:2 * B + 1])
+        hv[2 * B + 1] = 0
+        np.cumsum(e, out=hv[2 * B + 2:3 * B + 2])
+        noff, eoff = hv[B:2 * B + 1], hv[2 * B + 1:3 * B + 2]
+        N, E = int(noff[-1]), int(eoff[-1])
+        tn = te = None
         if T1:
             fi = np.asarray(first, dtype=np.int64)
             tn, te = noff[fi], eoff[fi]
             o = 3 * B + 2
-            host[o:o + T1] = torch.from_numpy(fi)
-            host[o + T1:o + 2 * T1] = torch.from_numpy(tn)
-            host[o + 2 * T1:o + 3 * T1] = torch.from_numpy(te)
+            hv[o:o + T1] = fi
+            hv[o + T1:o + 2 * T1] = tn
+            hv[o + 2 * T1:o + 3 * T1] = te
         meta = host.to(self.device, non_blocking=True)
         slot[1] = torch.cuda.Event()
         slot[1].record()

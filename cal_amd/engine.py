@@ -434,15 +434,24 @@ class PermStage:
         self.dev = [torch.empty(n, dtype=torch.long, device=device) for _ in range(slots)]
         self.ev = [None] * slots
         self.i = 0
+        self.host_np = None
 
     def put(self, perm):
-        n = perm.numel()
+        """``perm``: a CPU int64 tensor, or the Python list ``random.shuffle`` produced (written straight into the pinned slot:
+        ``torch.tensor(list)`` + a tensor copy were 35 us of every step of the reference-shaped loop)."""
+        is_list = isinstance(perm, list)
+        n = len(perm) if is_list else perm.numel()
         if n > self.host[0].numel():
-            return perm.to(self.device)
+            return (torch.tensor(perm) if is_list else perm).to(self.device)
         k, self.i = self.i, (self.i + 1) % len(self.host)
         if self.ev[k] is not None:
             self.ev[k].synchronize()
-        self.host[k][:n].copy_(perm)
+        if is_list:
+            if self.host_np is None:
+                self.host_np = [h.numpy() for h in self.host]
+            self.host_np[k][:n] = perm
+        else:
+            self.host[k][:n].copy_(perm)
         d = self.dev[k][:n]
         d.copy_(self.host[k][:n], non_blocking=True)
         self.ev[k] = torch.cuda.Event()

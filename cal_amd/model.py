@@ -104,8 +104,9 @@ class _CausalBase(torch.nn.Module):
         if eng is not None:
             from .engine import engine_forward_autograd
             if perm is None:
-                perm = self.intervention_index(int(data.num_graphs), eval_random)
-            perm = perm.to(x.device) if perm.is_cuda else eng.perm_stage().put(perm)      # (pinned ring: a pageable H2D copy blocks the host)
+                perm = eng.perm_stage().put(self.intervention_list(int(data.num_graphs), eval_random))
+            else:
+                perm = perm.to(x.device) if perm.is_cuda else eng.perm_stage().put(perm)  # (pinned ring: a pageable H2D copy blocks the host)
             if self.training and torch.is_grad_enabled():
                 return engine_forward_autograd(eng, data, perm)
             eng.forward(data, perm, training=self.training)
@@ -152,14 +153,16 @@ class _CausalBase(torch.nn.Module):
         x = ops.linear(x, self.fc2_o.weight, self.fc2_o.bias)
         return F.log_softmax(x, dim=-1)
 
-    def intervention_index(self, num, eval_random):
-        """model.py:147-152: Python ``random.shuffle`` of range(num), gated as the
-        reference gates it."""
+    def intervention_list(self, num, eval_random):
+        """model.py:147-152: Python ``random.shuffle`` of range(num), gated as the reference gates it (the list itself)."""
         l = [i for i in range(num)]
         gate = eval_random and (self.with_random if self._gate_on_with_random else True)
         if gate:
             random.shuffle(l)
-        return torch.tensor(l)
+        return l
+
+    def intervention_index(self, num, eval_random):
+        return torch.tensor(self.intervention_list(num, eval_random))
 
     def random_readout_layer(self, xc, xo, eval_random, perm=None):
         num = xc.shape[0]

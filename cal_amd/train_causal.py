@@ -105,7 +105,7 @@ def _fused_epoch(model, binding, loader, device, args):
                 stats = eng.train_step(data, None, adam=True, draw_perm=True)
             else:
                 # model.py:147-152: Python's RNG on the host, exactly the reference's stream
-                perm = stage.put(model.intervention_index(n, args.with_random))
+                perm = stage.put(model.intervention_list(n, args.with_random))
                 stats = eng.train_step(data, perm, adam=True)
             binding.stepped()
             w = weights.get(n)
@@ -176,7 +176,7 @@ def eval_acc_causal(model, loader, device, args):
             if shuffles:
                 if stage is None:
                     stage = eng.perm_stage()
-                perm = stage.put(model.intervention_index(num_graphs(data), eval_random))
+                perm = stage.put(model.intervention_list(num_graphs(data), eval_random))
             eng.forward(data, perm, training=False)
             hits.add_(eng.buffer("stats", 8)[4:7])
         n = len(loader.dataset)
