@@ -17,7 +17,7 @@ for w in spmotif_b0.9_causalgcn_nodenum15_bs32 spmotif_b0.9_causalgat_h128_l3_bs
     python bench.py --workload $w --steps 100 --warmup 10 --batches 4 --no-e2e --cpu-seconds 8 > gpurun_out/$tag/bench_$w.json 2> gpurun_out/$tag/bench_$w.err
 done
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for w in ba5000_causalgat_h256_l3_bs32 ba5000_causalgcn_h256_l3_bs32 spmotif_b0.9_causalgcn_nodenum15_bs32 nci1like_causalgcn_h128_l3_bs512 spmotif_b0.9_causalgin_h128_l3_bs128 spmotif_b0.9_causalgat_h128_l3_bs128; do
+for w in ba5000_causalgat_h256_l3_bs32 ba5000_causalgcn_h256_l3_bs32 spmotif_b0.9_causalgcn_nodenum15_bs32 mutaglike_causalgat_h128_l3_bs64 nci1like_causalgcn_h128_l3_bs512 spmotif_b0.9_causalgin_h128_l3_bs128 spmotif_b0.9_causalgat_h128_l3_bs128; do
     rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag/$w -o b -- python bench.py --workload $w --steps 20 --warmup 3 --batches 2 --no-e2e --no-cpu-baseline --no-roofline --mode eager --repeats 1 > /tmp/prof_$w.log 2>&1
     cp $(find /tmp/prof_$tag/$w -name "*kernel_stats.csv" | head -1) gpurun_out/$tag/rocprof_kernel_stats_$w.csv
 done
