@@ -176,7 +176,7 @@ struct Engine {
     char* ws; size_t ws_bytes;
     int64_t capN, capE, capB;
     // float regions
-    float *h, *z, *zco, *hco, *anode, *pq, *att, *dis_unit, *dis_co, *pooled, *xco, *y1, *zl, *logp, *stats, *zpart;
+    float *h, *z, *zco, *hco, *anode, *pq, *att, *dis_unit, *dis_co, *pooled, *pcnt, *xco, *y1, *zl, *logp, *stats, *zpart;
     int adam_fused;          // 1: mode-4 steps apply Adam inside k_finish; CAL_AMD_ADAM_FUSED=0 keeps the k_adam launch
     int ro_rows;             // 1: ... also for 129 .. 512 graphs, in row blocks (k_ro_step<true>); CAL_AMD_RO_ROWS=0: the GEMM chain there
     int ro_step;             // 1: training steps run the readout as one launch (k_ro_step); CAL_AMD_RO_STEP=0 keeps the four kernels
@@ -342,7 +342,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     auto I32 = [&](int*& p, size_t n) { if (assign) p = (int*)(e->ws) + off; off += al(n); };
     F32(e->h, (L + 1) * N * H); F32(e->z, N * H); F32(e->zco, 2 * N * H); F32(e->hco, 2 * N * H);
     F32(e->anode, 2 * N); F32(e->pq, 4 * N); F32(e->att, 2 * E); F32(e->dis_unit, N); F32(e->dis_co, 2 * N);
-    F32(e->pooled, 2 * B * H); F32(e->xco, 2 * B * H); F32(e->y1, 3 * B * H); F32(e->zl, 3 * B * C); F32(e->logp, 3 * B * C);
+    F32(e->pooled, 2 * B * H); F32(e->pcnt, 2 * B * H); F32(e->xco, 2 * B * H); F32(e->y1, 3 * B * H); F32(e->zl, 3 * B * C); F32(e->logp, 3 * B * C);
     F32(e->stats, 8); F32(e->zpart, 3 * ((H + 15) / 16) * B * C);
     F32(e->dzl, 3 * B * C); F32(e->dyh1, 3 * B * H); F32(e->dy1, 3 * B * H); F32(e->dxh, 4 * B * H); F32(e->dpool, 2 * B * H);
     F32(e->dZco, 2 * N * H); F32(e->gn, 4 * E); F32(e->gself, 4 * N); F32(e->ddeg, 2 * N); F32(e->dl, E);
@@ -507,8 +507,11 @@ int flush_finals(Ctx& c) {
 int spmm_rpb(int H, bool stats, int N = 1 << 30) {
     // (small batches are latency-bound: a second row per group is a second chain of three dependent gathers, 14 vs 8 us
     //  at 7.5 k nodes -- one row per group there, the partial-row buffer holds N / 8 rows up to 16 k nodes)
+    // (big batches: every workgroup leaves one fp64 partial row per statistic -- at two rows per group a 160 k-node batch wrote
+    //  2 x 20 000 rows of 2 KB and k_stats_final spent 65 us walking them; rows per workgroup grow with N while the launch keeps
+    //  >= 4096 workgroups: 131 + 68 us -> 127 + 17 us per layer at config 5, 16 rows per group lose to the tail: 152 + 9)
     const int rows = 256 / group_for(H, 4);
-    return stats && N > 16384 ? 2 * rows : rows;
+    return stats && N > 16384 ? std::min(8, std::max(2, N / (rows * 4096))) * rows : rows;
 }
 Acc spmm_acc(Ctx& c, double* dst, int cols, int rpb) {
     const int P = cdiv(c.N, rpb);
@@ -671,9 +674,12 @@ int launch_espmm(hipStream_t st, const CSR& csr, const SpmmBranch2& bb, int nbra
     const dim3 grid(cdiv(N, rpb), nbranch);
     if (sd) {       // transposed weighted aggregation + SDDMM
         if (!wt || stt) { set_error("k_espmm: the fused SDDMM is built for the weighted branches without statistics"); return 2; }
+        const bool pb = bb.b[0].pb_g != nullptr;
+        if (pb != (bb.b[nbranch - 1].pb_g != nullptr)) { set_error("k_espmm: branches differ in kind"); return 2; }
         return with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            PROF_LAUNCH((k_espmm<4, G, true, false, true>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
+            if (pb) PROF_LAUNCH((k_espmm<4, G, true, false, true, true>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
+            else PROF_LAUNCH((k_espmm<4, G, true, false, true>), grid, dim3(256), 0, st, csr, bb, relu, loop_w, N, H, rpb);
             return 0;
         });
     }
@@ -790,6 +796,38 @@ int gin_rows(Ctx& c, int mode, const GinRowArgs& ga) {
         else if (mode == 1) hipLaunchKernelGGL((k_gin_rows<4, G, 1>), grid, dim3(256), 0, st, ga, N, H, c.rpb_n);
         else if (mode == 2) hipLaunchKernelGGL((k_gin_rows<4, G, 2>), grid, dim3(256), 0, st, ga, N, H, c.rpb_n);
         else hipLaunchKernelGGL((k_gin_rows<4, G, 3>), grid, dim3(256), 0, st, ga, N, H, c.rpb_n);
+        return 0;
+    });
+}
+
+// add-pool of the two causal branches (model.py:115-116) + the per-graph positive counts the node-level backward uses
+int launch_pool2(Ctx& c) {
+    Engine* e = c.e;
+    const int N = (int)c.N, B = (int)c.B, H = e->H;
+    const size_t NH = (size_t)N * H;
+    const int tc = std::min(256, pow2ceil(H / 4));
+    // few large graphs: split every graph's rows over S workgroups (slices parked in dZco, a backward-only buffer that the
+    // backward itself no longer writes; slices of >= 128 rows: at S = 4 the 256 workgroups of config 5 read its 328 MB at 3.3 TB/s)
+    const int S = std::max(1, std::min(32, N / std::max(1, B * 128)));
+    hipLaunchKernelGGL((k_pool2<4>), dim3(B, 2, S), dim3(256), 0, c.st, e->hco, e->hco + NH, e->gptr, e->pooled,
+                       e->pooled + (size_t)B * H, H, tc, e->dZco, e->pcnt);
+    CAL_CHECK_LAUNCH("k_pool2");
+    if (S > 1) {
+        hipLaunchKernelGGL(k_pool2_sum, dim3(cdiv(4 * (int64_t)B * H, 256)), dim3(256), 0, c.st, e->dZco, S, 2 * (int64_t)B * H, e->pooled, e->pcnt);
+        CAL_CHECK_LAUNCH("k_pool2_sum");
+    }
+    return 0;
+}
+// the counts alone (forward pooled per graph inside k_gconv_fwd, backward node-level)
+int launch_pool_cnt(Ctx& c) {
+    Engine* e = c.e;
+    const int N = (int)c.N, B = (int)c.B, H = e->H;
+    hipLaunchKernelGGL(k_zero_f32, dim3(cdiv(2 * (int64_t)B * H, 256)), dim3(256), 0, c.st, e->pcnt, 2 * (int64_t)B * H);
+    CAL_CHECK_LAUNCH("k_zero_f32");
+    return with_g(H, [&](auto g) {
+        constexpr int G = decltype(g)::value;
+        hipLaunchKernelGGL((k_pool_cnt<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, c.st, e->hco, e->hco + (size_t)N * H, c.batch, e->pcnt, N, B, H, c.rpb_n);
+        CAL_CHECK_LAUNCH("k_pool_cnt");
         return 0;
     });
 }
@@ -1070,16 +1108,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     }
     // 9. add-pool (model.py:115-116)
     if (!gc) {
-        int tc = std::min(256, pow2ceil(H / 4));
-        // few large graphs: split every graph's rows over S workgroups (slices parked in dZco, a backward-only buffer)
-        const int S = std::max(1, std::min(32, N / std::max(1, B * 1024)));
-        hipLaunchKernelGGL((k_pool2<4>), dim3(B, 2, S), dim3(256), 0, st, e->hco, e->hco + NH, e->gptr, e->pooled,
-                           e->pooled + (size_t)B * H, H, tc, e->dZco);
-        CAL_CHECK_LAUNCH("k_pool2");
-        if (S > 1) {
-            hipLaunchKernelGGL(k_pool2_sum, dim3(cdiv(2 * (int64_t)B * H, 256)), dim3(256), 0, st, e->dZco, S, 2 * (int64_t)B * H, e->pooled);
-            CAL_CHECK_LAUNCH("k_pool2_sum");
-        }
+        RC(launch_pool2(c));
         STAGE();
     }
     // 10. readouts (model.py:125-164)
@@ -1300,23 +1329,21 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     }
     const bool gcb = use_gcb(c);
     const bool agb = gcb && T <= 256;           // per-graph attention backward (two workgroups per graph: one wave of the chip)
-    // P1. add-pool backward + ReLU of the causal/trivial convs + their bias gradients
+    // P1. add-pool backward + ReLU of the causal/trivial convs: d(conv output)[v] = relu'(h_k[v]) * (gradient of the pooled row of v's
+    // graph) is never stored -- the transposed aggregation below (P5) builds it per gathered row from the activation, and the bias
+    // gradients are count x pooled-row gradient per graph (k_pool2 counted the positive rows).  Rounds 1-3 wrote and re-read the
+    // two [N, H] matrices (656 MB and 155 us per step at config 5).
     // (per-graph fused backward: both are built while k_gconv_bwd stages dOut, and it emits gn / gself as well)
     if (!gcb) {
-        const Acc acb = deferred(H, d_cb), aob = deferred(H, d_ob);
-        if (!acb.on() || !aob.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
-        RC(with_g(H, [&](auto g) {
-            constexpr int G = decltype(g)::value;
-            if (ro)
-                hipLaunchKernelGGL((k_pool_bwd_relu_ro<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, e->dxh, e->iperm, batch,
-                                   e->hco, e->hco + NH, e->dZco, e->dZco + NH, acb, aob, N, B, H, c.rpb_n);
-            else
-                hipLaunchKernelGGL((k_pool_bwd_relu<4, G>), dim3(cdiv(N, c.rpb_n), 2), dim3(256), 0, st, e->dpool, batch, e->hco, e->hco + NH,
-                                   e->dZco, e->dZco + NH, acb, aob, N, B, H, c.rpb_n);
-            return 0;
-        }));
+        if (use_gc(c)) { RC(launch_pool_cnt(c)); STAGE(); }             // the forward pooled inside k_gconv_fwd: no counts yet
+        d_cb.p = parts_alloc(c, (size_t)B * H); d_cb.P = B; d_cb.stride = H;
+        d_ob.p = parts_alloc(c, (size_t)B * H); d_ob.P = B; d_ob.stride = H;
+        if (!d_cb.p || !d_ob.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+        // (fused readout: d pooled is still two addends per row -- combined here into dpool, which that path leaves unused)
+        hipLaunchKernelGGL(k_pool_bias_grad, dim3(B, 2), dim3(256), 0, st, e->pcnt, ro ? e->dxh : e->dpool, ro ? e->dxh + 2 * (size_t)B * H : nullptr,
+                           e->iperm, e->dpool, d_cb.p, d_ob.p, B, H);
+        CAL_CHECK_LAUNCH("k_pool_bias_grad"); STAGE();
     }
-    if (!gcb) { CAL_CHECK_LAUNCH("k_pool_bwd_relu"); STAGE(); }
     // P2-P4. gradient w.r.t. the edge weights through propagate and through the normalisation
     auto norm_bwd = [&](const float* gn2, const float* gself2) -> int {
         hipLaunchKernelGGL(k_normbwd_node2, dim3(cdiv(N, 32), 2), dim3(256), 0, st, gs, gd, e->att, e->dis_co, e->gn, e->gself, e->ddeg,
@@ -1334,10 +1361,12 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     // lane-group reduction per slot instead of a second pass over both matrices (the separate SDDMM kernel of rounds 1-3: 265 us per
     // step at config 5).  Input self-loop edges have no slot: their gn entry is never read (k_normbwd_* skip them like the plan does).
     if (!gcb) {
-        SpmmBranch b0{e->dZco, e->dzco, nullptr, e->att, e->dis_co, Acc(), Acc(), nullptr, nullptr, nullptr};
-        SpmmBranch b1{e->dZco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, Acc(), Acc(), nullptr, nullptr, nullptr};
+        SpmmBranch b0{e->hco, e->dzco, nullptr, e->att, e->dis_co, Acc(), Acc(), nullptr, nullptr, nullptr};
+        SpmmBranch b1{e->hco + NH, e->dzco + NH, nullptr, e->att + E, e->dis_co + N, Acc(), Acc(), nullptr, nullptr, nullptr};
         b0.sd_z = e->zco; b0.sd_gn = e->gn; b0.sd_gself = e->gself;
         b1.sd_z = e->zco + NH; b1.sd_gn = e->gn + E; b1.sd_gself = e->gself + N;
+        b0.pb_g = e->dpool; b0.pb_batch = batch;
+        b1.pb_g = e->dpool + (size_t)B * H; b1.pb_batch = batch;
         RC(launch_espmm(st, gs, SpmmBranch2{{b0, b1}}, 2, 0, e->loop_w, N, H, spmm_rpb(H, false)));
         CAL_CHECK_LAUNCH("k_espmm(co,T)"); STAGE();
         RC(norm_bwd(nullptr, nullptr));

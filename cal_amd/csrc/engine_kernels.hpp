@@ -215,6 +215,12 @@ struct SpmmBranch {
     const float* sd_z;     // z = x' W of this branch (the forward aggregation's input), or null
     float* sd_gn;          // [E] by edge id
     float* sd_gself;       // [N]
+    // add-pool + ReLU backward folded into the gathers (k_espmm<.., PB = true>): `h` is the branch's ACTIVATION relu(A_hat z + b),
+    // and the row the aggregation uses for node v is dOut[v] = (h[v] > 0) * pb_g[pb_batch[v]] -- pb_g[b] the gradient of graph b's
+    // pooled row (model.py:115-116,153-156; combined per graph by k_pool_bias_grad).  Every neighbour of a row lies in the row's
+    // own graph (block-diagonal batch), so the pooled-row gradient is fetched once per row.
+    const float* pb_g;     // [B, H] or null (plain feature rows)
+    const int64_t* pb_batch;
 };
 
 struct SpmmBranch2 { SpmmBranch b[2]; };
@@ -243,9 +249,14 @@ __device__ __forceinline__ float group_dot_sum(float d) {
     }
     return d;
 }
-template <int NB, int G, bool SD = false>
+// relu'(h) * g, elementwise: the row of d(conv output) that belongs to activation row h under pooled-row gradient g
+__device__ __forceinline__ void pool_bwd_row(Vec<4>& h, const Vec<4>& g) {
+    h.v.x = h.v.x > 0.f ? g.v.x : 0.f; h.v.y = h.v.y > 0.f ? g.v.y : 0.f;
+    h.v.z = h.v.z > 0.f ? g.v.z : 0.f; h.v.w = h.v.w > 0.f ? g.v.w : 0.f;
+}
+template <int NB, int G, bool SD = false, bool PB = false>
 __device__ __forceinline__ void espmm_batch(Vec<4>& acc, const float* __restrict__ h, int H, int jl, float cl, int q, int cnt, int gi, int c,
-                                            const Vec<4>* zj = nullptr, float* gdot = nullptr, int lane = 0) {
+                                            const Vec<4>* zj = nullptr, float* gdot = nullptr, int lane = 0, const Vec<4>* gp = nullptr) {
     constexpr int SPLIT = 64 / G;
     Vec<4> v[NB];
     float cf[NB];
@@ -266,6 +277,10 @@ __device__ __forceinline__ void espmm_batch(Vec<4>& acc, const float* __restrict
     }
 #pragma unroll
     for (int u = 0; u < NB; ++u) v[u].pin();
+    if constexpr (PB) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) pool_bwd_row(v[u], *gp);
+    }
 #pragma unroll
     for (int u = 0; u < NB; ++u) acc.fma(cf[u], v[u]);
     if constexpr (SD) {
@@ -287,7 +302,7 @@ __device__ __forceinline__ void espmm_batch(Vec<4>& acc, const float* __restrict
 
 // WT: per-edge weights (the two causal branches; their load rides with deg^-1/2 of the neighbour), ST: column statistics of the
 // output for the next BatchNorm (8 fp64 accumulators per lane: without them the kernel keeps 8 waves per SIMD)
-template <int VEC, int G, bool WT, bool ST, bool SD = false>
+template <int VEC, int G, bool WT, bool ST, bool SD = false, bool PB = false>
 __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch2 bb, int relu,
                                                float loop_w, int N, int H, int rows_per_block) {
     static_assert(VEC == 4 && G >= 8 && G <= 64, "16 B per lane, 8..64 lanes per row");
@@ -314,7 +329,12 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch2 bb
         const int i = __builtin_amdgcn_readfirstlane(iw);
         const int p0 = g.ptr[i], p1 = g.ptr[i + 1];
         const float di = br.dis[i];
-        const V hs = V::ld(br.h + (size_t)i * H + cld);      // the row's own features go out with the first round
+        V hs = V::ld(br.h + (size_t)i * H + cld);            // the row's own features go out with the first round
+        V gp = V::zero();
+        if constexpr (PB) {
+            gp = V::ld(br.pb_g + (size_t)br.pb_batch[i] * H + cld);
+            pool_bwd_row(hs, gp);
+        }
         V zj = V::zero();
         if constexpr (SD) { zj = V::ld(br.sd_z + (size_t)i * H + cld); if (!cok) zj = V::zero(); }
         V acc = V::zero();
@@ -327,16 +347,16 @@ __global__ void __launch_bounds__(256) k_espmm(const CSR g, const SpmmBranch2 bb
             if constexpr (WT) cl *= br.w[el];
             const int cnt = min(64, p1 - base);
             int q = 0;
-            for (; q + 8 * SPLIT <= cnt; q += 8 * SPLIT) espmm_batch<8, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane);
+            for (; q + 8 * SPLIT <= cnt; q += 8 * SPLIT) espmm_batch<8, G, SD, PB>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane, &gp);
             switch ((cnt - q + SPLIT - 1) / SPLIT) {          // (8 only when 64 / G > 1: 7 * SPLIT < cnt - q < 8 * SPLIT)
-                case 8: espmm_batch<8, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
-                case 7: espmm_batch<7, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
-                case 6: espmm_batch<6, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
-                case 5: espmm_batch<5, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
-                case 4: espmm_batch<4, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
-                case 3: espmm_batch<3, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
-                case 2: espmm_batch<2, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
-                case 1: espmm_batch<1, G, SD>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane); break;
+                case 8: espmm_batch<8, G, SD, PB>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane, &gp); break;
+                case 7: espmm_batch<7, G, SD, PB>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane, &gp); break;
+                case 6: espmm_batch<6, G, SD, PB>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane, &gp); break;
+                case 5: espmm_batch<5, G, SD, PB>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane, &gp); break;
+                case 4: espmm_batch<4, G, SD, PB>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane, &gp); break;
+                case 3: espmm_batch<3, G, SD, PB>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane, &gp); break;
+                case 2: espmm_batch<2, G, SD, PB>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane, &gp); break;
+                case 1: espmm_batch<1, G, SD, PB>(acc, br.h, H, jl, cl, q, cnt, gi, cld, &zj, &gdot, lane, &gp); break;
                 default: break;
             }
             if constexpr (SD) { if (lane < cnt) br.sd_gn[el] = gdot; }
@@ -545,13 +565,19 @@ __global__ void __launch_bounds__(256) k_edge_att_deg(const CSR gs, const float*
 template <int VEC>
 __global__ void __launch_bounds__(256) k_pool2(const float* __restrict__ hc, const float* __restrict__ ho,
                                                const int* __restrict__ gptr, float* __restrict__ pc,
-                                               float* __restrict__ po, int H, int tc, float* __restrict__ slices) {
-    __shared__ float lds[256 * 4];
+                                               float* __restrict__ po, int H, int tc, float* __restrict__ slices,
+                                               float* __restrict__ cnt) {
+    __shared__ float lds[2][256 * 4];
     const float* h = blockIdx.y ? ho : hc;
     const int b = blockIdx.x;
     // gridDim.z > 1 (graphs of thousands of nodes, few graphs): row slice z of the graph goes to slices[z][branch][b][:]
-    // and k_pool2_sum adds the slices in a fixed order -- B x 2 workgroups alone read config 5's 328 MB at 1 TB/s
-    float* out = gridDim.z > 1 ? slices + ((size_t)blockIdx.z * 2 + blockIdx.y) * gridDim.x * H : (blockIdx.y ? po : pc);
+    // and k_pool2_sum adds the slices in a fixed order -- B x 2 workgroups alone read config 5's 328 MB at 1 TB/s.
+    // cnt (training steps of the node-level path): how many rows of the graph are POSITIVE per column -- the ReLU mask the
+    // backward needs only as this count (the bias gradient is count x pooled-row gradient, k_pool_bias_grad) and per gathered
+    // row (k_espmm<.., PB>); [2, B, H] after the pooled rows in both layouts.
+    const size_t BH = (size_t)gridDim.x * H;
+    float* out = gridDim.z > 1 ? slices + ((size_t)blockIdx.z * 4 + blockIdx.y) * BH : (blockIdx.y ? po : pc);
+    float* outc = gridDim.z > 1 ? slices + ((size_t)blockIdx.z * 4 + 2 + blockIdx.y) * BH : (cnt ? cnt + blockIdx.y * BH : nullptr);
     const int nrl = 256 / tc, cl = threadIdx.x % tc, rl = threadIdx.x / tc;
     int n0 = gptr[b], n1 = gptr[b + 1];
     if (gridDim.z > 1) {
@@ -563,37 +589,114 @@ __global__ void __launch_bounds__(256) k_pool2(const float* __restrict__ hc, con
     for (int c = cl * VEC; c - cl * VEC < H; c += tc * VEC) {
         const bool cok = c < H;
         V a = V::zero(), a2 = V::zero();
+        float pos[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) pos[j] = 0.f;
         if (cok) {
             int r = n0 + rl;
             for (; r + nrl < n1; r += 2 * nrl) {
-                a.add(V::ld(h + (size_t)r * H + c));
-                a2.add(V::ld(h + (size_t)(r + nrl) * H + c));
+                const V x0 = V::ld(h + (size_t)r * H + c), x1 = V::ld(h + (size_t)(r + nrl) * H + c);
+                a.add(x0); a2.add(x1);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) pos[j] += (x0.get(j) > 0.f ? 1.f : 0.f) + (x1.get(j) > 0.f ? 1.f : 0.f);
             }
-            if (r < n1) a.add(V::ld(h + (size_t)r * H + c));
+            if (r < n1) {
+                const V x0 = V::ld(h + (size_t)r * H + c);
+                a.add(x0);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) pos[j] += x0.get(j) > 0.f ? 1.f : 0.f;
+            }
             a.add(a2);
         }
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) lds[(rl * tc + cl) * VEC + j] = a.get(j);
+        for (int j = 0; j < VEC; ++j) { lds[0][(rl * tc + cl) * VEC + j] = a.get(j); lds[1][(rl * tc + cl) * VEC + j] = pos[j]; }
         __syncthreads();
         if (rl == 0 && cok) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                float t = 0.f;
-                for (int k = 0; k < nrl; ++k) t += lds[(k * tc + cl) * VEC + j];
+                float t = 0.f, n = 0.f;
+                for (int k = 0; k < nrl; ++k) { t += lds[0][(k * tc + cl) * VEC + j]; n += lds[1][(k * tc + cl) * VEC + j]; }
                 out[(size_t)b * H + c + j] = t;
+                if (outc) outc[(size_t)b * H + c + j] = n;
             }
         }
         __syncthreads();
     }
 }
 
-// pooled[branch][b][:] = sum over the S row slices written by k_pool2 (n = 2 * B * H floats per slice)
-__global__ void k_pool2_sum(const float* __restrict__ slices, int S, int64_t n, float* __restrict__ pooled) {
+// {pooled, cnt}[branch][b][:] = sum over the S row slices written by k_pool2 (a slice: [4][B][H] = two pooled branches, two counts;
+// n = 2 * B * H floats per half)
+__global__ void k_pool2_sum(const float* __restrict__ slices, int S, int64_t n, float* __restrict__ pooled, float* __restrict__ cnt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= 2 * n) return;
     float s = 0.f;
-    for (int z = 0; z < S; ++z) s += slices[(size_t)z * n + i];
-    pooled[i] = s;
+    for (int z = 0; z < S; ++z) s += slices[(size_t)z * 2 * n + i];
+    if (i < n) pooled[i] = s;
+    else if (cnt) cnt[i - n] = s;
+}
+
+// The positive counts alone, from the node -> graph map (any batch layout: packed tiles, graphs without nodes): for a batch whose
+// FORWARD pooled inside the per-graph convolution kernel while its backward runs node-level (65..128-node graphs, > 512 units,
+// edge lists beyond the per-graph kernels' capacity).  Integer-valued float atomics: exact, so order-independent.
+// cnt [2, B, H] zeroed by the caller; grid (row blocks, 2)
+template <int VEC, int G>
+__global__ void __launch_bounds__(256) k_pool_cnt(const float* __restrict__ hc, const float* __restrict__ ho, const int64_t* __restrict__ batch,
+                                                  float* __restrict__ cnt, int N, int B, int H, int rows_per_block) {
+    constexpr int RPB = 256 / G;
+    const float* h = blockIdx.y ? ho : hc;
+    float* out = cnt + (size_t)blockIdx.y * B * H;
+    const int grp = threadIdx.x / G, l = threadIdx.x % G;
+    const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
+    using V = Vec<VEC>;
+    for (int c = l * VEC; c < H; c += G * VEC) {
+        float n[VEC];
+        int cur = -1;
+        auto flush = [&]() {
+            if (cur < 0) return;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (n[j] != 0.f) atomicAdd(out + (size_t)cur * H + c + j, n[j]);
+        };
+        for (int v = rbeg + grp; v < rend; v += RPB) {
+            const int b = (int)batch[v];
+            if (b != cur) {
+                flush();
+                cur = b;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) n[j] = 0.f;
+            }
+            const V hv = V::ld(h + (size_t)v * H + c);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) n[j] += hv.get(j) > 0.f ? 1.f : 0.f;
+        }
+        flush();
+    }
+}
+__global__ void k_zero_f32(float* __restrict__ a, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = 0.f;
+}
+
+// Node-level backward of the add-pool: per graph, (1) the gradient of its two pooled rows, combined from the readout-input
+// gradients when the readout backward left them apart (model.py:153-156: d pooled_c[b] = dxin_c[b] + dxin_co[iperm[b]],
+// d pooled_o[b] = dxin_o[b] + dxin_co[b]) -> g [2, B, H], the rows k_espmm<.., PB> masks per gathered activation row; (2) the
+// bias gradient of the two causal convs from the positive counts of k_pool2: d b_k = sum_v relu'(h_k[v]) * g_k[batch[v]] =
+// sum_b cnt_k[b] * g_k[b] (exact in fp64: every term of the left sum is the same fp32 number).  One partial row per graph,
+// summed by k_finish.  grid (B, 2)
+__global__ void __launch_bounds__(256) k_pool_bias_grad(const float* __restrict__ cnt, const float* __restrict__ g0, const float* __restrict__ g1,
+                                                        const int* __restrict__ iperm, float* __restrict__ g, double* __restrict__ parts_c,
+                                                        double* __restrict__ parts_o, int B, int H) {
+    const int b = blockIdx.x, k = blockIdx.y;
+    const size_t BH = (size_t)B * H;
+    double* out = (k ? parts_o : parts_c) + (size_t)b * H;
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float v = g0[k * BH + (size_t)b * H + c];
+        if (g1) {
+            v += g1[(size_t)(k == 0 ? iperm[b] : b) * H + c];
+            g[k * BH + (size_t)b * H + c] = v;
+        }
+        out[c] = (double)cnt[k * BH + (size_t)b * H + c] * (double)v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -904,47 +1007,6 @@ __global__ void __launch_bounds__(256) k_readout_bwd_tail(const BnIn hc, const B
     const int W = cat ? 2 * H : H;
     dpool[t] = bn_bwd_elem(hc, r, c, H) + bn_bwd_elem(hco, iperm[r], c, W);
     dpool[(size_t)B * H + t] = bn_bwd_elem(ho, r, c, H) + bn_bwd_elem(hco, r, cat ? H + c : c, W);
-}
-
-// ------------------------------------------------------------------------------------------------
-// add-pool backward + ReLU mask + bias-gradient sums for both branches: grid (blocks, 2)
-//   dZ[v,:] = dpool[batch[v],:] * (h[v,:] > 0)
-// ------------------------------------------------------------------------------------------------
-template <int VEC, int G>
-__global__ void __launch_bounds__(256) k_pool_bwd_relu(const float* __restrict__ dpool, const int64_t* __restrict__ batch,
-                                                       const float* __restrict__ hc, const float* __restrict__ ho,
-                                                       float* __restrict__ dzc, float* __restrict__ dzo,
-                                                       const Acc dbc, const Acc dbo, int N, int B,
-                                                       int H, int rows_per_block) {
-    __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
-    constexpr int RPB = 256 / G;
-    const int brn = blockIdx.y;
-    const float* h = brn ? ho : hc;
-    float* dz = brn ? dzo : dzc;
-    const Acc db = brn ? dbo : dbc;
-    const float* dp = dpool + (size_t)brn * B * H;
-    const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
-    using V = Vec<VEC>;
-    for (int c = l * VEC; c - l * VEC < H; c += G * VEC) {
-        const bool cok = c < H;
-        double cs[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) cs[j] = 0.0;
-        if (cok)
-            for (int v = rbeg + grp; v < rend; v += RPB) {
-                V g = V::ld(dp + (size_t)batch[v] * H + c), hv = V::ld(h + (size_t)v * H + c);
-                float o[VEC];
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) { o[j] = hv.get(j) > 0.f ? g.get(j) : 0.f; cs[j] += (double)o[j]; }
-                V ov;
-                if constexpr (VEC == 4) ov.v = make_float4(o[0], o[1], o[2], o[3]); else ov.v = o[0];
-                ov.st(dz + (size_t)v * H + c);
-            }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-            block_col_atomic(cs[j], l * VEC + j, grp, RPB, G * VEC, cok, db, c + j, lds);
-    }
 }
 
 // d deg for both branches (gcn_conv.py:63-70 differentiated); 8 lanes per node

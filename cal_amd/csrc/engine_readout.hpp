@@ -627,46 +627,4 @@ __global__ void __launch_bounds__(256) k_ro_bwd_b(const RoArgs a) {
     RO_CLK(21);
 }
 
-// pool backward + ReLU mask with the readout-input gradients combined on the fly (model.py:153-156):
-//   d pooled_c[b] = dxin_c[b] + dxin_co[iperm[b]],   d pooled_o[b] = dxin_o[b] + dxin_co[b]
-template <int VEC, int G>
-__global__ void __launch_bounds__(256) k_pool_bwd_relu_ro(const float* __restrict__ dxin, const int* __restrict__ iperm,
-                                                          const int64_t* __restrict__ batch, const float* __restrict__ hc,
-                                                          const float* __restrict__ ho, float* __restrict__ dzc,
-                                                          float* __restrict__ dzo, const Acc dbc, const Acc dbo, int N, int B,
-                                                          int H, int rows_per_block) {
-    __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
-    constexpr int RPB = 256 / G;
-    const int brn = blockIdx.y;
-    const float* h = brn ? ho : hc;
-    float* dz = brn ? dzo : dzc;
-    const Acc db = brn ? dbo : dbc;
-    const size_t BH = (size_t)B * H;
-    const int grp = threadIdx.x / G, l = threadIdx.x % G;
-    const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
-    using V = Vec<VEC>;
-    for (int c = l * VEC; c - l * VEC < H; c += G * VEC) {
-        const bool cok = c < H;
-        double cs[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) cs[j] = 0.0;
-        if (cok)
-            for (int v = rbeg + grp; v < rend; v += RPB) {
-                const int b = (int)batch[v];
-                V g = V::ld(dxin + (size_t)brn * BH + (size_t)b * H + c);
-                g.add(V::ld(dxin + 2 * BH + (size_t)(brn ? b : iperm[b]) * H + c));
-                V hv = V::ld(h + (size_t)v * H + c);
-                float o[VEC];
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) { o[j] = hv.get(j) > 0.f ? g.get(j) : 0.f; cs[j] += (double)o[j]; }
-                V ov;
-                if constexpr (VEC == 4) ov.v = make_float4(o[0], o[1], o[2], o[3]); else ov.v = o[0];
-                ov.st(dz + (size_t)v * H + c);
-            }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j)
-            block_col_atomic(cs[j], l * VEC + j, grp, RPB, G * VEC, cok, db, c + j, lds);
-    }
-}
-
 }  // namespace cal
