@@ -33,6 +33,7 @@
 #include "engine_ro_step.hpp"
 #include "engine_gin.hpp"
 #include "engine_ggin.hpp"
+#include "engine_feat.hpp"
 
 namespace cal {
 
@@ -800,6 +801,26 @@ int gin_rows(Ctx& c, int mode, const GinRowArgs& ga) {
     });
 }
 
+// narrow feature matrices of big batches: the feature layer as row kernels (engine_feat.hpp) instead of tiled GEMMs
+bool feat_rows(const Ctx& c) {
+    const Engine* e = c.e;
+    return e->F <= FEAT_FMAX && c.N > 16384 && e->H % 4 == 0 && e->H <= 256 && group_for(e->H, 4) >= FEAT_FMAX;
+}
+template <typename Fn>
+int with_g_fp(int H, int F, Fn f) {
+    return with_g(H, [&](auto g) {
+        constexpr int G = decltype(g)::value;
+        if constexpr (G >= FEAT_FMAX) {
+            if (F <= 4) return f(g, std::integral_constant<int, 4>());
+            if (F <= 8) return f(g, std::integral_constant<int, 8>());
+            if (F <= 12) return f(g, std::integral_constant<int, 12>());
+            return f(g, std::integral_constant<int, 16>());
+        } else {
+            set_error("feature row kernels: hidden width too small"); return 2;
+        }
+    });
+}
+
 // add-pool of the two causal branches (model.py:115-116) + the per-graph positive counts the node-level backward uses
 int launch_pool2(Ctx& c) {
     Engine* e = c.e;
@@ -891,7 +912,17 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         if (wide) { RC(flush_finals(c)); STAGE(); }
     }
     // 3. h0 = relu(BN(x0) @ W_feat)   (model.py:90-91, gcn_conv.py:75-77)
-    {
+    if (feat_rows(c)) {
+        FeatFwdArgs fw;
+        fw.x0 = x0; fw.W = e->P + e->o_feat_w; fw.out = e->h; fw.bn0 = bnref(c, 0, N, 1);
+        if (c.training && L > 0 && !e->gin) { fw.st_sum = node_acc(c, bn_stsum(c, 1), H); fw.st_sq = node_acc(c, bn_stsq(c, 1), H); }
+        RC(with_g_fp(H, F, [&](auto g, auto fp) {
+            hipLaunchKernelGGL((k_feat_fwd_rows<decltype(g)::value, decltype(fp)::value>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, fw, N, H, F, c.rpb_n);
+            return 0;
+        }));
+        CAL_CHECK_LAUNCH("k_feat_fwd_rows"); STAGE();
+        RC(flush_finals(c)); STAGE();
+    } else {
         GemmArgs a = gemm_args(N, H, F, false, false, 1);
         a.p[0].A = x0; a.p[0].B = e->P + e->o_feat_w; a.p[0].C = e->h;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 1);
@@ -1768,7 +1799,28 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             { ProfScope ps(st, 3, 4.0 * N * H * H); RC(dual_gemm(c, a, 1, aw, 1, dst, fa, slab_off)); } STAGE();
             RC(flush_finals(c)); STAGE();
         }
-        {
+        if (i == 1 && !feat_done && feat_rows(c)) {
+            // the last BatchNorm backward feeds only the feature layer: dZ stays in registers (engine_feat.hpp)
+            const int P = cdiv(N, c.rpb_n), cols = (F + 1) * H;
+            FeatBwdRowsArgs fb{e->dXh, hin, bnref(c, 1, N, 0), bn_dsum(c, 1), bn_dprod(c, 1), x0, bnref(c, 0, N, 0), parts_alloc(c, (size_t)P * cols)};
+            double* sums = parts_alloc(c, cols);
+            d_bn0.p = parts_alloc(c, 2 * (size_t)F); d_bn0.P = 1; d_bn0.stride = 2 * F;
+            if (!fb.parts || !sums || !d_bn0.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
+            if (slab_off + (size_t)F * H > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
+            float* dw = e->slabs + slab_off;
+            fa.st[fa.nst++] = SlabTask{dw, e->G + e->o_feat_w, F * H, 1};
+            slab_off += (size_t)F * H;
+            RC(with_g_fp(H, F, [&](auto g, auto fp) {
+                hipLaunchKernelGGL((k_bn_bwd_feat<decltype(g)::value, decltype(fp)::value>), dim3(P), dim3(256), 0, st, fb, N, H, F, c.rpb_n);
+                return 0;
+            }));
+            CAL_CHECK_LAUNCH("k_bn_bwd_feat"); STAGE();
+            final_task(c, fb.parts, P, cols, cols, sums);
+            RC(flush_finals(c)); STAGE();
+            hipLaunchKernelGGL(k_feat_bwd_final, dim3(F), dim3(256), 0, st, sums, e->P + e->o_feat_w, bnref(c, 0, N, 0), dw, d_bn0.p, H, F);
+            CAL_CHECK_LAUNCH("k_feat_bwd_final"); STAGE();
+            feat_done = true;
+        } else {
             BnBwdProb p{e->dXh, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i),
                         i >= 2 ? deferred(H, d_convb[i - 2]) : Acc()};
             RC(with_g(H, [&](auto g) {
