@@ -423,28 +423,30 @@ __global__ void __launch_bounds__(256) k_node_att_fwd(const float* __restrict__ 
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
     using V = Vec<VEC>;
-    // Fast path (one column chunk per lane, at most 4 rows per lane group): the group's rows and the six
-    // weight vectors are loaded once, all up front, and stay in registers for both passes -- the generic
-    // code below reloads the weights per row and reads anode / x back from memory for the statistics.
-    if (H <= G * VEC && rows_per_block <= 4 * RPB) {
+    // Fast path (one column chunk per lane): the six weight vectors are loaded once and stay in registers, the group's rows
+    // come four at a time (all four loads up front) and serve both the projections and the statistics -- the generic code
+    // below reloads the weights per row and reads anode / x back from memory for the statistics (config 5, 157 rows per
+    // workgroup, ran there until round 4: 98 us for one pass over 164 MB).
+    if (H <= G * VEC) {
         const int c = l * VEC, cc = min(c, H - VEC);
         const bool cok = c < H;
         V w[6], xv[4];
         w[0] = V::ld(Wn + cc); w[1] = V::ld(Wn + H + cc); w[2] = V::ld(We + cc);
         w[3] = V::ld(We + 2 * H + cc); w[4] = V::ld(We + H + cc); w[5] = V::ld(We + 3 * H + cc);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xv[u] = V::ld(x + (size_t)max(min(rbeg + grp + u * RPB, rend - 1), 0) * H + cc);
         const float b0 = bn[0], b1 = bn[1];
 #pragma unroll
         for (int u = 0; u < 6; ++u) w[u].pin();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { xv[u].pin(); if (!cok) xv[u] = V::zero(); }
         double sc1[VEC], sc2[VEC], so1[VEC], so2[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { sc1[j] = sc2[j] = so1[j] = so2[j] = 0.0; }
+        for (int rb = rbeg + grp; rb < rend; rb += 4 * RPB) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xv[u] = V::ld(x + (size_t)min(rb + u * RPB, rend - 1) * H + cc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xv[u].pin(); if (!cok) xv[u] = V::zero(); }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int v = rbeg + grp + u * RPB;
+            const int v = rb + u * RPB;
             const float l0 = fnode * (group_sum<G>(xv[u].dot(w[0])) + b0), l1 = fnode * (group_sum<G>(xv[u].dot(w[1])) + b1);
             const float p0 = group_sum<G>(xv[u].dot(w[2])), p1 = group_sum<G>(xv[u].dot(w[3]));
             const float q0 = group_sum<G>(xv[u].dot(w[4])), q1 = group_sum<G>(xv[u].dot(w[5]));
@@ -463,6 +465,7 @@ __global__ void __launch_bounds__(256) k_node_att_fwd(const float* __restrict__ 
                     sc1[j] += xc; sc2[j] += xc * xc; so1[j] += xo; so2[j] += xo * xo;
                 }
             }
+        }
         }
         // the 4 VEC column sums of this lane through LDS in one go (G lanes x VEC columns = one slot per column)
 #pragma unroll
