@@ -312,14 +312,23 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int vecA, int vecB
     float amean = 0.f, arstd = 0.f;
     float aux[16] = {};
     if (want_dot && cok) {
+        // aux values and their row scales as one batch of unconditional loads (no scale: the aux pointer again, stride 0, value
+        // ignored); a per-row `if (aux_rs)` made every row a load, a branch and a dependent second load (gemm_big.hip)
+        const bool has_rs = pr.aux_rs != nullptr;
+        const float* rsp = has_rs ? pr.aux_rs : pr.aux;
+        const size_t rstr = has_rs ? (size_t)pr.aux_rs_stride : 0;
+        float ars[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = min(m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lk, M - 1);
-            float x = pr.aux[(size_t)row * N + col];
-            if (pr.aux_rs) x *= pr.aux_rs[(size_t)row * pr.aux_rs_stride];
-            aux[r] = x;
+            aux[r] = pr.aux[(size_t)row * N + col];
+            ars[r] = rsp[(size_t)row * rstr];
         }
         bn_mean_rstd(pr.aux_bn, col, amean, arstd);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(aux[r]), "+v"(ars[r]));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) aux[r] *= has_rs ? ars[r] : 1.f;
     }
     // hipcc re-inserts `s_waitcnt vmcnt(0)` at the head of every guarded block below while a load issued
     // before them may still be pending on some path; on gfx9 stores count in vmcnt too, so each store then
