@@ -230,50 +230,62 @@ __device__ __forceinline__ void block(const GemmArgs& a, int bx, int by, int bz,
     const bool want_st = pr.st_sum != nullptr, want_dot = pr.dot_sum != nullptr;
     const bool interior = m0 + T <= M && n0 + T <= N;
     double s1[2] = {0.0, 0.0}, s2[2] = {0.0, 0.0};
+    // Everything the epilogue reads comes first, as ONE batch of unconditional loads on clamped rows / columns: the 4 x 16 aux
+    // values of the wave's four accumulators, the 2 x 16 row scales (no scale: the aux pointer again, stride 0, value ignored),
+    // the BatchNorm constants and the bias.  Per accumulator (16 loads, wait, 16 stores, four times) every tile paid four
+    // round trips; with `if (aux_rs) x *= aux_rs[row]` inside the loop every row was a load, a branch and a dependent second
+    // load (the two-branch backward, the only caller with row scales: 585 us per branch against 455 us without them).
+    float auxv[2][2][16], bvv[2] = {0.f, 0.f}, amean[2] = {0.f, 0.f}, arstd[2] = {0.f, 0.f};
+#pragma unroll
+    for (int sn = 0; sn < 2; ++sn) {
+        const int colc = min(n0 + wn + sn * 32 + li, N - 1);
+        if (pr.bias) bvv[sn] = pr.bias[colc];
+    }
+    if (want_dot) {
+        const bool has_rs = pr.aux_rs != nullptr;
+        const float* rsp = has_rs ? pr.aux_rs : pr.aux;
+        const size_t rstr = has_rs ? (size_t)pr.aux_rs_stride : 0;
+        float ars[2][16];
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const size_t row = (size_t)min(m0 + wm + sm * 32 + 4 * lk + (r & 3) + 8 * (r >> 2), M - 1);
+                ars[sm][r] = rsp[row * rstr];
+#pragma unroll
+                for (int sn = 0; sn < 2; ++sn) auxv[sn][sm][r] = pr.aux[row * N + min(n0 + wn + sn * 32 + li, N - 1)];
+            }
+#pragma unroll
+        for (int sn = 0; sn < 2; ++sn) bn_mean_rstd(pr.aux_bn, min(n0 + wn + sn * 32 + li, N - 1), amean[sn], arstd[sn]);
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(ars[sm][r]), "+v"(auxv[0][sm][r]), "+v"(auxv[1][sm][r]));
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float f = has_rs ? ars[sm][r] : 1.f;
+                auxv[0][sm][r] *= f; auxv[1][sm][r] *= f;
+            }
+    }
+    // consume the loads before the guarded stores (else every store waits for the previous one: gemm.hip)
+    asm volatile("" :: "v"(bvv[0]), "v"(bvv[1]), "v"(amean[0]), "v"(amean[1]), "v"(arstd[0]), "v"(arstd[1]));
 #pragma unroll
     for (int sn = 0; sn < 2; ++sn) {
         const int col = n0 + wn + sn * 32 + li;
         const bool cok = col < N;
-        const float bvv = (pr.bias && cok) ? pr.bias[col] : 0.f;
-        float amean = 0.f, arstd = 0.f;
-        if (want_dot && cok) bn_mean_rstd(pr.aux_bn, col, amean, arstd);
 #pragma unroll
         for (int sm = 0; sm < 2; ++sm) {
             const int rbase = m0 + wm + sm * 32 + 4 * lk;
-            float aux[16] = {};
-            if (want_dot && cok) {
-                // the 16 aux values and their 16 row scales as ONE batch of unconditional loads (no scale: the aux pointer again,
-                // stride 0, value ignored) -- with `if (aux_rs) x *= aux_rs[row]` inside the loop every row was a load, a branch
-                // and a dependent second load: the two-branch backward (the only caller with row scales) ran its dX tiles at
-                // 585 us per branch against 455 us for the same product without them
-                const bool has_rs = pr.aux_rs != nullptr;
-                const float* rsp = has_rs ? pr.aux_rs : pr.aux;
-                const size_t rstr = has_rs ? (size_t)pr.aux_rs_stride : 0;
-                float ars[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = min(rbase + (r & 3) + 8 * (r >> 2), M - 1);
-                    aux[r] = pr.aux[(size_t)row * N + col];
-                    ars[r] = rsp[(size_t)row * rstr];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(aux[r]), "+v"(ars[r]));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) aux[r] *= has_rs ? ars[r] : 1.f;
-            }
-            // consume the loads before the guarded stores (else every store waits for the previous one: gemm.hip)
-            asm volatile("" :: "v"(bvv), "v"(amean), "v"(arstd));
-            if (want_dot) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(aux[r]));
-            }
+            const float (&aux)[16] = auxv[sn][sm];
             auto emit = [&](int r, int row) {
-                float v = acc[sm][sn][r] + bvv;
+                float v = acc[sm][sn][r] + bvv[sn];
                 if (a.relu) v = fmaxf(v, 0.f);
                 if (C) C[(size_t)row * a.ldc + col] = v;
                 if (want_st) { s1[sn] += (double)v; s2[sn] += (double)v * (double)v; }
                 if (want_dot) {
-                    const float xn = (aux[r] - amean) * arstd;
+                    const float xn = (aux[r] - amean[sn]) * arstd[sn];
                     s1[sn] += (double)v;
                     s2[sn] += (double)v * (double)xn;
                 }
@@ -345,26 +357,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     block<A_KC, B_KC, XA>(a, bx, by, bz, smem, lin >= 256 && lin < 512);
 }
 
-// dX = dZ W^T (NT) and dW = op(X)^T dZ (TN, split-K) of one layer in one grid: the short NT tiles first, the long
-// split-K slices after them; the two sets fill each other's tails (as k_gemm_dual does at config-2 scale)
+// dX = dZ W^T (NT) and dW = op(X)^T dZ (TN, split-K) of one layer in one grid.  The LONG tiles go first (a split-K slice is
+// 32 K tiles, ~60 us; an NT tile 8 K tiles + its epilogue, ~16 us): 628 slices on 512 resident slots leave a second round that
+// is 23 % full, and behind the 2500 NT tiles that round was the tail of the launch (~45 of 455 us with most of the chip idle);
+// dispatched first, the slices' stragglers are covered by NT tiles and the launch ends on 16 us tiles.
 struct Grid2 { int gx1, gy1, n1; int gx2, gy2, nz2; };
 template <int XA2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gemm_big_dual(const GemmArgs a1, const GemmArgs a2, const Grid2 g) {
     constexpr int F1 = Smem<true, true>::FLOATS, F2 = Smem<false, false>::FLOATS;
     __shared__ __attribute__((aligned(16))) float smem[F1 > F2 ? F1 : F2];
     int b = blockIdx.x;
-    if (b < g.n1) {
+    const int tiles = g.gx2 * g.gy2, n2 = tiles * g.nz2;
+    if (b >= n2) {
+        b -= n2;
         // the column tiles of one row tile read the same dZ rows: back to back on ONE XCD (xcd_order), so the second read is
         // an L2 hit -- in row-tile-major order they were 1250 workgroups apart on different XCDs and the strip came from HBM
         // once per column tile (1.78 GB per launch against 0.53 GB algorithmic)
         const int per = g.gx1 * g.gy1, bz = b / per;
         int rt, ct;
         xcd_order(b - bz * per, g.gx1, g.gy1, rt, ct);
-        block<true, true, 0>(a1, rt, ct, bz, smem, b >= 256 && b < 512);
+        block<true, true, 0>(a1, rt, ct, bz, smem, false);
     } else {
-        b -= g.n1;
         // likewise the gx2 * gy2 output tiles of one split-K slice (same 1024-node strips of both operands)
-        const int tiles = g.gx2 * g.gy2;
         int z, tl;
         xcd_order(b, g.nz2, tiles, z, tl);
         block<false, false, XA2>(a2, tl % g.gx2, tl / g.gx2, z, smem, false);
