@@ -406,11 +406,9 @@ class StepEngine:
         ``p.grad`` after every backward."""
         gv = getattr(self, "_grad_views", None)
         if gv is None:
+            from .trainer import flat_offsets
             params = list(self.model.parameters())
-            views, off = [], 0
-            for p in params:
-                views.append(self.flat_g[off:off + p.numel()].view(p.shape))
-                off += p.numel()
+            views = [self.flat_g[off:off + p.numel()].view(p.shape) for p, off in zip(params, flat_offsets(params)[0])]
             gv = self._grad_views = (params, views)
         return gv
 
@@ -490,15 +488,14 @@ class _EngineAutograd(torch.autograd.Function):
         old = eng.flat_g.clone() if any(alias) else None
         eng.backward_from(ctx.batch, g)
         eng._fwd_token += 1                                   # a second backward would double-count
-        off = 0
         for p, view, al in zip(params, views, alias):          # hand the gradients to autograd's owners
             if al:
+                off = view.storage_offset()
                 view.add_(old[off:off + p.numel()].view(p.shape))
             elif p.grad is None:
                 p.grad = view
             else:
                 p.grad.add_(view)
-            off += p.numel()
         return None, None, None, None
 
 

@@ -59,12 +59,8 @@ class Binding:
         self.pending = 0                    # engine-side Adam steps not yet written to the optimizer's `step` counters
         self.engine_step = 0.0              # what the engine's device step counter holds
         self.grads_mixed = False            # a step has seen gradients outside the engine's flat buffer
-        self._views = []
-        off = 0
-        for p in params:
-            n = p.numel()
-            self._views.append((off, n))
-            off += n
+        from .trainer import flat_offsets
+        self._views = [(off, p.numel()) for p, off in zip(params, flat_offsets(params)[0])]
 
     def sync_hparams(self):
         """betas / eps / weight_decay / lr of the optimizer's group -> the engine (lr is a device float: an async fill)."""

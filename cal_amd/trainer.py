@@ -39,20 +39,35 @@ from .plan import _p, _stream
 from .train_causal import causal_loss
 
 
-def flatten_parameters(model: torch.nn.Module):
-    """Re-home every parameter (and its .grad) into one contiguous buffer."""
-    params = [p for p in model.parameters()]
-    total = sum(p.numel() for p in params)
-    dev = params[0].device
-    flat_p = torch.empty(total, dtype=torch.float32, device=dev)
-    flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
-    off = 0
+#: floats: every parameter starts on a 16-byte boundary of the flat buffers (the 128 x 128 GEMM and the row kernels read weights
+#: with 16 B loads; packed back to back, a 10-element bn_feat.weight put everything behind it on an 8-byte boundary and an odd
+#: feature count on a 4-byte one, which the big-batch kernels refuse)
+FLAT_ALIGN = 4
+
+
+def flat_offsets(params):
+    """Offsets (in elements) of `params` inside the flat parameter / gradient / moment buffers, and the buffers' length."""
+    offs, off = [], 0
     for p in params:
+        off = (off + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
+        offs.append(off)
+        off += p.numel()
+    return offs, (off + FLAT_ALIGN - 1) // FLAT_ALIGN * FLAT_ALIGN
+
+
+def flatten_parameters(model: torch.nn.Module):
+    """Re-home every parameter (and its .grad) into one buffer (`flat_offsets`; the padding stays zero: zero gradient, zero
+    moments, so Adam leaves it alone)."""
+    params = [p for p in model.parameters()]
+    offs, total = flat_offsets(params)
+    dev = params[0].device
+    flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+    flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+    for p, off in zip(params, offs):
         n = p.numel()
         flat_p[off:off + n].copy_(p.data.reshape(-1))
         p.data = flat_p[off:off + n].view(p.shape)
         p.grad = flat_g[off:off + n].view(p.shape)
-        off += n
     return flat_p, flat_g
 
 

@@ -68,12 +68,19 @@ def test_flat_bucket_allreduce_world2():
     # single-process reference: mean of the two replica gradients
     torch.manual_seed(0)
     net = _Net()
+    from cal_amd.trainer import flat_offsets
+    params = list(net.parameters())
+    offs, total = flat_offsets(params)                                # every parameter on a 16-byte boundary, zero padding
+    assert total == g0.numel() and all(o % 4 == 0 for o in offs)
     ref = []
     for x in (x0, x1):
         net.zero_grad()
         net(x).pow(2).sum().backward()
-        ref.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
-                              for p in net.parameters()]))
+        flat = torch.zeros(total)
+        for p, o in zip(params, offs):
+            if p.grad is not None:
+                flat[o:o + p.numel()] = p.grad.reshape(-1)
+        ref.append(flat)
     assert torch.allclose(g0, (ref[0] + ref[1]) / 2, atol=1e-6)
 
 
@@ -112,7 +119,12 @@ def _model_worker(rank, world, port, q):
         # the oracle's gradient on this rank's shard (train_causal.py:173-192 per replica)
         tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-2, layers=2)
         tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
-        ref = torch.cat([(tr.sd[k].grad if tr.sd[k].grad is not None else torch.zeros_like(tr.sd[k])).reshape(-1) for k, _ in m.named_parameters()])
+        from cal_amd.trainer import flat_offsets
+        offs, total = flat_offsets(list(m.parameters()))
+        ref = torch.zeros(total)
+        for (k, p), o in zip(m.named_parameters(), offs):
+            if tr.sd[k].grad is not None:
+                ref[o:o + p.numel()] = tr.sd[k].grad.reshape(-1)
         q.put((rank, local.numpy().copy(), flat_g.numpy().copy(), flat_p.detach().numpy().copy(), ref.numpy().copy(), None))
     except Exception as exc:
         import traceback

@@ -156,6 +156,57 @@ def test_config5_width_causalgat_engine_step_matches_oracle():
             assert e_gpu <= 4 * e_cpu + 1e-5 * max(1.0, g64.abs().max().item()), (k, e_gpu, e_cpu)
 
 
+@pytest.mark.parametrize("hidden,nfeat,layers", [(128, 10, 2), (64, 16, 1), (128, 3, 2), (256, 7, 1)])
+def test_narrow_feature_layer_row_kernels_match_oracle(hidden, nfeat, layers):
+    """The node-level feature layer of a big batch with few input features (engine_feat.hpp: k_feat_fwd_rows, k_bn_bwd_feat +
+    k_feat_bwd_final; taken above 16 384 nodes for F <= 16) at every lane-group width (H = 64 / 128 / 256) and feature-register
+    count (F <= 4 / 8 / 12 / 16), and the add-pool backward folded into the transposed aggregation (k_espmm<.., PB>): 44 BA
+    graphs of 400 nodes = 17 600 rows, one train step against the CPU oracle, logits and every parameter gradient
+    (conv_feat.weight, bn_feat.weight / .bias and the two causal convs' biases are the ones the new kernels produce)."""
+    from cal_amd import synth
+    from cal_amd.data import Batch
+    gs = synth.ba_graphs(44, n=400, max_degree=max(nfeat, 4), seed=11)
+    fg = torch.Generator().manual_seed(nfeat)
+    for d in gs:                    # dense features (one-hot degrees of an m = 2 BA graph leave constant columns: BatchNorm-0 of a
+        d.feat = torch.randn(400, nfeat, generator=fg)      # constant column is 0/0 up to eps in any arithmetic)
+    b, bd = Batch.from_data_list(gs), Batch.from_data_list(gs).to(DEV)
+    assert b.feat.shape == (17600, nfeat)
+    torch.manual_seed(hidden + nfeat)
+    sd = O.init_state("CausalGCN", nfeat, 4, hidden=hidden, layers=layers)
+    g = torch.Generator().manual_seed(3)
+    for k in list(sd):
+        if k.endswith(".bias") or ("bn" in k and k.endswith(".weight")):
+            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=g)
+    m, eng = _engine("CausalGCN", {k: v.clone() for k, v in sd.items()}, _args(hidden=hidden, layers=layers), nfeat=nfeat)
+    perm = torch.randperm(44, generator=g)
+    tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=layers)
+    loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    # sums over 17 600 rows (and one-hot degree columns that are almost constant: BatchNorm-0 amplifies them): the gradient bound
+    # is stated against the oracle evaluated in fp64, as for configs[4]'s width above -- the HIP path must be as close to it as
+    # the fp32 oracle is (x4)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    tr64 = O.CpuTrainer("CausalGCN", sd64, 4, lr=1e-3, layers=layers)
+    loss64, _, _, _, logits64 = tr64.step(b.feat.double(), b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=False).cpu().numpy()
+    eng.check_status()
+    lp = eng.buffer("logp", 3 * 44 * 4).view(3, 44, 4).cpu()
+    for r, r64, t in zip(logits, logits64, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+        assert (r64.detach() - t.double()).abs().max().item() < LOGIT_TOL
+    assert abs(stats[0] - loss64.item()) < 1e-4
+    # A ReLU input within rounding of zero lands on different sides in different fp32 evaluation orders: one such node moves single
+    # entries of the gradients above it by that node's whole contribution (seen here: 4.5e-4 on one row of objects_convs.weight,
+    # in the fp32 oracle and the HIP path alike, against 1e-8 everywhere else).  So: the MEAN error must be the fp32 oracle's,
+    # and no entry may be off by more than 2 % of the tensor's largest gradient -- a wrong term fails both by orders of magnitude.
+    for k, p in m.named_parameters():
+        g32, g64 = tr.sd[k].grad, tr64.sd[k].grad
+        if g32 is not None:
+            dg, dc = (p.grad.cpu().double() - g64).abs(), (g32.double() - g64).abs()
+            scale = g64.abs().max().item()
+            assert dg.mean().item() <= 4 * dc.mean().item() + 1e-3 * g64.abs().mean().item() + 1e-9, (k, dg.mean().item(), dc.mean().item())
+            assert dg.max().item() <= 0.02 * scale + 1e-5, (k, dg.max().item(), scale)
+
+
 class _ForeignBatch:
     """Only what the reference's loops and models touch (SURVEY.md 8b batch protocol)."""
 

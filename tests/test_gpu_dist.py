@@ -99,9 +99,9 @@ def test_two_ranks_on_one_gpu_over_gloo_match_the_mean_gradient_oracle():
         grads.append({k: tr.sd[k].grad.clone() for k in tr.names if tr.sd[k].grad is not None})
     from cal_amd import model as M
     m = M.CausalGCN(10, 4, _margs())
-    off = 0
+    from cal_amd.trainer import flat_offsets
     flat_g, flat_p = torch.from_numpy(res[0][0][0]), torch.from_numpy(res[0][0][1])
-    for k, p in m.named_parameters():
+    for (k, p), off in zip(m.named_parameters(), flat_offsets(list(m.parameters()))[0]):
         n = p.numel()
         g_sum = flat_g[off:off + n].view(p.shape)             # the bucket holds the all-reduced SUM; Adam applies 1/world
         if k in grads[0]:
@@ -112,7 +112,6 @@ def test_two_ranks_on_one_gpu_over_gloo_match_the_mean_gradient_oracle():
             assert torch.allclose(flat_p[off:off + n].view(p.shape)[mask], ref_p[mask], atol=2e-5, rtol=1e-4), k
         else:
             assert k == "conv_feat.bias" and float(g_sum.abs().max()) == 0.0
-        off += n
 
 
 def _run_two_ranks(sd, **kw):
