@@ -392,8 +392,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 bool gemm_big_rows(int M, int K) { return M >= 16384 && K % big::BK == 0 && K >= big::BK && K <= big::XMAX; }
 // weight gradients (K = nodes): worth it from 64 x 64 outputs up
 bool gemm_big_grad(int M, int N, int K) { return K >= 16384 && M >= 64 && N >= 64 && M % 4 == 0 && N % 4 == 0; }
-// split-K slice of such a gradient: 32 K tiles per workgroup (a 128 x 128 slab per ~60 us of matrix-core work)
-int gemm_big_grad_splits(int K) { return cdiv(K, 1024); }
+// split-K slice of such a gradient: 32 K tiles per workgroup (a 128 x 128 slab per ~60 us of matrix-core work); 64 from 64 k rows up,
+// where the slices are plenty either way and half as many slabs go through k_finish (config 5: 247 -> 124 MB, 48 -> 35 us)
+int gemm_big_grad_splits(int K) { return cdiv(K, K >= 65536 ? 2048 : 1024); }
 
 static bool big_aligned(const GemmArgs& a, int nbatch, bool xb_plain) {
     bool ok = a.lda % 4 == 0 && a.ldb % 4 == 0 && xb_plain;
