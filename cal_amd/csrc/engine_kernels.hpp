@@ -633,6 +633,7 @@ __global__ void k_pool2_sum(const float* __restrict__ slices, int S, int64_t n, 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * n) return;
     float s = 0.f;
+#pragma unroll 8
     for (int z = 0; z < S; ++z) s += slices[(size_t)z * 2 * n + i];
     if (i < n) pooled[i] = s;
     else if (cnt) cnt[i - n] = s;
