@@ -221,6 +221,16 @@ class EngineAdam(torch.optim.Adam):
         b.stepped()
         return loss
 
+    def zero_grad(self, set_to_none: bool = True):
+        """``optimizer.zero_grad()`` of the reference loop (train_causal.py:175).  Same effect as the parent's for the default
+        ``set_to_none=True``; its per-parameter bookkeeping (profiler scope, foreach grouping) was 34 us of host time per step."""
+        b = getattr(self, "_cal_binding", None)
+        if set_to_none and b is not None:
+            for p in b.params:
+                p.grad = None
+            return
+        super().zero_grad(set_to_none)
+
     def state_dict(self):
         b = getattr(self, "_cal_binding", None)
         if b is not None:
