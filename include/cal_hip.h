@@ -175,6 +175,10 @@ CAL_API int cal_engine_set_options(void* engine, int cat, int no_node_att, int n
 CAL_API int cal_engine_set_gin(void* engine, int on);
 CAL_API int64_t cal_engine_num_param_slots(void* engine);
 CAL_API int64_t cal_engine_num_bn(void* engine);
+/* P / G / M1 / M2: flat parameter, gradient and Adam-moment buffers of `nparam` floats; offs[slot] = offset of a parameter in
+ * them.  Keep every offset a multiple of 4 floats (16 bytes; cal_amd.trainer.flat_offsets pads with zeros, which Adam leaves
+ * alone): batches of >= 16 384 nodes read the weight matrices with 16-byte loads and cal_engine_step fails with "operands of a
+ * statistics GEMM must be 16-byte aligned" otherwise. */
 CAL_API int cal_engine_bind(void* engine, float* P, float* G, float* M1, float* M2, float* step,
                             float* lr, int64_t nparam, const int64_t* offs, const int64_t* bn_ptrs,
                             float beta1, float beta2, float eps, float weight_decay);
