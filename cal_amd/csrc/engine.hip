@@ -56,6 +56,8 @@ struct FinishArgs {
     AdamArgs adam;
     AdamRange ar[MAX_ADAM_RANGES];
     int nar;
+    const int* status;       // the engine's status words: while any bit is up (this step's or a sticky earlier one) the gradients are
+                             // not trusted and NO parameter / moment is updated (check_status raises and clears them)
     int blk0[MAX_SLABS + MAX_COMMITS + MAX_ADAM_RANGES + 1];   // first block of every task in the flattened 1-D grid (filled at launch)
 };
 // grid: 1-D, task t owns blocks [blk0[t], blk0[t+1]): n/64 per slab task, ceil(n/16) per commit task (a
@@ -63,8 +65,9 @@ struct FinishArgs {
 __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __restrict__ grad) {
     int task = 0;
     const int ntask = fa.nst + fa.nct + fa.nar;
-    const AdamArgs& A = fa.adam;
+    AdamArgs A = fa.adam;
     float adam_t = 0.f, adam_lr = 0.f;
+    if (A.on && fa.status && (fa.status[0] | fa.status[1]) != 0) A.on = 0;   // every earlier kernel of the step has finished: uniform
     if (A.on) { adam_t = A.step[0]; adam_lr = A.lr[0]; }      // the step's first kernel has already advanced the counter
     while (task + 1 < ntask && (int)blockIdx.x >= fa.blk0[task + 1]) ++task;
     const int bx = blockIdx.x - fa.blk0[task], nbx = fa.blk0[task + 1] - fa.blk0[task];
@@ -1239,6 +1242,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     memset(&fa, 0, sizeof(fa));
     fa.tick = (c.tick_in_finish && !c.adam_in_finish) ? e->step : nullptr;      // (adam_in_finish: k_zero_f64 did it)
     fa.perm_ctr = c.draw_perm ? e->perm_ctr : nullptr;
+    fa.status = e->status;
     size_t slab_off = 0;
     auto commit_p = [&](const double* src, int P, int stride, int dst, int n, float scale) {
         if (fa.nct < MAX_COMMITS) fa.ct[fa.nct] = CommitTask{src, P, stride, dst, n, scale};
@@ -1982,7 +1986,7 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
     }
     if ((mode & 4) && c.adam_in_finish != 1) {          // k_finish has already advanced the step counter (c.tick_in_finish)
         hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, c.st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
-                           e->beta2, e->eps, e->wd, e->nparam, 1, e->grad_scale);
+                           e->beta2, e->eps, e->wd, e->nparam, 1, e->grad_scale, e->status);
         CAL_CHECK_LAUNCH("k_adam");
     }
     return 0;
@@ -2104,7 +2108,7 @@ CAL_EXPORT int cal_engine_adam(void* h, void* stream_) {
     Engine* e = (Engine*)h;
     hipStream_t st = (hipStream_t)stream_;
     hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
-                       e->beta2, e->eps, e->wd, e->nparam, 0, e->grad_scale);
+                       e->beta2, e->eps, e->wd, e->nparam, 0, e->grad_scale, e->status);
     CAL_CHECK_LAUNCH("k_adam");
     hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, st, e->step);
     CAL_CHECK_LAUNCH("k_adam_tick");
@@ -2116,7 +2120,7 @@ CAL_EXPORT int cal_engine_adam_ticked(void* h, void* stream_) {
     Engine* e = (Engine*)h;
     hipStream_t st = (hipStream_t)stream_;
     hipLaunchKernelGGL(k_adam, dim3(cdiv(e->nparam, 256)), dim3(256), 0, st, e->P, e->G, e->M1, e->M2, e->step, e->lr, e->beta1,
-                       e->beta2, e->eps, e->wd, e->nparam, 1, e->grad_scale);
+                       e->beta2, e->eps, e->wd, e->nparam, 1, e->grad_scale, e->status);
     CAL_CHECK_LAUNCH("k_adam");
     return 0;
 }

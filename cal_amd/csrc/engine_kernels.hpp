@@ -1243,8 +1243,10 @@ __device__ __forceinline__ void adam_update(const AdamArgs& A, int64_t i, float 
 
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        float* __restrict__ step, const float* __restrict__ lr_ptr, float beta1, float beta2, float eps,
-                       float wd, int64_t n, int ticked, float gscale) {
+                       float wd, int64_t n, int ticked, float gscale, const int* __restrict__ status) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // a flagged step (or an unchecked earlier one) leaves the gradients untrusted: parameters and moments stay as they are
+    if (status && (status[0] | status[1]) != 0) return;
     // every thread reads the step counter, so it cannot be advanced in this launch: either the step's
     // k_finish has already done it (ticked = 1) or a separate tiny launch follows (k_adam_tick)
     if (i >= n) return;

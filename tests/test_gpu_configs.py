@@ -246,6 +246,30 @@ def test_foreign_batch_gets_its_layout_derived_and_runs_the_fused_kernels(name):
     assert (eng.buffer("logp", 3 * 24 * 4) - out[0][0]).abs().max().item() < 2e-5
 
 
+def test_flagged_step_leaves_the_parameters_alone():
+    """A step whose status word is up (here: stale per-graph bounds) has untrusted gradients: its Adam update and those of
+    every later step are skipped until check_status() has raised and cleared the word; then training goes on."""
+    from cal_amd import _lib
+    from cal_amd.data import Batch
+    good = Batch.from_data_list(ref_graphs(list(range(8)))).to(DEV)
+    bad = Batch.from_data_list(ref_graphs([24, 25])).to(DEV)
+    bad.max_nodes, bad.max_edges = 50, 100
+    sd = O.init_state("CausalGCN", 10, 4, hidden=64, layers=2)
+    m, eng = _engine("CausalGCN", sd, _args(hidden=64, layers=2))
+    eng.train_step(good, None, adam=True)
+    eng.check_status()
+    p0, m0 = eng.flat_p.clone(), eng.exp_avg.clone()
+    eng.train_step(bad, None, adam=True)
+    assert torch.equal(eng.flat_p, p0) and torch.equal(eng.exp_avg, m0)
+    eng.train_step(good, None, adam=True)                           # sticky: still frozen
+    assert torch.equal(eng.flat_p, p0) and torch.equal(eng.exp_avg, m0)
+    with pytest.raises(_lib.CalError, match="per-graph bounds"):
+        eng.check_status()
+    eng.train_step(good, None, adam=True)
+    eng.check_status()
+    assert not torch.equal(eng.flat_p, p0)
+
+
 def test_status_word_is_sticky_until_checked():
     """A batch whose declared per-graph bounds are wrong is flagged on the device; the flag survives later (valid) steps
     until check_status() reads it (the loops check once per epoch)."""
