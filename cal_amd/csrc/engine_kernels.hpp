@@ -177,6 +177,40 @@ __global__ void __launch_bounds__(256) k_colstats(const float* __restrict__ x, i
     }
 }
 
+// The same for W = 256 (the GATConv layer outputs of config 5, model.py:388-390: the next BatchNorm's statistics): 16 B per lane,
+// a wave per row, eight rows in flight per wave -- the 4 B-per-lane form above keeps 32 KB in flight per CU with the four
+// workgroups a 1020-block grid leaves on it, and ran at 4 TB/s (41 us for 164 MB).  Column sums: the four waves through LDS,
+// then one fp64 atomic pair per column and block.
+__global__ void __launch_bounds__(256) k_colstats4(const float* __restrict__ x, int N, int rows_per_block, const Acc sum, const Acc sq) {
+    constexpr int W = 256;
+    __shared__ double lds[2 * 4 * W];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane * 4;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(N, r0 + rows_per_block);
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = r0 + wv; r < r1; r += 32) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(x + (size_t)min(r + 4 * u, r1 - 1) * W + c);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool on = r + 4 * u < r1;
+            const double d0 = on ? (double)v[u].x : 0.0, d1 = on ? (double)v[u].y : 0.0, d2 = on ? (double)v[u].z : 0.0, d3 = on ? (double)v[u].w : 0.0;
+            s[0] += d0; q[0] += d0 * d0; s[1] += d1; q[1] += d1 * d1;
+            s[2] += d2; q[2] += d2 * d2; s[3] += d3; q[3] += d3 * d3;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { lds[wv * W + c + j] = s[j]; lds[4 * W + wv * W + c + j] = q[j]; }
+    __syncthreads();
+    const int col = threadIdx.x;
+    const double ts = (lds[col] + lds[W + col]) + (lds[2 * W + col] + lds[3 * W + col]);
+    const double tq = (lds[4 * W + col] + lds[5 * W + col]) + (lds[6 * W + col] + lds[7 * W + col]);
+    sum.add(col, ts);
+    sq.add(col, tq);
+}
+
 // ------------------------------------------------------------------------------------------------
 // gptr + unweighted deg^-1/2 (gcn_conv.py:65-68 with edge_weight = 1)
 // ------------------------------------------------------------------------------------------------

@@ -566,9 +566,74 @@ __device__ __forceinline__ float wave_sum(float v) {       // every lane gets th
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float comp(const float4& v, int h) { return h == 0 ? v.x : (h == 1 ? v.y : (h == 2 ? v.z : v.w)); }
 
+// sum over the 16 lanes of a DPP row, NB independent values at once, as FUSED v_add_f32_dpp (the update_dpp form compiles to
+// v_mov_b32_dpp + v_add, and the SLP vectorizer packed the adds of two slots into v_pk_add_f32 behind ~14 register moves per slot:
+// 44 VALU instructions per gathered row, of which 9 were the work).  A DPP read needs two wait states after the VALU write of
+// its source: the leading s_nop covers the compiler's last write, inside the block the other values' instructions do (NB >= 3)
+// or an s_nop per step.
+template <int NB>
+__device__ __forceinline__ void row16_sum_n(float (&v)[NB]) {
+    static_assert(NB >= 1 && NB <= 4, "batch of 1..4");
+#define CAL_DPP(r, ctl) "v_add_f32_dpp " r ", " r ", " r " " ctl " row_mask:0xf bank_mask:0xf\n"
+    if constexpr (NB == 4) {
+        asm volatile("s_nop 1\n"
+                     CAL_DPP("%0", "row_ror:8") CAL_DPP("%1", "row_ror:8") CAL_DPP("%2", "row_ror:8") CAL_DPP("%3", "row_ror:8")
+                     CAL_DPP("%0", "row_ror:4") CAL_DPP("%1", "row_ror:4") CAL_DPP("%2", "row_ror:4") CAL_DPP("%3", "row_ror:4")
+                     CAL_DPP("%0", "row_ror:2") CAL_DPP("%1", "row_ror:2") CAL_DPP("%2", "row_ror:2") CAL_DPP("%3", "row_ror:2")
+                     CAL_DPP("%0", "row_ror:1") CAL_DPP("%1", "row_ror:1") CAL_DPP("%2", "row_ror:1") CAL_DPP("%3", "row_ror:1")
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    } else if constexpr (NB == 3) {
+        asm volatile("s_nop 1\n"
+                     CAL_DPP("%0", "row_ror:8") CAL_DPP("%1", "row_ror:8") CAL_DPP("%2", "row_ror:8")
+                     CAL_DPP("%0", "row_ror:4") CAL_DPP("%1", "row_ror:4") CAL_DPP("%2", "row_ror:4")
+                     CAL_DPP("%0", "row_ror:2") CAL_DPP("%1", "row_ror:2") CAL_DPP("%2", "row_ror:2")
+                     CAL_DPP("%0", "row_ror:1") CAL_DPP("%1", "row_ror:1") CAL_DPP("%2", "row_ror:1")
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+    } else if constexpr (NB == 2) {
+        asm volatile("s_nop 1\n"
+                     CAL_DPP("%0", "row_ror:8") CAL_DPP("%1", "row_ror:8") "s_nop 0\n"
+                     CAL_DPP("%0", "row_ror:4") CAL_DPP("%1", "row_ror:4") "s_nop 0\n"
+                     CAL_DPP("%0", "row_ror:2") CAL_DPP("%1", "row_ror:2") "s_nop 0\n"
+                     CAL_DPP("%0", "row_ror:1") CAL_DPP("%1", "row_ror:1")
+                     : "+v"(v[0]), "+v"(v[1]));
+    } else {
+        asm volatile("s_nop 1\n" CAL_DPP("%0", "row_ror:8") "s_nop 1\n" CAL_DPP("%0", "row_ror:4") "s_nop 1\n" CAL_DPP("%0", "row_ror:2")
+                     "s_nop 1\n" CAL_DPP("%0", "row_ror:1")
+                     : "+v"(v[0]));
+    }
+#undef CAL_DPP
+}
+
+// 5..8 values: two blocks
+template <int NB>
+__device__ __forceinline__ void row16_sum_b(float (&v)[NB]) {
+    if constexpr (NB <= 4) row16_sum_n<NB>(v);
+    else {
+        float a[4] = {v[0], v[1], v[2], v[3]}, b[NB - 4];
+#pragma unroll
+        for (int u = 4; u < NB; ++u) b[u - 4] = v[u];
+        row16_sum_n<4>(a);
+        row16_sum_n<NB - 4>(b);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = a[u];
+#pragma unroll
+        for (int u = 4; u < NB; ++u) v[u] = b[u - 4];
+    }
+}
+// four values summed over the 64 lanes (every lane gets the totals): fused row sums, then the two cross-row exchanges
+__device__ __forceinline__ void wave_sum4(float (&v)[4]) {
+    row16_sum_n<4>(v);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { v[h] += __shfl_xor(v[h], 16, 64); v[h] += __shfl_xor(v[h], 32, 64); }
+}
+
+// att_s / ad arrive scaled by log2(e) (lrelu is positively homogeneous: lrelu(x) log2e = lrelu(x log2e)), km = this lane's slot's
+// keep decisions of the four heads as bits 0..3, kbit = 1 << (this lane's head): a dropped (slot, head) adds nothing to the row,
+// the kept ones are scaled by 1 / (1 - p) once per row (after the loop) -- one v_readlane + and / compare / select per slot
+// instead of four v_readlane + three selects + a multiply (the kernel is VALU-co-bound at eight waves per SIMD).
 template <int NB, bool DROP>
 __device__ __forceinline__ void fwd_batch(Vec<4>& acc, float& m, float& lsum, const float* __restrict__ z, const Vec<4>& att_s, float ad,
-                                          float slope, int jl, const float (&kl)[4], int q, int c, int k) {
+                                          float slope, int jl, int km, int kbit, int q, int c) {
     Vec<4> zv[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) zv[u] = Vec<4>::ld(z + (size_t)__builtin_amdgcn_readlane(jl, q + u) * H + c);
@@ -576,16 +641,20 @@ __device__ __forceinline__ void fwd_batch(Vec<4>& acc, float& m, float& lsum, co
     for (int u = 0; u < NB; ++u) zv[u].pin();
     float e[NB], mn = m;
 #pragma unroll
-    for (int u = 0; u < NB; ++u) { e[u] = lrelu(ad + row16_sum(zv[u].dot(att_s)), slope) * GAT_LOG2E; mn = fmaxf(mn, e[u]); }
-    const float sc = exp2f(m - mn);                 // one rescale of the running softmax per batch
+    for (int u = 0; u < NB; ++u) e[u] = zv[u].dot(att_s);
+    row16_sum_n<NB>(e);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) { e[u] = lrelu(ad + e[u], slope); mn = fmaxf(mn, e[u]); }
+    const float sc = __builtin_amdgcn_exp2f(m - mn);   // one rescale of the running softmax per batch (arguments <= 0: the raw v_exp_f32,
+                                                     // without exp2f's denormal-range rescue -- a term below 2^-126 of the row maximum is 0)
     lsum *= sc;
     acc.scale(sc);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-        const float pe = exp2f(e[u] - mn);
+        const float pe = __builtin_amdgcn_exp2f(e[u] - mn);
         lsum += pe;
-        const float kq = DROP ? sel4(rdl(kl[0], q + u), rdl(kl[1], q + u), rdl(kl[2], q + u), rdl(kl[3], q + u), k) : 1.f;
-        acc.fma(pe * kq, zv[u]);
+        const float pk = DROP ? ((__builtin_amdgcn_readlane(km, q + u) & kbit) ? pe : 0.f) : pe;
+        acc.fma(pk, zv[u]);
     }
     m = mn;
 }
@@ -596,8 +665,8 @@ constexpr int FWD_NB = 4;      // z rows in flight per wave in the forward (8: 1
                                             case 3: CALL(3); break; case 2: CALL(2); break; case 1: CALL(1); break; default: break; }
 
 // GATConv forward, one pass (a_src of a neighbour recomputed from the z row the aggregation fetches, online edge softmax)
-template <bool DROP>
-__global__ void __launch_bounds__(256) k_gat_fwd_w(const int* __restrict__ rowptr, const int* __restrict__ nbr, const int* __restrict__ eid,
+template <bool DROP, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_gat_fwd_w(const int* __restrict__ rowptr, const int* __restrict__ nbr, const int* __restrict__ eid,
                                                    const float* __restrict__ z, const float* __restrict__ att, const float* __restrict__ bias,
                                                    int relu, float slope, float p, uint64_t seed, int64_t E, float* __restrict__ out,
                                                    float* __restrict__ adst, float* __restrict__ asrc, float* __restrict__ mx,
@@ -611,30 +680,34 @@ __global__ void __launch_bounds__(256) k_gat_fwd_w(const int* __restrict__ rowpt
     const int c = lane * 4, k = lane >> 4, d = c & (D - 1);
     const int s0 = rowptr[i], s1 = rowptr[i + 1];
     const V zi = V::ld(z + (size_t)i * H + c);
-    const V att_d = V::ld(att + k * 2 * D + d), att_s = V::ld(att + k * 2 * D + D + d);
+    const V att_d = V::ld(att + k * 2 * D + d);
+    V att_s = V::ld(att + k * 2 * D + D + d);
     const float inv_keep = DROP ? 1.f / (1.f - p) : 1.f;
     const float ad = row16_sum(zi.dot(att_d)), as_i = row16_sum(zi.dot(att_s));
+    att_s.scale(GAT_LOG2E);
+    const float ad2 = ad * GAT_LOG2E;
+    const int kbit = 1 << k;
     float m = lrelu(ad + as_i, slope) * GAT_LOG2E, lsum = 1.f;          // the node's own loop starts the running softmax
     V acc = zi;
-    if (DROP) acc.scale(keep_scale(seed, E + i, k, K, p, inv_keep));
+    if (DROP) { if (keep_scale(seed, E + i, k, K, p, 1.f) == 0.f) acc = V::zero(); }
     for (int base = s0; base < s1; base += 64) {
         const int sl = min(base + lane, s1 - 1);
         int jl = nbr[sl], el = DROP ? eid[sl] : 0;
         asm volatile("" : "+v"(jl), "+v"(el));
-        float kl[4] = {1.f, 1.f, 1.f, 1.f};
+        int km = 0;
         if (DROP) {
 #pragma unroll
-            for (int h = 0; h < 4; ++h) { kl[h] = keep_scale(seed, el, h, K, p, inv_keep); __builtin_amdgcn_sched_barrier(0); }   // this lane's slot, the four heads, ONE hash at a time (interleaved: +30 VGPRs)
+            for (int h = 0; h < 4; ++h) km |= keep_scale(seed, el, h, K, p, 1.f) != 0.f ? (1 << h) : 0;   // this lane's slot, the four heads
         }
         const int cnt = min(64, s1 - base);
         int q = 0;
-        for (; q + FWD_NB <= cnt; q += FWD_NB) fwd_batch<FWD_NB, DROP>(acc, m, lsum, z, att_s, ad, slope, jl, kl, q, c, k);
-#define GW_CALL(NB) fwd_batch<(NB < FWD_NB ? NB : 1), DROP>(acc, m, lsum, z, att_s, ad, slope, jl, kl, q, c, k)
+        for (; q + FWD_NB <= cnt; q += FWD_NB) fwd_batch<FWD_NB, DROP>(acc, m, lsum, z, att_s, ad2, slope, jl, km, kbit, q, c);
+#define GW_CALL(NB) fwd_batch<(NB < FWD_NB ? NB : 1), DROP>(acc, m, lsum, z, att_s, ad2, slope, jl, km, kbit, q, c)
         GW_SWITCH(cnt - q, GW_CALL)
 #undef GW_CALL
     }
     const float dn = lsum + 1e-16f;
-    acc.scale(1.f / dn);
+    acc.scale(inv_keep / dn);
     if (bias) acc.add(V::ld(bias + c));
     if (relu) acc.relu();
     acc.st(out + (size_t)i * H + c);
@@ -653,8 +726,8 @@ __global__ void __launch_bounds__(256) k_gat_fwd_w(const int* __restrict__ rowpt
 // Slot t of the row = edge s0 + t (t < deg) or the node's own loop (t = deg).  Rows of <= 64 slots (all but a few hubs of a BA
 // graph) are ONE sweep: dalpha of the slots stays in the slot lanes until S = sum alpha dalpha is known; longer rows sweep twice
 // (the second sweep gathers the z rows again instead of parking dalpha in memory).
-template <bool DROP>
-__global__ void __launch_bounds__(256) k_gat_bwd_dst_w(const int* __restrict__ rowptr, const int* __restrict__ nbr, const int* __restrict__ eid,
+template <bool DROP, int WPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_gat_bwd_dst_w(const int* __restrict__ rowptr, const int* __restrict__ nbr, const int* __restrict__ eid,
                                                        const float* __restrict__ z, const float* __restrict__ adst, const float* __restrict__ asrc,
                                                        const float* __restrict__ mx, const float* __restrict__ den, const float* __restrict__ gout,
                                                        float slope, float p, uint64_t seed, int64_t E, float* __restrict__ draw,
@@ -670,6 +743,7 @@ __global__ void __launch_bounds__(256) k_gat_bwd_dst_w(const int* __restrict__ r
     const int deg = s1 - s0, nsl = deg + 1;
     const V gi = V::ld(gout + (size_t)i * H + c);
     const float4 ad4 = ld4(adst + (size_t)i * K), m4 = ld4(mx + (size_t)i * K), dn4 = ld4(den + (size_t)i * K);     // uniform addresses
+    const float4 rdn4 = make_float4(1.f / dn4.x, 1.f / dn4.y, 1.f / dn4.z, 1.f / dn4.w);      // once per row (uniform values)
     const float inv_keep = DROP ? 1.f / (1.f - p) : 1.f;
     float al[4], da[4], raw[4];
     int idl = 0;
@@ -696,12 +770,15 @@ __global__ void __launch_bounds__(256) k_gat_bwd_dst_w(const int* __restrict__ r
             for (int u = 0; u < NB; ++u) zv[u] = V::ld(z + (size_t)__builtin_amdgcn_readlane(jl, q + u) * H + c);
 #pragma unroll
             for (int u = 0; u < NB; ++u) zv[u].pin();
+            float dot[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) dot[u] = gi.dot(zv[u]);
+            row16_sum_b<NB>(dot);                                       // <g_i, z_j> per head, in every lane of the head
 #pragma unroll
             for (int u = 0; u < NB; ++u) {
-                const float dot = row16_sum(gi.dot(zv[u]));             // <g_i, z_j> per head, in every lane of the head
                 const bool mine = lane == q + u;                        // ... and into the slot's lane (one compare, four selects)
 #pragma unroll
-                for (int h = 0; h < 4; ++h) dal[h] = mine ? rdl(dot, 16 * h) : dal[h];
+                for (int h = 0; h < 4; ++h) dal[h] = mine ? rdl(dot[u], 16 * h) : dal[h];
             }
         };
         int q = 0;
@@ -712,28 +789,37 @@ __global__ void __launch_bounds__(256) k_gat_bwd_dst_w(const int* __restrict__ r
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             raw[h] = comp(ad4, h) + comp(as4, h);
-            al[h] = valid ? exp2f((lrelu(raw[h], slope) - comp(m4, h)) * GAT_LOG2E) / comp(dn4, h) : 0.f;
+            // (the exponent is <= 0 up to rounding: m is the row maximum -- the raw v_exp_f32 without exp2f's denormal-range rescue)
+            al[h] = valid ? __builtin_amdgcn_exp2f((lrelu(raw[h], slope) - comp(m4, h)) * GAT_LOG2E) * comp(rdn4, h) : 0.f;
             da[h] = dal[h] * (DROP ? keep_scale(seed, idl, h, K, p, inv_keep) : 1.f);
             if (DROP) __builtin_amdgcn_sched_barrier(0);
         }
     };
     float S[4] = {0.f, 0.f, 0.f, 0.f}, rowsum[4] = {0.f, 0.f, 0.f, 0.f};
     auto finish = [&]() {
-        float de[4];
+        float de[4], ds[4];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) { de[h] = al[h] * (da[h] - S[h]) * (raw[h] > 0.f ? 1.f : slope); rowsum[h] += wave_sum(de[h]); }
+        for (int h = 0; h < 4; ++h) { de[h] = al[h] * (da[h] - S[h]) * (raw[h] > 0.f ? 1.f : slope); ds[h] = de[h]; }
+        wave_sum4(ds);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) rowsum[h] += ds[h];
         if (valid) *reinterpret_cast<float4*>(draw + (size_t)idl * K) = make_float4(de[0], de[1], de[2], de[3]);
     };
     if (nsl <= 64) {
         chunk(0);
 #pragma unroll
-        for (int h = 0; h < 4; ++h) S[h] = wave_sum(al[h] * da[h]);
+        for (int h = 0; h < 4; ++h) S[h] = al[h] * da[h];
+        wave_sum4(S);
         finish();
     } else {
         for (int base = 0; base < nsl; base += 64) {
             chunk(base);
+            float t4[4];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) S[h] += wave_sum(al[h] * da[h]);
+            for (int h = 0; h < 4; ++h) t4[h] = al[h] * da[h];
+            wave_sum4(t4);
+#pragma unroll
+            for (int h = 0; h < 4; ++h) S[h] += t4[h];
         }
         for (int base = 0; base < nsl; base += 64) { chunk(base); finish(); }
     }
@@ -777,7 +863,7 @@ __global__ void __launch_bounds__(256) k_gat_bwd_src_w(const int* __restrict__ r
         float at[4];
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const float a = exp2f((lrelu(comp(ad4, h) + comp(as4, h), slope) - comp(m4, h)) * GAT_LOG2E) / comp(dn4, h);
+            const float a = __builtin_amdgcn_exp2f((lrelu(comp(ad4, h) + comp(as4, h), slope) - comp(m4, h)) * GAT_LOG2E) * __builtin_amdgcn_rcpf(comp(dn4, h));   // (v_rcp_f32: 1 ulp)
             at[h] = valid ? a * (DROP ? keep_scale(seed, idl, h, K, p, inv_keep) : 1.f) : 0.f;
             das[h] += valid ? comp(dr4, h) : 0.f;
             if (DROP) __builtin_amdgcn_sched_barrier(0);
@@ -933,6 +1019,11 @@ static void gat_fused_launch(int lh, hipStream_t stream, A... a) {
 }  // namespace cal
 
 namespace cal {
+// EXPERIMENT switch (round 4, last session): occupancy target of the wave-per-row kernels (CAL_AMD_GAT_WPE = 5 | 7 | 8)
+static int gat_wpe() {
+    static const int v = [] { const char* e = getenv("CAL_AMD_GAT_WPE"); return e ? atoi(e) : 8; }();
+    return v;
+}
 int gat_forward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst, const float* z,
                 const float* att, const float* bias, int relu, float slope, float p, uint64_t seed, const uint64_t* ctr,
                 float* out, float* adst, float* asrc, float* mx, float* den, int64_t N, int64_t E,
@@ -944,9 +1035,9 @@ int gat_forward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t
     bool vec_ok = (D % 4 == 0) && aligned16(z) && aligned16(out) && (!bias || aligned16(bias));
     if (vec_ok && K == 4 && D == 64 && aligned16(att) && aligned16(adst) && aligned16(asrc) && aligned16(mx) && aligned16(den)) {
         // H = 256, four heads: one wave per row, slots in lanes (k_gat_fwd_w)
-        if (p > 0.f) hipLaunchKernelGGL((k_gat_fwd_w<true>), dim3(cdiv(N, 4)), dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, att, bias, relu,
+        if (p > 0.f) hipLaunchKernelGGL((k_gat_fwd_w<true, 8>), dim3(cdiv(N, 4)), dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, att, bias, relu,
                                         slope, p, seed, E, out, adst, asrc, mx, den, (int)N, ctr);
-        else hipLaunchKernelGGL((k_gat_fwd_w<false>), dim3(cdiv(N, 4)), dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, att, bias, relu,
+        else hipLaunchKernelGGL((k_gat_fwd_w<false, 8>), dim3(cdiv(N, 4)), dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, att, bias, relu,
                                 slope, p, seed, E, out, adst, asrc, mx, den, (int)N, ctr);
         CAL_CHECK_LAUNCH("k_gat_fwd_w");
         return 0;
@@ -1020,13 +1111,18 @@ int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_
                                aligned16(draw) && E + N < (1ll << 31);
         if (wave_rows) {
             const dim3 grid(cdiv(N, 4));
-            if (p > 0.f) {
-                hipLaunchKernelGGL((k_gat_bwd_dst_w<true>), grid, dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, adst, asrc, mx, den, gout,
+            if (p > 0.f && gat_wpe() >= 7) {
+                hipLaunchKernelGGL((k_gat_bwd_dst_w<true, 7>), grid, dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, adst, asrc, mx, den, gout,
+                                   slope, p, seed, E, draw, dadst, (int)N, ctr);
+                hipLaunchKernelGGL((k_gat_bwd_src_w<true>), grid, dim3(256), 0, stream, rowptr_src, nbr_src, eid_src, att, adst, asrc, mx, den, gout,
+                                   dadst, draw, dasrc, slope, p, seed, E, dz, (int)N, ctr);
+            } else if (p > 0.f) {
+                hipLaunchKernelGGL((k_gat_bwd_dst_w<true, 6>), grid, dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, adst, asrc, mx, den, gout,
                                    slope, p, seed, E, draw, dadst, (int)N, ctr);
                 hipLaunchKernelGGL((k_gat_bwd_src_w<true>), grid, dim3(256), 0, stream, rowptr_src, nbr_src, eid_src, att, adst, asrc, mx, den, gout,
                                    dadst, draw, dasrc, slope, p, seed, E, dz, (int)N, ctr);
             } else {
-                hipLaunchKernelGGL((k_gat_bwd_dst_w<false>), grid, dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, adst, asrc, mx, den, gout,
+                hipLaunchKernelGGL((k_gat_bwd_dst_w<false, 7>), grid, dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, adst, asrc, mx, den, gout,
                                    slope, p, seed, E, draw, dadst, (int)N, ctr);
                 hipLaunchKernelGGL((k_gat_bwd_src_w<false>), grid, dim3(256), 0, stream, rowptr_src, nbr_src, eid_src, att, adst, asrc, mx, den, gout,
                                    dadst, draw, dasrc, slope, p, seed, E, dz, (int)N, ctr);
