@@ -627,13 +627,14 @@ __device__ __forceinline__ void wave_sum4(float (&v)[4]) {
     for (int h = 0; h < 4; ++h) { v[h] += __shfl_xor(v[h], 16, 64); v[h] += __shfl_xor(v[h], 32, 64); }
 }
 
-// att_s / ad arrive scaled by log2(e) (lrelu is positively homogeneous: lrelu(x) log2e = lrelu(x log2e)), km = this lane's slot's
-// keep decisions of the four heads as bits 0..3, kbit = 1 << (this lane's head): a dropped (slot, head) adds nothing to the row,
-// the kept ones are scaled by 1 / (1 - p) once per row (after the loop) -- one v_readlane + and / compare / select per slot
-// instead of four v_readlane + three selects + a multiply (the kernel is VALU-co-bound at eight waves per SIMD).
+// att_s / ad arrive scaled by log2(e) (lrelu is positively homogeneous: lrelu(x) log2e = lrelu(x log2e)).  hm = the keep decisions
+// of this lane's HEAD for the chunk's 64 slots, one bit per slot: a dropped (slot, head) adds nothing to the row, the kept ones
+// are scaled by 1 / (1 - p) once per row (after the loop).  The kernel is VALU-co-bound at eight waves per SIMD: the decisions
+// come from ONE hash per 16 slots (lane (head, l) hashes slot 16 g + l for its head; a ballot and two shifts put the head's 16
+// bits into every lane of the head) instead of four per slot lane -- a row of <= 16 slots paid 64 VALU instructions for them.
 template <int NB, bool DROP>
 __device__ __forceinline__ void fwd_batch(Vec<4>& acc, float& m, float& lsum, const float* __restrict__ z, const Vec<4>& att_s, float ad,
-                                          float slope, int jl, int km, int kbit, int q, int c) {
+                                          float slope, int jl, uint64_t hm, int q, int c) {
     Vec<4> zv[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) zv[u] = Vec<4>::ld(z + (size_t)__builtin_amdgcn_readlane(jl, q + u) * H + c);
@@ -653,7 +654,7 @@ __device__ __forceinline__ void fwd_batch(Vec<4>& acc, float& m, float& lsum, co
     for (int u = 0; u < NB; ++u) {
         const float pe = __builtin_amdgcn_exp2f(e[u] - mn);
         lsum += pe;
-        const float pk = DROP ? ((__builtin_amdgcn_readlane(km, q + u) & kbit) ? pe : 0.f) : pe;
+        const float pk = DROP ? (((hm >> (q + u)) & 1ull) ? pe : 0.f) : pe;
         acc.fma(pk, zv[u]);
     }
     m = mn;
@@ -686,23 +687,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
     const float ad = row16_sum(zi.dot(att_d)), as_i = row16_sum(zi.dot(att_s));
     att_s.scale(GAT_LOG2E);
     const float ad2 = ad * GAT_LOG2E;
-    const int kbit = 1 << k;
     float m = lrelu(ad + as_i, slope) * GAT_LOG2E, lsum = 1.f;          // the node's own loop starts the running softmax
     V acc = zi;
     if (DROP) { if (keep_scale(seed, E + i, k, K, p, 1.f) == 0.f) acc = V::zero(); }
     for (int base = s0; base < s1; base += 64) {
         const int sl = min(base + lane, s1 - 1);
-        int jl = nbr[sl], el = DROP ? eid[sl] : 0;
-        asm volatile("" : "+v"(jl), "+v"(el));
-        int km = 0;
-        if (DROP) {
-#pragma unroll
-            for (int h = 0; h < 4; ++h) km |= keep_scale(seed, el, h, K, p, 1.f) != 0.f ? (1 << h) : 0;   // this lane's slot, the four heads
-        }
+        int jl = nbr[sl], eg = DROP ? eid[min(base + (lane & 15), s1 - 1)] : 0;      // eg: edge id of slot (lane & 15), the first group
+        asm volatile("" : "+v"(jl), "+v"(eg));
         const int cnt = min(64, s1 - base);
+        uint64_t hm = 0;
+        if (DROP) {
+            for (int g = 0; 16 * g < cnt; ++g) {
+                if (g > 0) eg = eid[min(base + 16 * g + (lane & 15), s1 - 1)];
+                const uint64_t b = __ballot(keep_scale(seed, eg, k, K, p, 1.f) != 0.f);       // bit 16 head + l: (slot 16 g + l, head)
+                const uint32_t w = (k & 2) ? (uint32_t)(b >> 32) : (uint32_t)b;
+                hm |= (uint64_t)((w >> ((k & 1) * 16)) & 0xffffu) << (16 * g);
+            }
+        }
         int q = 0;
-        for (; q + FWD_NB <= cnt; q += FWD_NB) fwd_batch<FWD_NB, DROP>(acc, m, lsum, z, att_s, ad2, slope, jl, km, kbit, q, c);
-#define GW_CALL(NB) fwd_batch<(NB < FWD_NB ? NB : 1), DROP>(acc, m, lsum, z, att_s, ad2, slope, jl, km, kbit, q, c)
+        for (; q + FWD_NB <= cnt; q += FWD_NB) fwd_batch<FWD_NB, DROP>(acc, m, lsum, z, att_s, ad2, slope, jl, hm, q, c);
+#define GW_CALL(NB) fwd_batch<(NB < FWD_NB ? NB : 1), DROP>(acc, m, lsum, z, att_s, ad2, slope, jl, hm, q, c)
         GW_SWITCH(cnt - q, GW_CALL)
 #undef GW_CALL
     }
@@ -742,9 +746,58 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE)))
     const int s0 = rowptr[i], s1 = rowptr[i + 1];
     const int deg = s1 - s0, nsl = deg + 1;
     const V gi = V::ld(gout + (size_t)i * H + c);
+    const float inv_keep = DROP ? 1.f / (1.f - p) : 1.f;
+    if (nsl <= 16) {
+        // Rows of at most 16 slots (98 % of a BA graph's rows): lane (head k, l) owns (slot l, head k) -- ONE logit, exp, hash and
+        // d(raw logit) per lane instead of four per slot lane (the VALU cost of a wave instruction does not depend on how many
+        // lanes are on: a 5-slot row paid 4 x 64-lane instructions for 5 x 4 values), a head's dot product moves into its slot
+        // lane by one compare + select, and the two row reductions are 16-lane DPP sums inside the head.
+        const int k = lane >> 4, l = lane & 15;
+        const bool valid = l < nsl;
+        int jl = i, el = 0;
+        if (deg > 0) {
+            const int se = s0 + min(l, deg - 1);
+            jl = nbr[se]; el = eid[se];
+            asm volatile("" : "+v"(jl), "+v"(el));
+            if (l >= deg) jl = i;
+        }
+        const int idl = l < deg ? el : (int)E + i;
+        const float as = asrc[(size_t)jl * K + k];
+        const float adk = adst[(size_t)i * K + k], mk = mx[(size_t)i * K + k], dnk = den[(size_t)i * K + k];
+        float dal = 0.f;
+        auto batch = [&](auto nbc, int q) {
+            constexpr int NB = decltype(nbc)::value;
+            V zv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) zv[u] = V::ld(z + (size_t)__builtin_amdgcn_readlane(jl, q + u) * H + c);
+#pragma unroll
+            for (int u = 0; u < NB; ++u) zv[u].pin();
+            float dot[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) dot[u] = gi.dot(zv[u]);
+            row16_sum_b<NB>(dot);                                       // <g_i, z_j> of the lane's head, in its 16 lanes
+#pragma unroll
+            for (int u = 0; u < NB; ++u) dal = l == q + u ? dot[u] : dal;
+        };
+        int q = 0;
+        for (; q + 8 <= nsl; q += 8) batch(std::integral_constant<int, 8>(), q);
+#define GW_CALL(NB) batch(std::integral_constant<int, NB>(), q)
+        GW_SWITCH(nsl - q, GW_CALL)
+#undef GW_CALL
+        const float raw = adk + as;
+        const float al = valid ? __builtin_amdgcn_exp2f((lrelu(raw, slope) - mk) * GAT_LOG2E) / dnk : 0.f;
+        const float da = dal * (DROP ? keep_scale(seed, idl, k, K, p, inv_keep) : 1.f);
+        float s1[1] = {al * da};
+        row16_sum_n<1>(s1);
+        const float de = al * (da - s1[0]) * (raw > 0.f ? 1.f : slope);
+        float r1[1] = {de};
+        row16_sum_n<1>(r1);
+        if (valid) draw[(size_t)idl * K + k] = de;
+        if (l == 0) dadst[(size_t)i * K + k] = r1[0];
+        return;
+    }
     const float4 ad4 = ld4(adst + (size_t)i * K), m4 = ld4(mx + (size_t)i * K), dn4 = ld4(den + (size_t)i * K);     // uniform addresses
     const float4 rdn4 = make_float4(1.f / dn4.x, 1.f / dn4.y, 1.f / dn4.z, 1.f / dn4.w);      // once per row (uniform values)
-    const float inv_keep = DROP ? 1.f / (1.f - p) : 1.f;
     float al[4], da[4], raw[4];
     int idl = 0;
     bool valid = false;
