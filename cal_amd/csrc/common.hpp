@@ -24,10 +24,43 @@ inline int group_for(int H, int vec) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Reductions over aligned groups of G lanes (G a power of two <= 64; every lane of the group gets the same bits).  Inside a DPP row
+// of 16 lanes: four FUSED v_add_f32_dpp / v_max_f32_dpp steps -- quad_perm xor 1, quad_perm xor 2, row_half_mirror (l <-> 7 - l: the
+// other quad of the eight), row_mirror (l <-> 15 - l: the other eight) -- ~10 cycles each; across rows: the four row totals by
+// v_readlane and two or three adds.  The __shfl_xor form this replaces is one ds_bpermute_b32 per step (address arithmetic + an LDS
+// crossbar pass of ~100 cycles of dependent latency, and LDS-pipe time: k_node_att_fwd issued 36 of them per row).  A DPP read
+// needs two wait states behind the VALU write of its source, which the compiler cannot see into an asm for: s_nop 1 in front.
+#define CAL_DPP_STEP(NAME, OP, CTRL)                                                                                      \
+    __device__ __forceinline__ float NAME(float v) {                                                                      \
+        float r;                                                                                                          \
+        asm("s_nop 1\n\t" OP " %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));                       \
+        return r;                                                                                                         \
+    }
+CAL_DPP_STEP(dpp_add_x1, "v_add_f32_dpp", "quad_perm:[1,0,3,2]")
+CAL_DPP_STEP(dpp_add_x2, "v_add_f32_dpp", "quad_perm:[2,3,0,1]")
+CAL_DPP_STEP(dpp_add_hm, "v_add_f32_dpp", "row_half_mirror")
+CAL_DPP_STEP(dpp_add_rm, "v_add_f32_dpp", "row_mirror")
+CAL_DPP_STEP(dpp_max_x1, "v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+CAL_DPP_STEP(dpp_max_x2, "v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+CAL_DPP_STEP(dpp_max_hm, "v_max_f32_dpp", "row_half_mirror")
+CAL_DPP_STEP(dpp_max_rm, "v_max_f32_dpp", "row_mirror")
+#undef CAL_DPP_STEP
+__device__ __forceinline__ float rdlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "group of 1..64 lanes, a power of two");
+    if constexpr (G >= 2) v = dpp_add_x1(v);
+    if constexpr (G >= 4) v = dpp_add_x2(v);
+    if constexpr (G >= 8) v = dpp_add_hm(v);
+    if constexpr (G >= 16) v = dpp_add_rm(v);
+    if constexpr (G == 32) {
+        const float lo = rdlane_f(v, 0) + rdlane_f(v, 16), hi = rdlane_f(v, 32) + rdlane_f(v, 48);
+        v = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 32u) ? hi : lo;     // (lane id)
+    }
+    if constexpr (G == 64) v = (rdlane_f(v, 0) + rdlane_f(v, 16)) + (rdlane_f(v, 32) + rdlane_f(v, 48));
     return v;
 }
 
@@ -40,8 +73,16 @@ __device__ __forceinline__ double group_sum_d(double v) {
 
 template <int G>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "group of 1..64 lanes, a power of two");
+    if constexpr (G >= 2) v = dpp_max_x1(v);
+    if constexpr (G >= 4) v = dpp_max_x2(v);
+    if constexpr (G >= 8) v = dpp_max_hm(v);
+    if constexpr (G >= 16) v = dpp_max_rm(v);
+    if constexpr (G == 32) {
+        const float lo = fmaxf(rdlane_f(v, 0), rdlane_f(v, 16)), hi = fmaxf(rdlane_f(v, 32), rdlane_f(v, 48));
+        v = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 32u) ? hi : lo;     // (lane id)
+    }
+    if constexpr (G == 64) v = fmaxf(fmaxf(rdlane_f(v, 0), rdlane_f(v, 16)), fmaxf(rdlane_f(v, 32), rdlane_f(v, 48)));
     return v;
 }
 

@@ -269,20 +269,7 @@ struct SpmmBranch2 { SpmmBranch b[2]; };
 // scripts/micro/gather_lds.hip, profiles/r4/micro_gather_lds.txt: 128 -> 101 us at config 5 (32 BA graphs of 5000 nodes, H = 256).
 // sum over the G lanes (8..64, a power of two) of a lane group; every lane of the group gets the total
 template <int G>
-__device__ __forceinline__ float group_dot_sum(float d) {
-    if constexpr (G >= 16) {
-        d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x128, 0xf, 0xf, false));   // row_ror:8
-        d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x124, 0xf, 0xf, false));
-        d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x122, 0xf, 0xf, false));
-        d += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, d), 0x121, 0xf, 0xf, false));
-        if constexpr (G >= 32) d += __shfl_xor(d, 16, 64);
-        if constexpr (G >= 64) d += __shfl_xor(d, 32, 64);
-    } else {
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-    }
-    return d;
-}
+__device__ __forceinline__ float group_dot_sum(float d) { return group_sum<G>(d); }     // (common.hpp: fused DPP steps + row totals by v_readlane)
 // relu'(h) * g, elementwise: the row of d(conv output) that belongs to activation row h under pooled-row gradient g
 __device__ __forceinline__ void pool_bwd_row(Vec<4>& h, const Vec<4>& g) {
     h.v.x = h.v.x > 0.f ? g.v.x : 0.f; h.v.y = h.v.y > 0.f ? g.v.y : 0.f;
