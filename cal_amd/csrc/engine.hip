@@ -1029,8 +1029,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             if (c.training && i < L) {
                 int tc = std::min(256, pow2ceil(H));
                 int rpb = std::max(32, cdiv(N, 1024));
-                static const bool cs4 = [] { const char* v = getenv("CAL_AMD_COLSTATS4"); return !(v && v[0] == '0'); }();
-                if (cs4 && H == 256 && aligned16(hi))
+                if (H == 256 && aligned16(hi))
                     hipLaunchKernelGGL(k_colstats4, dim3(cdiv(N, rpb)), dim3(256), 0, st, hi, N, rpb, Acc(bn_stsum(c, i + 1)), Acc(bn_stsq(c, i + 1)));
                 else
                     hipLaunchKernelGGL(k_colstats, dim3(cdiv(N, rpb)), dim3(256), 0, st, hi, N, H, tc, rpb, Acc(bn_stsum(c, i + 1)), Acc(bn_stsq(c, i + 1)));

@@ -661,11 +661,14 @@ __device__ __forceinline__ void fwd_batch(Vec<4>& acc, float& m, float& lsum, co
 }
 }  // namespace gw
 
-constexpr int FWD_NB = 4;      // z rows in flight per wave in the forward (8: 100 VGPRs, 4 waves per SIMD)
+constexpr int FWD_NB = 4;      // z rows in flight per wave in the forward (8: spills at seven / eight waves per SIMD)
 #define GW_SWITCH(REM, CALL) switch (REM) { case 7: CALL(7); break; case 6: CALL(6); break; case 5: CALL(5); break; case 4: CALL(4); break; \
                                             case 3: CALL(3); break; case 2: CALL(2); break; case 1: CALL(1); break; default: break; }
 
-// GATConv forward, one pass (a_src of a neighbour recomputed from the z row the aggregation fetches, online edge softmax)
+// GATConv forward, one pass (a_src of a neighbour recomputed from the z row the aggregation fetches, online edge softmax).
+// WPE: waves per SIMD the register allocator has to make room for (amdgpu_waves_per_eu): a wave is a chain of ~4 dependent round
+// trips per row, so the kernels are as fast as the number of rows in flight until VALU issue or the fabric takes over
+// (forward: 5 -> 8 waves 178 -> 160 us, then the VALU diet above 160 -> 135 us; by-destination backward 6 -> 7 waves 213 -> 206 us).
 template <bool DROP, int WPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) k_gat_fwd_w(const int* __restrict__ rowptr, const int* __restrict__ nbr, const int* __restrict__ eid,
                                                    const float* __restrict__ z, const float* __restrict__ att, const float* __restrict__ bias,
@@ -1072,11 +1075,6 @@ static void gat_fused_launch(int lh, hipStream_t stream, A... a) {
 }  // namespace cal
 
 namespace cal {
-// EXPERIMENT switch (round 4, last session): occupancy target of the wave-per-row kernels (CAL_AMD_GAT_WPE = 5 | 7 | 8)
-static int gat_wpe() {
-    static const int v = [] { const char* e = getenv("CAL_AMD_GAT_WPE"); return e ? atoi(e) : 8; }();
-    return v;
-}
 int gat_forward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_t* eid_dst, const float* z,
                 const float* att, const float* bias, int relu, float slope, float p, uint64_t seed, const uint64_t* ctr,
                 float* out, float* adst, float* asrc, float* mx, float* den, int64_t N, int64_t E,
@@ -1164,13 +1162,8 @@ int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_
                                aligned16(draw) && E + N < (1ll << 31);
         if (wave_rows) {
             const dim3 grid(cdiv(N, 4));
-            if (p > 0.f && gat_wpe() >= 7) {
+            if (p > 0.f) {
                 hipLaunchKernelGGL((k_gat_bwd_dst_w<true, 7>), grid, dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, adst, asrc, mx, den, gout,
-                                   slope, p, seed, E, draw, dadst, (int)N, ctr);
-                hipLaunchKernelGGL((k_gat_bwd_src_w<true>), grid, dim3(256), 0, stream, rowptr_src, nbr_src, eid_src, att, adst, asrc, mx, den, gout,
-                                   dadst, draw, dasrc, slope, p, seed, E, dz, (int)N, ctr);
-            } else if (p > 0.f) {
-                hipLaunchKernelGGL((k_gat_bwd_dst_w<true, 6>), grid, dim3(256), 0, stream, rowptr_dst, nbr_dst, eid_dst, z, adst, asrc, mx, den, gout,
                                    slope, p, seed, E, draw, dadst, (int)N, ctr);
                 hipLaunchKernelGGL((k_gat_bwd_src_w<true>), grid, dim3(256), 0, stream, rowptr_src, nbr_src, eid_src, att, adst, asrc, mx, den, gout,
                                    dadst, draw, dasrc, slope, p, seed, E, dz, (int)N, ctr);
