@@ -230,7 +230,9 @@ def test_gat_h256_four_heads_hub_rows_and_isolated_nodes(p_drop):
     from cal_amd.data import Batch, Data
     g = torch.Generator().manual_seed(21)
     ds = []
-    for n, hub_deg in ((200, 150), (90, 70), (5, 0)):
+    # (40, 14..16) / (40, 31..32): stars WITHOUT extra edges at the hub -- in-degree exactly 14 / 15 / 16 / 31 / 32, i.e. 15, 16 (the
+    # (head, slot) lane layout of the by-destination backward and one 16-slot hash group), 17, 32 and 33 slots with the node's own loop
+    for n, hub_deg in ((200, 150), (90, 70), (5, 0), (40, 14), (40, 15), (40, 16), (40, 31), (40, 32)):
         src, dst = [], []
         for v in range(1, hub_deg + 1):                      # star around node 0, both directions
             src += [0, v]; dst += [v, 0]
@@ -246,6 +248,7 @@ def test_gat_h256_four_heads_hub_rows_and_isolated_nodes(p_drop):
     pl = _plan(b)
     deg_dst = (pl.rowptr_dst[1:] - pl.rowptr_dst[:-1]).cpu()
     assert int(deg_dst.max()) > 128 and int((deg_dst > 63).sum()) >= 2 and int((deg_dst == 0).sum()) >= 2
+    assert all(int((deg_dst == d).sum()) >= 1 for d in (14, 15, 16, 31, 32))
     z = (b.x * 0.5).clone().requires_grad_(True)
     att = (torch.randn(1, K, 2 * D, generator=g) * 0.3).requires_grad_(True)
     bias = torch.randn(H, generator=g).requires_grad_(True)
