@@ -356,7 +356,8 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     // (per-graph fused backward: one [M,N] slab per graph)
     // (big batches: one slab per 1024-node split-K slice of the 128x128 gradient kernel, gemm_big.hip)
     auto slab_of = [&](size_t M, size_t Nn) {
-        const size_t big = gemm_big_grad((int)M, (int)Nn, (int)N) ? (size_t)gemm_big_grad_splits((int)N) * M * Nn : 0;
+        const size_t big = gemm_wres_grad((int)M, (int)Nn, (int)N) ? (size_t)gemm_wres_grad_splits((int)N, 1) * M * Nn
+                         : gemm_big_grad((int)M, (int)Nn, (int)N) ? (size_t)gemm_big_grad_splits((int)N) * M * Nn : 0;
         return std::max<size_t>(std::max<size_t>(512 * 64 * 64, (size_t)B * M * Nn), big) + 2 * M * Nn;
     };
     slab += slab_of(F, H) + (L + 2) * slab_of(H, H) + 2 * slab_of(H, H) + slab_of(H, 2 * H) + 3 * slab_of(C, H);
@@ -544,7 +545,7 @@ int fwd_gemm(Ctx& c, bool transB, const GemmArgs& a, int nbatch) {
 // same for a GEMM epilogue (two sums per column, P = row tiles)
 void gemm_stats(Ctx& c, GemmProb& pr, int M, int N, double* d0, double* d1, bool dot, int K = 0) {
     if (dot) { pr.dot_sum = d0; pr.dot_prod = d1; } else { pr.st_sum = d0; pr.st_sq = d1; }
-    const int P = use_ks(M) ? gemm_ks_row_tiles(M) : gemm_row_tiles(M, K);
+    const int P = use_ks(M) ? gemm_ks_row_tiles(M) : gemm_row_tiles(M, N, K);
     if ((size_t)P * N * 2 <= 4096) return;
     double* p = parts_alloc(c, (size_t)P * 2 * N);
     if (!p) return;
@@ -1850,7 +1851,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         a.p[0].aux = x0; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, 0, N, 0);
         a.p[0].dot_sum = bn_dsum(c, 0); a.p[0].dot_prod = bn_dprod(c, 0);
         {   // bn_feat's sums are only needed by the commit: keep the partial rows, no finalise launch
-            const int P0 = use_ks(N) ? gemm_ks_row_tiles(N) : gemm_row_tiles(N, H);
+            const int P0 = use_ks(N) ? gemm_ks_row_tiles(N) : gemm_row_tiles(N, F, H);
             if ((size_t)P0 * F * 2 > 4096) {
                 d_bn0.p = parts_alloc(c, (size_t)P0 * 2 * F); d_bn0.P = P0; d_bn0.stride = 2 * F;
                 a.p[0].parts = d_bn0.p;

@@ -176,13 +176,19 @@ int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStre
 int launch_gemm_dual(const GemmArgs& ax, int nbx, const GemmArgs& aw, int nbw, hipStream_t stream);
 int splitk_for(int64_t M, int64_t N, int64_t K, int nbatch);
 void gemm_set_split(GemmArgs& a, int S);
-int gemm_row_tiles(int M, int K);
+int gemm_row_tiles(int M, int N, int K);
 // throughput variant (gemm_big.hip): 128x128 tiles for node-level products with >= 16k rows; 1 launched, 0 n/a, < 0 error
 bool gemm_big_rows(int M, int K);
 bool gemm_big_grad(int M, int N, int K);
 int gemm_big_grad_splits(int K);
 int launch_gemm_big(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStream_t stream);
 int launch_gemm_big_dual(const GemmArgs& ax, int nbx, const GemmArgs& aw, int nbw, hipStream_t stream);
+// weight-resident / direct-operand variants (gemm_wres.hip): hidden width 128 / 256, >= 16k rows; same return convention
+bool gemm_wres_rows(int M, int N, int K);
+bool gemm_wres_grad(int M, int N, int K);
+int gemm_wres_grad_splits(int K, int nbatch);
+int gemm_wres_parts();
+int launch_gemm_wres(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStream_t stream);
 // latency-oriented variant (gemm_ks.hip): 32x32 tiles, K split across the four waves
 int launch_gemm_ks(bool transB, const GemmArgs& a, int nbatch, hipStream_t stream);
 int gemm_ks_row_tiles(int M);

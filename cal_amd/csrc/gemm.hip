@@ -424,7 +424,7 @@ __global__ void k_splitk_reduce(const float* __restrict__ part, float* __restric
 }
 
 // row tiles of a node-level GEMM (= partial statistic rows its epilogue writes): 128-row tiles on the throughput kernel
-int gemm_row_tiles(int M, int K) { return gemm_big_rows(M, K) ? cdiv(M, 128) : cdiv(M, BM); }
+int gemm_row_tiles(int M, int N, int K) { return gemm_wres_rows(M, N, K) ? gemm_wres_parts() : gemm_big_rows(M, K) ? cdiv(M, 128) : cdiv(M, BM); }
 
 template <bool A_KC, bool B_KC, int XA, int XB>
 static void launch_one(const GemmArgs& a, dim3 grid, int vecA, int vecB, hipStream_t stream) {
@@ -456,6 +456,10 @@ static int gemm_classify(bool a_kc, bool b_kc, const GemmArgs& a, int nbatch, in
 int launch_gemm_dual(const GemmArgs& ax, int nbx, const GemmArgs& aw, int nbw, hipStream_t stream) {
     if (ax.M == 0 || ax.N == 0 || nbx == 0) return launch_gemm(true, false, aw, nbw, stream);
     if (aw.M == 0 || aw.N == 0 || nbw == 0) return launch_gemm(false, true, ax, nbx, stream);
+    if (gemm_wres_rows(ax.M, ax.N, ax.K) || gemm_wres_grad(aw.M, aw.N, aw.K)) {     // weight-resident kernels: one launch each
+        if (int rc = launch_gemm(false, true, ax, nbx, stream)) return rc;
+        return launch_gemm(true, false, aw, nbw, stream);
+    }
     if (int r = launch_gemm_big_dual(ax, nbx, aw, nbw, stream)) return r < 0 ? 2 : 0;
     if (gemm_big_rows(ax.M, ax.K) || gemm_big_grad(aw.M, aw.N, aw.K)) {      // one of the two alone
         if (int rc = launch_gemm(false, true, ax, nbx, stream)) return rc;
@@ -479,6 +483,10 @@ int launch_gemm_dual(const GemmArgs& ax, int nbx, const GemmArgs& aw, int nbw, h
 
 int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStream_t stream) {
     if (a.M == 0 || a.N == 0 || nbatch == 0) return 0;
+    if (int r = launch_gemm_wres(transA, transB, a, nbatch, stream)) return r < 0 ? 2 : 0;
+    if (!transA && gemm_wres_rows(a.M, a.N, a.K))
+        for (int b = 0; b < nbatch; ++b)
+            if (a.p[b].parts) { set_error("launch_gemm: statistics rows were sized for the weight-resident kernel, which cannot take this launch"); return 2; }
     if (int r = launch_gemm_big(transA, transB, a, nbatch, stream)) return r < 0 ? 2 : 0;
     if (!transA && gemm_big_rows(a.M, a.K))
         for (int b = 0; b < nbatch; ++b)
@@ -514,6 +522,7 @@ int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStre
 
 // split-K factor for a weight-gradient GEMM: aim at ~256 workgroups, >= 4 K tiles per slice
 int splitk_for(int64_t M, int64_t N, int64_t K, int nbatch) {
+    if (K < (1ll << 31) && gemm_wres_grad((int)M, (int)N, (int)K)) return gemm_wres_grad_splits((int)K, nbatch);
     if (K < (1ll << 31) && gemm_big_grad((int)M, (int)N, (int)K)) return gemm_big_grad_splits((int)K);
     int64_t tiles = (int64_t)cdiv(M, BM) * cdiv(N, BN) * nbatch;
     if (tiles >= 128 || K <= 8 * BK) return 1;

@@ -194,9 +194,12 @@ def test_causal_gin_matches_oracle():
 def test_linear_op_matches_torch():
     from cal_amd import ops
     g = torch.Generator().manual_seed(0)
-    # the last three take the 128x128 throughput kernel (gemm_big.hip: >= 16k rows, K % 32 == 0), ragged edges included
+    # (16391, 64, 132) and (33000, 96, 64) take the 128x128 throughput kernel (gemm_big.hip: >= 16k rows, K % 32 == 0), ragged
+    # edges included; the shapes with K, N in {128, 256} and >= 16k rows the weight-resident kernels (gemm_wres.hip: k_wres NN / NT
+    # with whole and partial (M % 32 != 0) last row blocks, k_tn for the 256 x 256 weight gradient)
     for (M_, K, N) in [(130, 10, 128), (7000, 128, 128), (64, 128, 4), (257, 96, 33),
-                       (20000, 256, 256), (16391, 64, 132), (33000, 96, 64)]:
+                       (20000, 256, 256), (16391, 64, 132), (33000, 96, 64),
+                       (20011, 256, 256), (17000, 128, 128), (16500, 128, 256), (16401, 256, 128)]:
         x = torch.randn(M_, K, generator=g).to(DEV).requires_grad_(True)
         w = (torch.randn(N, K, generator=g) * 0.1).to(DEV).requires_grad_(True)
         b = torch.randn(N, generator=g).to(DEV).requires_grad_(True)
