@@ -28,7 +28,7 @@ HOST_SYMBOLS = ("cal_last_error", "cal_version", "cal_plan_build", "cal_graph_pt
                 "cal_colsum_parts", "cal_relu_bwd_colsum", "cal_gcn_norm_bwd", "cal_gemm_ws", "cal_gemm", "cal_gemm_ks",
                 "cal_edge_att_fwd", "cal_edge_att_bwd_ws", "cal_edge_att_bwd", "cal_node_att_split_fwd",
                 "cal_node_att_bwd_ws", "cal_node_att_split_bwd", "cal_add_pool_fwd", "cal_add_pool_bwd", "cal_gat_fwd",
-                "cal_gat_bwd_ws", "cal_gat_bwd", "cal_gat_dropout_mask")
+                "cal_gat_bwd_ws", "cal_gat_bwd", "cal_gat_dropout_mask", "cal_collate_host")
 
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,

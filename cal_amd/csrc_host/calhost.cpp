@@ -480,3 +480,27 @@ HOST_EXPORT int cal_gat_dropout_mask(uint64_t seed, int64_t E, int64_t N, int64_
     for (int64_t t = 0; t < (E + N) * K; ++t) mask[t] = keep_scale(seed, t / K, (int)(t % K), (int)K, p, 1.f);
     return 0;
 }
+
+// Batch.from_data_list for graphs that live in ONE host-side concatenation (train_causal.py:13-15; cal_amd/data.py::_HostConcat):
+// features copied, edge_index rebased by the running node offset, batch vector and labels written.  Same entry point as
+// libcalhip.so (collate.hip) -- it only ever sees host pointers, so a machine with the host library alone serves DataLoader too.
+HOST_EXPORT int cal_collate_host(const float* X, const int64_t* EI, int64_t Etot, int64_t F, const int64_t* node_ptr,
+                                 const int64_t* edge_ptr, const int64_t* Y, const int64_t* idx, int64_t B, float* xo,
+                                 int64_t* eio, int64_t Eout, int64_t* batcho, int64_t* yo) {
+    HOST_REQUIRE(X && EI && node_ptr && edge_ptr && Y && idx && xo && eio && batcho && yo && B >= 0 && F > 0, "bad arguments");
+    int64_t nodes = 0, edges = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t g = idx[b];
+        const int64_t nb = node_ptr[g], nn = node_ptr[g + 1] - nb, eb = edge_ptr[g], ne = edge_ptr[g + 1] - eb;
+        HOST_REQUIRE(nn >= 0 && ne >= 0 && edges + ne <= Eout, "offsets out of range");
+        std::copy(X + nb * F, X + (nb + nn) * F, xo + nodes * F);
+        const int64_t* src = EI + eb;
+        const int64_t* dst = EI + Etot + eb;
+        for (int64_t k = 0; k < ne; ++k) { eio[edges + k] = src[k] + nodes; eio[Eout + edges + k] = dst[k] + nodes; }
+        std::fill(batcho + nodes, batcho + nodes + nn, b);
+        yo[b] = Y[g];
+        nodes += nn; edges += ne;
+    }
+    HOST_REQUIRE(edges == Eout, "edge count mismatch");
+    return 0;
+}

@@ -330,9 +330,10 @@ class _HostConcat:
         o_b, o_y, o_p, o_e, o_t = 2 * E, 2 * E + N, 2 * E + N + B, 2 * E + N + 2 * B + 1, 2 * E + N + 3 * B + 2
         fbuf, ibuf, slot = self._buffers(N * F, o_t + 3 * T1)
         ia = ibuf.numpy()
+        # host pointers only -> the host library (a CPU-only machine without libcalhip.so collates too)
         _lib.call("cal_collate_host", self.X.ctypes.data, self.EI.ctypes.data, int(self.EI.shape[1]), F, self.node_ptr.ctypes.data,
                   self.edge_ptr.ctypes.data, self.Y.ctypes.data, idx.ctypes.data, B, fbuf.data_ptr(), ibuf.data_ptr(), E,
-                  ibuf.data_ptr() + 8 * o_b, ibuf.data_ptr() + 8 * o_y)
+                  ibuf.data_ptr() + 8 * o_b, ibuf.data_ptr() + 8 * o_y, host=True)
         ia[o_p:o_e] = noff
         ia[o_e:o_t] = eoff
         views = [("x" if self.feat_is_x else "feat", "f", 0, N * F, (N, F)), ("edge_index", "i", 0, 2 * E, (2, E)),
