@@ -56,6 +56,7 @@ struct FinishArgs {
     AdamArgs adam;
     AdamRange ar[MAX_ADAM_RANGES];
     int nar;
+    int* host_status;        // host-mapped mirror of status[0] | status[1], written by this kernel (cal_engine_peek_status), or null
     const int* status;       // the engine's status words: while any bit is up (this step's or a sticky earlier one) the gradients are
                              // not trusted and NO parameter / moment is updated (check_status raises and clears them)
     int blk0[MAX_SLABS + MAX_COMMITS + MAX_ADAM_RANGES + 1];   // first block of every task in the flattened 1-D grid (filled at launch)
@@ -75,6 +76,8 @@ __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __re
         fa.stats[0] = fa.wc * fa.stats[1] + fa.wo * fa.stats[2] + fa.wco * fa.stats[3];
     if (fa.tick && blockIdx.x == 0 && threadIdx.x == 0) fa.tick[0] += 1.f;
     if (fa.perm_ctr && blockIdx.x == 0 && threadIdx.x == 0) fa.perm_ctr[0] += 1;
+    if (fa.host_status && fa.status && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(fa.host_status, fa.status[0] | fa.status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // Both task kinds are pure reductions over S slabs / P partial rows: the loops keep 8 loads in flight
     // per lane (unconditional on a clamped index, pinned, masked when added) -- as dependent loops with
     // two loads in flight the 58-slab weight-gradient sums made this kernel 11 us.
@@ -162,6 +165,7 @@ struct Engine {
     unsigned long long perm_seed; unsigned long long* perm_ctr;   // device draw of the random-intervention permutation (mode bit 16)
     int64_t* perm_dev;          // [capB] the permutation drawn by the step itself
     P2PArgs p2p; int p2p_on;    // one-shot peer-memory gradient exchange (cal_engine_p2p_bind)
+    int* host_status;                 // host-mapped mirror of the status words, refreshed by every step's last kernel (cal_engine_peek_status)
     int* p2p_host_status;             // host-mapped word k_p2p_adam sets when an exchange timed out (cal_engine_p2p_status)
     int p2p_max_polls;                // bound of k_p2p_adam's flag wait (cal_engine_create: 2^22; cal_engine_p2p_set_timeout)
     float grad_scale;           // gradient factor inside Adam (1 / world_size after a sum all-reduce)
@@ -242,6 +246,8 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     }
     Engine* e = new Engine();
     memset(e, 0, sizeof(Engine));
+    if (hipHostMalloc((void**)&e->host_status, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) *e->host_status = 0;
+    else { (void)hipGetLastError(); e->host_status = nullptr; }       // (no mirror: cal_engine_peek_status reports 0, check_status still works)
     { const char* v = getenv("CAL_AMD_RO_STEP"); e->ro_step = !(v && v[0] == '0'); }
     { const char* v = getenv("CAL_AMD_RO_ROWS"); e->ro_rows = !(v && v[0] == '0'); }
     {
@@ -272,6 +278,7 @@ CAL_EXPORT void cal_engine_destroy(void* h) {
     for (int i = 0; i < 24; ++i) { hipEventDestroy(e->ev_fork[i]); hipEventDestroy(e->ev_join[i]); }
     hipStreamDestroy(e->side);
     if (e->p2p_host_status) hipHostFree(e->p2p_host_status);
+    if (e->host_status) hipHostFree(e->host_status);
     delete e;
 }
 
@@ -1247,6 +1254,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     fa.tick = (c.tick_in_finish && !c.adam_in_finish) ? e->step : nullptr;      // (adam_in_finish: k_zero_f64 did it)
     fa.perm_ctr = c.draw_perm ? e->perm_ctr : nullptr;
     fa.status = e->status;
+    fa.host_status = e->host_status;
     size_t slab_off = 0;
     auto commit_p = [&](const double* src, int P, int stride, int dst, int n, float scale) {
         if (fa.nct < MAX_COMMITS) fa.ct[fa.nct] = CommitTask{src, P, stride, dst, n, scale};
@@ -2210,6 +2218,14 @@ CAL_EXPORT int cal_engine_p2p_set_timeout(void* h, int64_t max_polls) {
     CAL_REQUIRE(e && max_polls >= 1 && max_polls <= (1ll << 30), "bad arguments");
     e->p2p_max_polls = (int)max_polls; e->p2p.max_polls = (int)max_polls;
     return 0;
+}
+// The status words (this step's | the sticky earlier ones) as the latest COMPLETED training step left them: a host-mapped word the
+// step's last kernel refreshes, so the loops can look at it before every step without a synchronisation -- a flagged batch
+// (whose step updated nothing, and neither does any later one) surfaces a step or two later instead of at the end of the epoch.
+CAL_EXPORT int64_t cal_engine_peek_status(void* h) {
+    Engine* e = (Engine*)h;
+    if (!e || !e->host_status) return 0;
+    return (int64_t)__atomic_load_n(e->host_status, __ATOMIC_ACQUIRE);
 }
 // 0, or 64 once an exchange has timed out (the word is host-mapped: no device synchronisation, cheap enough for every step).
 // After a timeout k_p2p_adam updates nothing any more; allocate fresh regions and bind again to resume.

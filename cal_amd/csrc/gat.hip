@@ -1191,7 +1191,8 @@ int gat_backward(const int32_t* rowptr_dst, const int32_t* nbr_dst, const int32_
             hipLaunchKernelGGL(k_gat_datt_part_w, dim3(nb), dim3(256), 0, stream, z, dadst, dasrc, part, (int)N, rpb);
         else
         hipLaunchKernelGGL(k_gat_datt_part, dim3(nb), dim3(threads), 0, stream, z, dadst, dasrc, part, (int)N, (int)K, (int)D, rpb);
-        CAL_CHECK_LAUNCH("k_gat_datt_part");
+        // (launch-site name of the whole backward, as the engine's stage list sees it: which dst / src kernels ran in front)
+        CAL_CHECK_LAUNCH(wave_rows ? "k_gat_bwd_w+k_gat_datt_part" : "k_gat_bwd_dst+k_gat_bwd_src+k_gat_datt_part");
     }
     if (!part_out) {
         hipLaunchKernelGGL(k_gat_datt_finish, dim3(cdiv(2 * H, 16)), dim3(256), 0, stream, part, nb, (int)(2 * H), datt);

@@ -264,6 +264,11 @@ class StepEngine:
                     (256, "the one-launch readout timed out at an in-kernel barrier (its workgroups were not co-resident: "
                           "another process is holding CUs; CAL_AMD_RO_STEP=0 runs the readout as separate launches)"))
 
+    def peek_status(self) -> int:
+        """The status words as the latest COMPLETED training step left them (host-mapped mirror written by the step's last
+        kernel: no synchronisation, cheap enough for every step).  Non-zero: call ``check_status`` for the message."""
+        return _lib.query("cal_engine_peek_status", self._h)
+
     def check_status(self, reset: bool = True):
         """Synchronising check of the device status word over every step since the last check: the per-graph kernels
         skip graphs that violate the layout facts the batch declared (``max_nodes``, ``max_edges``, ``ptr``,

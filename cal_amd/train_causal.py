@@ -98,6 +98,8 @@ def _fused_epoch(model, binding, loader, device, args):
     stage = eng.perm_stage()
     try:
         for data in loader:
+            if eng.peek_status():        # host-mapped mirror, no sync: an earlier step flagged its batch (and updated nothing
+                eng.check_status()       # since): raise now, not at the end of the epoch
             data = data.to(device)
             n = num_graphs(data)
             shuffles = bool(args.with_random and (model.with_random if model._gate_on_with_random else True))

@@ -475,6 +475,8 @@ class CausalTrainer:
         tensor [loss, c_loss, o_loss, co_loss, correct_o] (no host sync)."""
         if self.p2p is not None:
             self.p2p.check()          # an exchange that timed out left the parameters untouched: say so before stepping on (host-mapped word, no sync)
+        if self.engine is not None and self.engine.peek_status():
+            self.engine.check_status()        # an earlier step flagged its batch (host-mapped mirror, no sync): raise with the message
         nb = batch.num_graphs
         dev = perm is None and self._use_device_perm(nb)
         if perm is None and not dev:

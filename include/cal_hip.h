@@ -224,6 +224,10 @@ CAL_API int64_t cal_engine_p2p_region_bytes(void* engine);
 CAL_API int cal_engine_p2p_bind(void* engine, void* const* peer_bases, const int64_t* peer_devices, int64_t world, int64_t rank);
 CAL_API int cal_engine_p2p_set_timeout(void* engine, int64_t max_polls);
 CAL_API int64_t cal_engine_p2p_status(void* engine);
+/* status words (latest step | sticky) as of the latest completed training step: host-mapped mirror, no synchronisation
+ * (train_causal.py:171-192 has no counterpart: the reference validates nothing; here a stale batch attribute must not train on
+ * garbage silently) */
+CAL_API int64_t cal_engine_peek_status(void* engine);
 CAL_API int cal_engine_p2p_adam(void* engine, void* stream);
 /* the 3-term loss of train_causal.py:176-183 on log-probabilities logp [3,B,C] (heads c, o, co) and labels y [B]:
  * out [4] = {loss, c_loss, o_loss, co_loss}; dlogp [3,B,C] (or null) = d loss / d logp, the input of cal_engine_backward_from.

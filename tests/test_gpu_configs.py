@@ -156,6 +156,90 @@ def test_config5_width_causalgat_engine_step_matches_oracle():
             assert e_gpu <= 4 * e_cpu + 1e-5 * max(1.0, g64.abs().max().item()), (k, e_gpu, e_cpu)
 
 
+def _stage_names():
+    from cal_amd import _lib
+    names = [_lib.lib().cal_engine_stage_name(k).decode() for k in range(1, 200)]
+    return [n for n in names if n]
+
+
+def _gat_masks(seeds, bd, b, heads, p):
+    """The keep masks the kernels draw for `seeds`, in the oracle's slot order (edges without self loops, then one loop per node)."""
+    from cal_amd import ops
+    from cal_amd.plan import plan_of
+    plan = plan_of(bd)
+    row, col = b.edge_index
+    keep_e = (row != col).nonzero().view(-1)
+    out = []
+    for s in seeds:
+        full = ops.gat_dropout_mask(int(s), plan, heads, p).cpu()
+        out.append(torch.cat([full[keep_e], full[plan.E:]], 0))
+    return out
+
+
+def test_config5_width_causalgat_step_with_dropout_matches_oracle():
+    """The instantiation BASELINE.json configs[4] is benchmarked on -- CausalGAT, hidden 256, 4 heads, attention dropout
+    p = 0.2 (model.py:340,388-390) -- against the oracle: 8 BA(m=2) graphs of 5000 nodes (N = 40000 rows: the wave-per-row
+    GATConv kernels with the dropout hash compiled in, k_gat_fwd_w<true> / k_gat_bwd_dst_w<true> / k_gat_bwd_src_w<true>, the
+    weight-resident GEMMs of gemm_wres.hip and k_espmm).  (a) fixed per-layer seeds: the keep masks the kernels draw
+    (cal_gat_dropout_mask) go to the oracle, one train step, bounds as in the p = 0 test above; (b) no fixed seeds: the masks
+    are keyed by the device step counter, the oracle gets the masks of the effective seeds.  Both assert through the step's
+    launch-site names that the wave-per-row kernels ran."""
+    from cal_amd import synth
+    from cal_amd.data import Batch
+    GOLD = 0x9E3779B97F4A7C15          # cal_amd/csrc/gat.hip step_seed()
+    NG = 8                             # eight graphs: the readout BatchNorms over four rows amplify summation-order noise in the
+                                       # gradients beyond what a x4 bound against the fp32 oracle holds for every seed
+    gs = synth.ba_graphs(NG, n=5000, seed=7)
+    b, bd = Batch.from_data_list(gs), Batch.from_data_list(gs).to(DEV)
+    torch.manual_seed(17)
+    sd = O.init_state("CausalGAT", 10, 4, hidden=256, layers=3, heads=4)
+    perm = torch.tensor([1, 2, 3, 0, 5, 6, 7, 4])
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+
+    def check(eng, m, masks, tag):
+        tr = O.CpuTrainer("CausalGAT", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=3, heads=4, gat_dropout=0.2, gat_masks=masks)
+        loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+        tr64 = O.CpuTrainer("CausalGAT", {k: v.clone() for k, v in sd64.items()}, 4, lr=1e-3, layers=3, heads=4, gat_dropout=0.2,
+                            gat_masks=[mk.double() for mk in masks])
+        loss64, _, _, _, logits64 = tr64.step(b.feat.double(), b.edge_index, b.batch, b.y, perm=perm)
+        lp = eng.buffer("logp", 3 * NG * 4).view(3, NG, 4).cpu()
+        for r32, r64, t in zip(logits, logits64, lp):
+            e_gpu = (r64.detach() - t.double()).abs().max().item()
+            e_cpu = (r64.detach() - r32.detach().double()).abs().max().item()
+            assert e_gpu < 2.5e-5, (tag, e_gpu, e_cpu)             # a quarter of north_star's 1e-4, against the fp64 oracle
+            assert e_cpu < LOGIT_TOL, (tag, e_cpu)
+        assert abs(eng.buffer("stats", 5)[0].item() - loss64.item()) < 1e-4, tag
+        eng.check_status()
+        for k, p in m.named_parameters():
+            g32, g64 = tr.sd[k].grad, tr64.sd[k].grad
+            if g32 is not None:
+                e_gpu = (p.grad.cpu().double() - g64).abs().max().item()
+                e_cpu = (g32.double() - g64).abs().max().item()
+                assert e_gpu <= 4 * e_cpu + 1e-5 * max(1.0, g64.abs().max().item()), (tag, k, e_gpu, e_cpu)
+        names = _stage_names()
+        assert names.count("k_gat_fwd_w") == 3 and names.count("k_gat_bwd_w+k_gat_datt_part") >= 3, names
+
+    # (a) fixed per-layer seeds
+    m, eng = _engine("CausalGAT", {k: v.clone() for k, v in sd.items()}, _args(hidden=256), dropout=0.2)
+    assert eng.heads == 4 and eng.H // eng.heads == 64
+    for i, c in enumerate(m.convs):
+        c.seed = 2000 + i
+    eng.train_step(bd, perm.to(DEV), adam=False)
+    assert eng.gat_fixed
+    masks = _gat_masks([c.seed for c in m.convs], bd, b, 4, 0.2)
+    kept = float(sum((mk > 0).float().mean().item() for mk in masks) / len(masks))
+    assert 0.78 < kept < 0.82, kept                                 # the masks really drop a fifth of the (edge, head) slots
+    check(eng, m, masks, "fixed seeds")
+    # (b) seeds keyed by the device step counter (what the bench runs)
+    m, eng = _engine("CausalGAT", {k: v.clone() for k, v in sd.items()}, _args(hidden=256), dropout=0.2)
+    eng.train_step(bd, perm.to(DEV), adam=False)
+    assert not eng.gat_fixed
+    v = int(eng.gat_ctr.item())
+    assert v == 1
+    eff = [(s_ + v * GOLD) % (1 << 64) for s_ in eng.gat_layer_seeds]
+    check(eng, m, _gat_masks(eff, bd, b, 4, 0.2), "counter-keyed seeds")
+
+
 @pytest.mark.parametrize("hidden,nfeat,layers", [(128, 10, 2), (64, 16, 1), (128, 3, 2), (256, 7, 1)])
 def test_narrow_feature_layer_row_kernels_match_oracle(hidden, nfeat, layers):
     """The node-level feature layer of a big batch with few input features (engine_feat.hpp: k_feat_fwd_rows, k_bn_bwd_feat +
@@ -268,6 +352,40 @@ def test_flagged_step_leaves_the_parameters_alone():
     eng.train_step(good, None, adam=True)
     eng.check_status()
     assert not torch.equal(eng.flat_p, p0)
+
+
+def test_flagged_batch_surfaces_within_the_epoch_not_at_its_end():
+    """The reference-shaped loop looks at the host-mapped mirror of the status word before every mini-batch (no
+    synchronisation): a batch with stale per-graph bounds in the middle of an epoch raises a step or two later -- long
+    before the loader is exhausted -- instead of freezing the parameters until the per-epoch check (round-4 review)."""
+    import argparse as _ap
+    from cal_amd import _lib, model as M
+    from cal_amd.data import Batch
+    from cal_amd.train_causal import train_causal_epoch
+    good = [Batch.from_data_list(ref_graphs(list(range(8)))).to(DEV) for _ in range(60)]
+    bad = Batch.from_data_list(ref_graphs([24, 25])).to(DEV)
+    bad.max_nodes, bad.max_edges = 50, 100
+
+    class Loader:
+        def __init__(self, batches): self.batches, self.seen = batches, 0
+        dataset = list(range(8 * 60))
+        def __iter__(self):
+            for b in self.batches:
+                self.seen += 1
+                yield b
+    args = _args(hidden=64, layers=2)
+    args.with_random, args.eval_random = True, False
+    torch.manual_seed(3)
+    m = M.CausalGCN(10, 4, args).to(DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    ld = Loader(good[:5] + [bad] + good[5:])
+    with pytest.raises(_lib.CalError, match="per-graph bounds"):
+        train_causal_epoch(m, opt, ld, DEV, args)
+    assert getattr(m, "_engine", None) is not None
+    assert 6 < ld.seen < 40, ld.seen          # raised a few steps after the bad batch (launches are asynchronous), not after all 61
+    assert m._engine.peek_status() in (0, 8)  # (the mirror is refreshed by the next step's last kernel)
+    train_causal_epoch(m, opt, Loader(good[:4]), DEV, args)          # cleared by the raise: training goes on
+    assert m._engine.peek_status() == 0
 
 
 def test_status_word_is_sticky_until_checked():
