@@ -285,7 +285,7 @@ def engine_roofline(trainer, batches, workload, iters=20):
         note = ("single-kernel classes: events attached to the dispatch (hipExtLaunchKernelGGL start/stop), eager step" if pmc else
                 "single-kernel classes: events attached to the dispatch, eager step; no PMC pass was collected for this workload (traffic null)")
     mfma = {
-        "gemm": ("k_gemm", "k_gemm / k_gemm_big<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers, unfused path; 128x128 tiles from 16k rows)", "k_gemm_backbone"),
+        "gemm": ("k_gemm", "k_gemm / k_wres<NN, BN prologue> [N,H]x[H,H] fp32 MFMA 32x32x2 (backbone layers, unfused path; the weight-resident kernel of gemm_wres.hip from 16k rows at H = 128 / 256)", "k_gemm_backbone"),
         "gconv": ("k_gconv_fwd", "k_gconv_fwd: per-graph fused BN + [n,H]x[H,64] MFMA GEMM + dense-block aggregation MFMA + "
                                  "bias/ReLU/BN statistics (backbone layers, forward)", "k_gconv_fwd"),
         "gconv_bwd": ("k_gconv_bwd", "k_gconv_bwd: per-graph fused backward -- dense-block transposed aggregation + dX' = dz W^T (BN-backward "
@@ -298,8 +298,8 @@ def engine_roofline(trainer, batches, workload, iters=20):
                                "MFMA + bias + BN statistics (backbone layers, forward)", "k_ggin_fwd"),
         "ggin_bwd": ("k_ggin_bwd", "k_ggin_bwd<1>: per-graph fused GINConv backward, first half -- BatchNorm backward + transposed unit aggregation + "
                                    "d h = dz W1 + dW1 = dz^T h, all on MFMA (backbone layers, backward)", "k_ggin_bwd"),
-        "dual": ("k_gemm_dual", "k_gemm_dual / k_gemm_big_dual: dX = dZ W^T (NT, BN-backward sums) + dW = BN(h)^T dZ (TN, split-K) in one grid "
-                                "(backbone layers, backward)", "k_gemm_dual"),
+        "dual": ("k_gemm_dual", "k_gemm_dual (one grid) / k_wres<NT, dot sums> + k_tn (two launches, timed as one class): dX = dZ W^T with the BN-backward sums "
+                                "+ dW = BN(h)^T dZ over node ranges (backbone layers, backward)", "k_gemm_dual"),
     }
     # primary roofline = the MFMA kernel class that takes the most time per step
     best = None
@@ -311,8 +311,17 @@ def engine_roofline(trainer, batches, workload, iters=20):
             continue
         dur, work, per_step = out[key]
         ach = work / dur / 1e12
+        # the PMC summary names the instantiation that ran: 64x64 tiles, 128x128 tiles or the weight-resident kernels (by size)
+        alts = {"k_gemm_backbone": (("k_wres_fwd",), ("k_gemm_big",), ("k_gemm_backbone",)),
+                "k_gemm_dual": (("k_wres_nt", "k_tn"), ("k_gemm_big_dual",), ("k_gemm_dual",))}.get(mfma[key][2], ((mfma[key][2],),))
+        traffic = None
+        for names in alts:
+            vals = [pmc.get(nm, {}).get("bytes_per_launch") for nm in names]
+            if all(v is not None for v in vals):
+                traffic = int(sum(vals))
+                break
         d = dict(bound="mfma", kernel=mfma[key][1], achieved=ach, peak=157.3, unit="TFLOP/s", frac=ach / 157.3,
-                 traffic=(pmc.get(mfma[key][2]) or pmc.get(mfma[key][2].replace("k_gemm_dual", "k_gemm_big_dual")) or {}).get("bytes_per_launch"),
+                 traffic=traffic,
                  avg_launch_us=dur * 1e6,
                  algorithmic_flops_per_launch=work, timed_launches_per_step=per_step, note=note, traffic_source=traffic_src)
         roof["roofline" if key == best else "roofline_" + mfma[key][0]] = d
@@ -652,7 +661,9 @@ def main():
     }
     if dp_diag is not None:
         out["data_parallel"] = dp_diag
-    if rank == 0 and world == 1:
+    # rank 0 also at N > 1 (after the timed regions; the other ranks wait at the barrier below): a SCALE line then carries
+    # the same roofline / cpu_baseline blocks as the N = 1 line and can be cross-checked against it (round-4 review)
+    if rank == 0:
         if not a.no_roofline:
             try:
                 if trainer.engine is not None:
@@ -661,17 +672,18 @@ def main():
                     out["roofline"] = spmm_roofline(trainer, batches, wl)
             except Exception as exc:
                 out["roofline"] = {"error": repr(exc)}
-        if not a.no_e2e:
+        if not a.no_e2e and world == 1:
             try:
                 out["end_to_end"] = end_to_end(wl, margs)
             except Exception as exc:
                 out["end_to_end"] = {"error": repr(exc)}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, batches_cpu, a.cpu_seconds)
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]      # (N > 1: the whole job against ONE host's cores)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()
         dist.destroy_process_group()
 
 

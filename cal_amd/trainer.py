@@ -310,14 +310,32 @@ class CausalTrainer:
         torch.cuda.current_stream().wait_stream(s)
         self._restore(snap)
         g = torch.cuda.CUDAGraph()
+        failed = None
         try:
             with torch.cuda.graph(g, pool=self._pool):
                 cap.stats = self._fwd_bwd(batch, cap.perm, cap.stats, draw=draws)
         except Exception as exc:
             if not self.exchange_in_graph:
                 raise
-            # the collective refused stream capture: keep it between two graphs instead (every rank runs the same
-            # software, so every rank takes this branch)
+            failed = exc
+        if self.exchange_in_graph and self.p2p is None and dist.is_initialized() and dist.get_world_size() > 1 \
+                and not getattr(self, "_capture_agreed", False):
+            # The ranks must agree on the outcome: a rank that captured the collective would wait inside its graph for a rank
+            # that fell back to the eager one -- a hang, not an error.  One eager all-reduce (MAX) of the local verdict at the
+            # FIRST capture (every rank's first step; later captures happen at rank-specific times and must not communicate):
+            # every rank reaches it (capture itself communicates nothing), and if ANY rank failed, ALL take the split form below.
+            self._capture_agreed = True
+            torch.cuda.synchronize()
+            verdict = torch.tensor([1.0 if failed is not None else 0.0], device=self.flat_p.device)
+            dist.all_reduce(verdict, op=dist.ReduceOp.MAX)
+            if verdict.item() > 0 and failed is None:
+                failed = RuntimeError("another rank could not capture the gradient all-reduce")
+        if failed is not None and getattr(self, "_capture_agreed", False) and not getattr(self, "_first_capture_open", True):
+            raise failed              # a later capture failed after the ranks had agreed that it works: an error, never a one-sided fallback
+        self._first_capture_open = False
+        if failed is not None:
+            exc = failed
+            # the collective refused stream capture (here or on another rank): keep it between two graphs instead
             warnings.warn("cal_amd: gradient all-reduce could not be captured into the step graph (%r); "
                           "running it between the forward/backward graph and the Adam graph" % (exc,))
             self.exchange_in_graph = False
