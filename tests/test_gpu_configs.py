@@ -531,14 +531,22 @@ def test_workspace_growth_evicts_captured_graphs_and_keeps_the_status_word():
     perm8 = torch.arange(8, device=DEV)
     l0 = float(trn.step(small, perm=perm8)[0].item())
     gen0 = trn.engine.ws_generation
-    trn.engine.buffer("status", 4, torch.int32)[1] = 8            # pretend an earlier step flagged a bad bound
     big = Batch.from_data_list(ref_graphs(list(range(24)))).to(DEV)
     trn.step(big, perm=torch.arange(24, device=DEV))              # grows the workspace
     assert trn.engine.ws_generation > gen0
     l1 = float(trn.step(small, perm=perm8)[0].item())             # stale capture -> re-captured on the new workspace
     assert abs(l0 - l1) < 1e-6
     assert trn._graphs[id(small)].ws_gen == trn.engine.ws_generation
+    trn.check_status()
+    # what an earlier step flagged survives a re-allocation: it surfaces at the next step that looks at the host-mapped mirror
+    # (round 5: CausalTrainer.step peeks before every step) or, at the latest, at the explicit check
+    gen1 = trn.engine.ws_generation
+    trn.engine.buffer("status", 4, torch.int32)[1] = 8            # pretend an earlier step flagged a bad bound
+    bigger = Batch.from_data_list(ref_graphs(list(range(24)) + list(range(16)))).to(DEV)
     with pytest.raises(Exception, match="status 0x8"):
+        trn.step(bigger, perm=torch.arange(40, device=DEV))       # grows the workspace again, carrying the sticky word along
+        assert trn.engine.ws_generation > gen1
+        trn.step(small, perm=perm8)
         trn.check_status()
 
 
