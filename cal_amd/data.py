@@ -387,20 +387,41 @@ def shard_indices(n: int, shuffle: bool, rank: int, world_size: int, drop_last: 
     return idx
 
 
-_CONCATS = []        # [(dataset list, fingerprint, _HostConcat)]: the last few static datasets a DataLoader was built over
+_CONCATS = []        # [(dataset list, fingerprint, _HostConcat)]: the last two static datasets a DataLoader was built over
+
+
+def _fingerprint(dataset):
+    """Identity AND in-place version of every graph's tensors (torch bumps ``_version`` on every in-place write): a replaced
+    element, an edited label / feature / edge list or a transform applied in place all change it.  ~1 us per graph -- the
+    reference's loader re-reads its dataset every batch (train_causal.py:13-15), so a stale concatenation must not outlive a change."""
+    h = len(dataset)
+    for g in dataset:
+        x = g.x if getattr(g, "x", None) is not None else getattr(g, "feat", None)
+        ei, y = getattr(g, "edge_index", None), getattr(g, "y", None)
+        h = hash((h, id(g), 0 if x is None else (x.data_ptr(), x._version), 0 if ei is None else (ei.data_ptr(), ei._version),
+                  0 if y is None else (y.data_ptr(), y._version)))
+    return h
+
+
+def clear_collate_cache():
+    """Drop the cached host concatenations (they hold a copy of the last two datasets a DataLoader was built over)."""
+    del _CONCATS[:]
 
 
 def _concat_of(dataset):
     """One ``_HostConcat`` per dataset list, kept across DataLoader objects (loops that build a new loader every epoch over the
-    same list would pay the concatenation -- ~30 ms for 5 000 graphs -- sixteen steps apart)."""
-    n = len(dataset)
-    fp = (n, id(dataset[0]) if n else 0, id(dataset[n // 2]) if n else 0, id(dataset[-1]) if n else 0)
-    for ds, f, hc in _CONCATS:
-        if ds is dataset and f == fp:
-            return hc
+    same list would pay the concatenation -- ~30 ms for 5 000 graphs -- sixteen steps apart); rebuilt when the list or any of
+    its graphs has changed since (``_fingerprint``)."""
+    fp = _fingerprint(dataset)
+    for i, (ds, f, hc) in enumerate(_CONCATS):
+        if ds is dataset:
+            if f == fp:
+                return hc
+            del _CONCATS[i]
+            break
     hc = _HostConcat(dataset)
     _CONCATS.append((dataset, fp, hc))
-    del _CONCATS[:-4]
+    del _CONCATS[:-2]
     return hc
 
 

@@ -520,6 +520,27 @@ def _as_one_block(gc, go, gco, B, C):
     return base.view(3, B, C)
 
 
+_LOSS_FLAGS = {}         # device -> int32[1]: bit 1 once a fused loss saw a label outside [0, C) (sticky until check_loss_labels)
+
+
+def _loss_flag(device):
+    f = _LOSS_FLAGS.get(device)
+    if f is None:
+        f = _LOSS_FLAGS[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return f
+
+
+def check_loss_labels():
+    """Raise if a fused causal loss since the last call saw a label outside [0, num_classes) -- ``F.nll_loss`` in the reference
+    (train_causal.py:178-180) stops with a device assert there; the fused kernel gives such a graph zero loss and flags it.
+    Synchronising: called where the loops read their statistics back anyway."""
+    for dev, f in list(_LOSS_FLAGS.items()):
+        if int(f.item()) != 0:
+            f.zero_()
+            raise _lib.CalError("cal_amd: a label outside [0, num_classes) reached the fused causal loss (torch's nll_loss would "
+                                "have raised; ignore_index is not supported on the fused path)")
+
+
 class _FusedCausalLoss(torch.autograd.Function):
     """``loss, c_loss, o_loss, co_loss`` of train_causal.py:176-183 from the three log-prob outputs as ONE launch
     (``cal_causal_loss``), with the gradient w.r.t. the log-probs produced in the same launch: a statement-by-statement loop
@@ -530,7 +551,8 @@ class _FusedCausalLoss(torch.autograd.Function):
         B, C = c_logs.shape                              # (the three are consecutive [B, C] blocks of one buffer: fused_causal_loss)
         out = torch.empty(4, dtype=torch.float32, device=c_logs.device)
         dl = torch.empty(3, B, C, dtype=torch.float32, device=c_logs.device)
-        _lib.call("cal_causal_loss", _p(c_logs), _p(y), B, C, float(wc), float(wo), float(wco), _p(out), _p(dl), None, _stream())
+        _lib.call("cal_causal_loss", _p(c_logs), _p(y), B, C, float(wc), float(wo), float(wco), _p(out), _p(dl),
+                  _p(_loss_flag(c_logs.device)), _stream())
         ctx.dl, ctx.w = dl, (float(wc), float(wo), float(wco))
         return out[0], out[1], out[2], out[3]
 

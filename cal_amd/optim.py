@@ -210,7 +210,9 @@ class EngineAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         b = self._binding()
-        if b is None or not b.grads_in_flat(full=False) or (b.grads_mixed and not b.grads_in_flat()):
+        # every parameter's .grad must alias its slice of the flat buffer (~40 pointer compares): a frozen layer (grad None) or
+        # a replaced gradient in the middle of the list sends the step to torch's Adam, which skips / uses it as torch would
+        if b is None or not b.grads_in_flat():
             if b is not None:
                 b.flush()
                 b.grads_mixed = True                # some gradients live outside the flat buffer: check all of them from now on

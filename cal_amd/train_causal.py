@@ -43,6 +43,8 @@ def _check_engine(model):
     eng = getattr(model, "_engine", None)
     if eng is not None:
         eng.check_status()
+        from .engine import check_loss_labels
+        check_loss_labels()
 
 
 def num_graphs(data):

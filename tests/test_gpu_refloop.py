@@ -212,6 +212,33 @@ def test_fused_causal_loss_equals_the_torch_formulation():
             assert torch.allclose(ga, gb, atol=1e-6 + 1e-5 * float(gb.abs().max()), rtol=1e-4), (a, k)
 
 
+def test_fused_causal_loss_flags_a_label_outside_the_class_range():
+    """F.nll_loss in the reference (train_causal.py:178-180) stops with a device assert on a label outside [0, C); the fused
+    loss gives such a graph zero loss, so it raises the sticky flag and ``check_loss_labels`` (called where the loops read their
+    statistics back) turns it into an error (advisor, round 4)."""
+    from cal_amd import _lib
+    from cal_amd.data import Batch
+    from cal_amd.engine import check_loss_labels
+    from cal_amd.train_causal import causal_loss
+    gs = _graphs(8, seed=5)
+    bd = Batch.from_data_list(gs).to(DEV)
+    args = _args(layers=2, hidden=64)
+    torch.manual_seed(1)
+    m = _model("CausalGCN", O.init_state("CausalGCN", 10, 4, hidden=64, layers=2), args)
+    m.train()
+    c, o, co = m(bd, eval_random=False)
+    causal_loss(c, o, co, bd.y, 4, args)
+    check_loss_labels()                                   # all labels in range: nothing
+    y_bad = bd.y.clone()
+    y_bad[3] = 7
+    c, o, co = m(bd, eval_random=False)
+    out = causal_loss(c, o, co, y_bad, 4, args)
+    assert type(out[0].grad_fn).__name__.startswith("_FusedCausalLoss")
+    with pytest.raises(_lib.CalError, match="label outside"):
+        check_loss_labels()
+    check_loss_labels()                                   # cleared by the raise
+
+
 def test_lr_scheduler_reaches_the_fused_step():
     """CosineAnnealingLR rewrites param_groups[0]['lr'] (train_causal.py:22,29); the next fused epoch must use it: two
     models, one stepped with lr = 0 after the schedule, stay / move accordingly."""
