@@ -68,13 +68,17 @@ __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __re
     const int ntask = fa.nst + fa.nct + fa.nar;
     AdamArgs A = fa.adam;
     float adam_t = 0.f, adam_lr = 0.f;
-    if (A.on && fa.status && (fa.status[0] | fa.status[1]) != 0) A.on = 0;   // every earlier kernel of the step has finished: uniform
+    const bool flagged = fa.status && (fa.status[0] | fa.status[1]) != 0;     // every earlier kernel of the step has finished: uniform
+    // a gated step applies no update, so it must not count as one either: the step's first kernel has already advanced the
+    // Adam step counter (bias correction) -- take that back (advisor, round 4: the counter drifted by the frozen steps)
+    if (A.on && flagged && blockIdx.x == 0 && threadIdx.x == 0) A.step[0] -= 1.f;
+    if (A.on && flagged) A.on = 0;
     if (A.on) { adam_t = A.step[0]; adam_lr = A.lr[0]; }      // the step's first kernel has already advanced the counter
     while (task + 1 < ntask && (int)blockIdx.x >= fa.blk0[task + 1]) ++task;
     const int bx = blockIdx.x - fa.blk0[task], nbx = fa.blk0[task + 1] - fa.blk0[task];
     if (fa.stats && blockIdx.x == 0 && threadIdx.x == 0)
         fa.stats[0] = fa.wc * fa.stats[1] + fa.wo * fa.stats[2] + fa.wco * fa.stats[3];
-    if (fa.tick && blockIdx.x == 0 && threadIdx.x == 0) fa.tick[0] += 1.f;
+    if (fa.tick && !flagged && blockIdx.x == 0 && threadIdx.x == 0) fa.tick[0] += 1.f;      // (the k_adam that follows skips a flagged step too)
     if (fa.perm_ctr && blockIdx.x == 0 && threadIdx.x == 0) fa.perm_ctr[0] += 1;
     if (fa.host_status && fa.status && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(fa.host_status, fa.status[0] | fa.status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

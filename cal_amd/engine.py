@@ -281,6 +281,8 @@ class StepEngine:
         if reset:
             st[:2].zero_()
         if word:
+            for cb in list(getattr(self, "_on_flag", ())):
+                cb()                           # (optim.Binding: the flagged steps were not applied -- re-read the device step counter)
             msgs = [m for bit, m in self._STATUS_BITS if word & bit] or ["unknown status bits"]
             raise _lib.CalError("cal_amd engine: invalid batch (status 0x%x): %s" % (word, "; ".join(msgs)))
 

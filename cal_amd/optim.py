@@ -61,6 +61,19 @@ class Binding:
         self.grads_mixed = False            # a step has seen gradients outside the engine's flat buffer
         from .trainer import flat_offsets
         self._views = [(off, p.numel()) for p, off in zip(params, flat_offsets(params)[0])]
+        hooks = getattr(engine, "_on_flag", None)
+        if hooks is None:
+            hooks = engine._on_flag = []
+        hooks[:] = [self.after_flag]            # one binding per engine at a time
+
+    def after_flag(self):
+        """``check_status`` found flagged steps: the device applied none of them and did not count them (k_finish), while
+        ``stepped()`` did -- bring the host-side counters back to what the device holds (synchronising; the raise follows)."""
+        s = float(self.engine.step_count.item())
+        drift = self.engine_step - s
+        if drift > 0:
+            self.pending = max(0, self.pending - int(round(drift)))
+            self.engine_step = s
 
     def sync_hparams(self):
         """betas / eps / weight_decay / lr of the optimizer's group -> the engine (lr is a device float: an async fill)."""

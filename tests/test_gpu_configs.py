@@ -343,15 +343,18 @@ def test_flagged_step_leaves_the_parameters_alone():
     eng.train_step(good, None, adam=True)
     eng.check_status()
     p0, m0 = eng.flat_p.clone(), eng.exp_avg.clone()
+    assert float(eng.step_count.item()) == 1.0
     eng.train_step(bad, None, adam=True)
     assert torch.equal(eng.flat_p, p0) and torch.equal(eng.exp_avg, m0)
     eng.train_step(good, None, adam=True)                           # sticky: still frozen
     assert torch.equal(eng.flat_p, p0) and torch.equal(eng.exp_avg, m0)
+    assert float(eng.step_count.item()) == 1.0                      # frozen steps are not counted (Adam's bias correction must not drift)
     with pytest.raises(_lib.CalError, match="per-graph bounds"):
         eng.check_status()
     eng.train_step(good, None, adam=True)
     eng.check_status()
     assert not torch.equal(eng.flat_p, p0)
+    assert float(eng.step_count.item()) == 2.0
 
 
 def test_flagged_batch_surfaces_within_the_epoch_not_at_its_end():
