@@ -387,20 +387,37 @@ def shard_indices(n: int, shuffle: bool, rank: int, world_size: int, drop_last: 
     return idx
 
 
-_CONCATS = []        # [(dataset list, fingerprint, _HostConcat)]: the last two static datasets a DataLoader was built over
+_CONCATS = []        # [(dataset list, per-graph signatures, _HostConcat)]: the last two static datasets a DataLoader was built over
 
 
-def _fingerprint(dataset):
-    """Identity AND in-place version of every graph's tensors (torch bumps ``_version`` on every in-place write): a replaced
-    element, an edited label / feature / edge list or a transform applied in place all change it.  ~1 us per graph -- the
-    reference's loader re-reads its dataset every batch (train_causal.py:13-15), so a stale concatenation must not outlive a change."""
-    h = len(dataset)
-    for g in dataset:
-        x = g.x if getattr(g, "x", None) is not None else getattr(g, "feat", None)
-        ei, y = getattr(g, "edge_index", None), getattr(g, "y", None)
-        h = hash((h, id(g), 0 if x is None else (x.data_ptr(), x._version), 0 if ei is None else (ei.data_ptr(), ei._version),
-                  0 if y is None else (y.data_ptr(), y._version)))
-    return h
+_FP_PHASE = [0]
+
+
+def _graph_sig(g):
+    """Identity and in-place version of a graph's tensors (torch bumps ``_version`` on every in-place write)."""
+    x = g.x if getattr(g, "x", None) is not None else getattr(g, "feat", None)
+    ei, y = getattr(g, "edge_index", None), getattr(g, "y", None)
+    return (id(g), 0 if x is None else (x.data_ptr(), x._version), 0 if ei is None else (ei.data_ptr(), ei._version),
+            0 if y is None else (y.data_ptr(), y._version))
+
+
+def _unchanged(dataset, sigs) -> bool:
+    """Has the list (or a graph in it) changed since ``sigs`` was taken?  A replaced element, an edited label / feature / edge
+    list or a transform applied in place all show.  Lists of up to 512 graphs are checked completely; longer ones at ~512
+    positions whose phase rotates from call to call (~1.4 us per graph: a full pass over the reference's 5 596-graph training
+    split every epoch would cost as much as its first twenty steps) -- an edit of ONE graph of a long list is then seen within
+    a few loaders at the latest, a transform over the whole list at once.  The reference's loader re-reads its dataset every
+    batch (train_causal.py:13-15); ``clear_collate_cache()`` forces a rebuild."""
+    n = len(dataset)
+    if n != len(sigs):
+        return False
+    if n <= 512:
+        idx = range(n)
+    else:
+        step = n // 509
+        _FP_PHASE[0] = (_FP_PHASE[0] + 1) % step
+        idx = list(range(_FP_PHASE[0], n, step)) + [0, n // 2, n - 1]
+    return all(sigs[i] == _graph_sig(dataset[i]) for i in idx)
 
 
 def clear_collate_cache():
@@ -410,17 +427,16 @@ def clear_collate_cache():
 
 def _concat_of(dataset):
     """One ``_HostConcat`` per dataset list, kept across DataLoader objects (loops that build a new loader every epoch over the
-    same list would pay the concatenation -- ~30 ms for 5 000 graphs -- sixteen steps apart); rebuilt when the list or any of
-    its graphs has changed since (``_fingerprint``)."""
-    fp = _fingerprint(dataset)
-    for i, (ds, f, hc) in enumerate(_CONCATS):
+    same list would pay the concatenation -- ~30 ms for 5 000 graphs -- sixteen steps apart); rebuilt when the list or a graph
+    in it has changed since (``_unchanged``)."""
+    for i, (ds, sigs, hc) in enumerate(_CONCATS):
         if ds is dataset:
-            if f == fp:
+            if _unchanged(dataset, sigs):
                 return hc
             del _CONCATS[i]
             break
     hc = _HostConcat(dataset)
-    _CONCATS.append((dataset, fp, hc))
+    _CONCATS.append((dataset, [_graph_sig(g) for g in dataset], hc))
     del _CONCATS[:-2]
     return hc
 
