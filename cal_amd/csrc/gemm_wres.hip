@@ -3,7 +3,7 @@
 //
 // Round 5.  The 128 x 128 tile kernel of gemm_big.hip stages both operands through LDS with a barrier per 32-wide k tile and
 // ran at 0.60-0.65 matrix-core busy: a workgroup's prologue / epilogue and its barrier phases leave the pipe idle, two
-// resident workgroups do not cover each other (profiles/r4/pmc_issue_ba5000_*).  These kernels have no
+// resident workgroups do not cover each other (profiles/r4/pmc_issue_ba5000_*, profiles/r4/DESIGN_r4.md section 8).  These kernels have no
 // barrier and no operand staging inside the loop:
 //
 //   k_wres (C = op(A) W, NN / NT).  A persistent workgroup keeps one 128-column half of the WEIGHT in LDS for its whole life
