@@ -537,7 +537,9 @@ void gemm_set_split(GemmArgs& a, int S) {
     int kchunk = (int)((((int64_t)a.K + S - 1) / S + BK - 1) / BK * BK);
     if (kchunk == 0) kchunk = BK;
     // a slice just over PRE_T tiles would fall back to the streaming loop: cut it at PRE_T tiles instead
-    if (S > 1 && kchunk > PRE_T * BK && kchunk <= (PRE_T + 2) * BK) kchunk = PRE_T * BK;
+    // (not for the direct-operand gradient kernel, gemm_wres.hip: its slab count was sized as S, and a shorter chunk would make
+    //  more slices than slabs -- 375 for 256 at K = 47 950 nodes, a write past the workspace found by tests/tools/fuzz_gemm_wres.py)
+    if (S > 1 && kchunk > PRE_T * BK && kchunk <= (PRE_T + 2) * BK && !gemm_wres_grad(a.M, a.N, a.K)) kchunk = PRE_T * BK;
     a.kchunk = kchunk;
     a.nsplit = a.K == 0 ? 1 : cdiv(a.K, kchunk);
 }

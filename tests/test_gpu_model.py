@@ -218,6 +218,26 @@ def test_linear_op_matches_torch():
         assert torch.allclose(y2.detach().cpu(), x.detach().cpu() @ w2.detach().cpu(), atol=1e-4, rtol=1e-4)
 
 
+def test_weight_gradient_gemm_over_node_counts_around_the_split_window():
+    """dW[256,256] = X^T dZ (cal_gemm TN -> k_tn, gemm_wres.hip) over node counts whose split-K chunk lands where the 64 x 64
+    kernel re-cuts a chunk to its preload depth: left alone that made more slices than slabs (375 for 256 at 47 950 nodes) and
+    wrote past the workspace -- found by tests/tools/fuzz_gemm_wres.py in round 5.  Against torch in fp64."""
+    from cal_amd import _lib
+    from cal_amd.plan import _p, _stream
+    g = torch.Generator().manual_seed(3)
+    for nodes in (33000, 41000, 47950, 49152):
+        x = torch.randn(nodes, 256, generator=g).to(DEV)
+        d = torch.randn(nodes, 256, generator=g).to(DEV)
+        n_ws = _lib.query("cal_gemm_ws", 256, 256, nodes)
+        ws = torch.empty(max(n_ws, 4) + 1024, device=DEV)
+        ws[n_ws:].fill_(12345.0)                                   # canary behind the workspace the entry point asked for
+        dw = torch.full((256, 256), float("nan"), device=DEV)
+        _lib.call("cal_gemm", 1, 0, _p(x), _p(d), _p(dw), None, 0, _p(ws), 256, 256, nodes, _stream())
+        ref = x.double().t() @ d.double()
+        assert ((dw.double() - ref).abs().max() / ref.abs().max()).item() < 2e-5, nodes
+        assert bool((ws[n_ws:] == 12345.0).all().item()), nodes
+
+
 def test_train_causal_real_k_fold_loop_runs_on_the_engine():
     """train_causal.py:63-160 on a TU-style dataset (synthetic MUTAG-like stand-in): 2 folds x 3 epochs, the reference's
     loop shape (model(data) -> loss -> backward -> torch Adam) on the native engine behind the nn.Module."""
