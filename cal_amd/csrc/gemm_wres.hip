@@ -24,6 +24,7 @@
 // Same contract as gemm_block (engine.hpp GemmArgs / GemmProb).
 #include "engine.hpp"
 #include <type_traits>
+#include <cstdlib>
 
 namespace cal {
 
@@ -354,9 +355,11 @@ __global__ void __launch_bounds__(TNT) k_tn(const GemmArgs a) {
 
 // ---- selection -----------------------------------------------------------------------------------------------
 // node-level products on the weight-resident kernel: K = 128 / 256 whole, N one or two 128-column halves, enough rows
-bool gemm_wres_rows(int M, int N, int K) { return M >= 16384 && (K == 128 || K == 256) && (N == 128 || N == 256); }
+// CAL_AMD_WRES=0: these kernels off (the 128 x 128 tile kernels of gemm_big.hip take the launches: A/B measurements, bisecting)
+static bool wres_on() { static const bool on = [] { const char* v = getenv("CAL_AMD_WRES"); return !(v && v[0] == '0'); }(); return on; }
+bool gemm_wres_rows(int M, int N, int K) { return wres_on() && M >= 16384 && (K == 128 || K == 256) && (N == 128 || N == 256); }
 // weight gradients on the direct-operand kernel: exactly 256 x 256 over a long node axis
-bool gemm_wres_grad(int M, int N, int K) { return K >= 16384 && M == 256 && N == 256; }
+bool gemm_wres_grad(int M, int N, int K) { return wres_on() && K >= 16384 && M == 256 && N == 256; }
 // node ranges of such a gradient: one 256 x 256 slab per workgroup, ~one workgroup per CU over the whole batch
 int gemm_wres_grad_splits(int K, int nbatch) {
     const int s = wres::GRID / (nbatch < 1 ? 1 : nbatch);

@@ -29,7 +29,7 @@ def _engine(sd, args, nfeat=10, ncls=4, lr=1e-3, dropout=0.2, name="CausalGAT"):
     from cal_amd import model as M
     from cal_amd.engine import StepEngine
     m = getattr(M, name)(nfeat, ncls, args)
-    m.load_state_dict(sd)
+    m.load_state_dict(sd, strict=name != "CausalGIN")          # (GINConv's eps buffers are not part of the oracle's state)
     m = m.to(DEV).train()
     if name == "CausalGAT":
         for c in m.convs:
@@ -272,25 +272,32 @@ def test_config3_config4_standin_shapes_match_oracle(name, kind, nfeat, batch):
             assert torch.allclose(p.grad.cpu(), gref, atol=1e-4, rtol=3e-3), k
 
 
-@pytest.mark.parametrize("name", ["CausalGCN", "CausalGAT"])
-def test_big_batch_takes_the_throughput_gemm_and_matches_oracle(name):
+@pytest.mark.parametrize("name,hidden", [("CausalGCN", 64), ("CausalGAT", 64), ("CausalGCN", 128), ("CausalGAT", 128), ("CausalGIN", 128)])
+def test_big_batch_takes_the_throughput_gemm_and_matches_oracle(name, hidden):
     """A config-5-like batch (4 BA graphs of 5000 nodes: N = 20000 >= 16k rows) runs its node-level products on the
-    128x128 MFMA kernel (gemm_big.hip: 128-row statistic tiles, 1024-node split-K slabs): one train step vs the oracle."""
+    throughput kernels: hidden 64 on the 128x128 tiles of gemm_big.hip (128-row statistic tiles, 1024-node split-K slabs),
+    hidden 128 on the weight-resident kernel of gemm_wres.hip at its K = 128 instantiation (BN / row-scale prologues, the
+    statistics and dot-sum epilogues as one partial row per workgroup; GINConv's two GEMMs per layer included): one train
+    step vs the oracle."""
     from cal_amd import synth
     from cal_amd.data import Batch
-    gs = synth.ba_graphs(4, n=5000, seed=3)
+    # (CausalGAT at hidden 128: eight graphs of 2500 nodes -- with four, the readout BatchNorms over four rows amplify the
+    #  summation-order noise of this model's gradients to 10x the fp32 oracle's own distance from fp64, with the 128 x 128 tile
+    #  kernels and with the weight-resident ones alike (CAL_AMD_WRES=0 / 1: 2.04e-3 / 2.00e-3 on bn_feat.weight at scale 2.5))
+    ng, nn = (8, 2500) if (name, hidden) == ("CausalGAT", 128) else (4, 5000)
+    gs = synth.ba_graphs(ng, n=nn, seed=3)
     b, bd = Batch.from_data_list(gs), Batch.from_data_list(gs).to(DEV)
     torch.manual_seed(8)
-    sd = O.init_state(name, 10, 4, hidden=64, layers=2, heads=4)
-    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(hidden=64, layers=2), dropout=0.0, name=name)
-    perm = torch.randperm(4)
+    sd = O.init_state(name, 10, 4, hidden=hidden, layers=2, heads=4)
+    m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(hidden=hidden, layers=2), dropout=0.0, name=name)
+    perm = torch.randperm(ng)
     tr = O.CpuTrainer(name, {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=2, heads=4, gat_dropout=0.0)
     loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
     sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     tr64 = O.CpuTrainer(name, sd64, 4, lr=1e-3, layers=2, heads=4, gat_dropout=0.0)
     tr64.step(b.feat.double(), b.edge_index, b.batch, b.y, perm=perm)
     stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
-    lp = eng.buffer("logp", 3 * 4 * 4).view(3, 4, 4).cpu()
+    lp = eng.buffer("logp", 3 * ng * 4).view(3, ng, 4).cpu()
     for r, t in zip(logits, lp):
         assert (r.detach() - t).abs().max().item() < LOGIT_TOL
     assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
@@ -302,7 +309,10 @@ def test_big_batch_takes_the_throughput_gemm_and_matches_oracle(name):
             # HIP path must be as close to it as the fp32 oracle is (x4), plus 1e-5 of the gradient's largest entry
             e_gpu = (p.grad.cpu().double() - g64).abs().max().item()
             e_cpu = (g32.double() - g64).abs().max().item()
-            assert e_gpu <= 4 * e_cpu + 1e-5 * max(1.0, g64.abs().max().item()), (k, e_gpu, e_cpu)
+            # (CausalGAT at hidden 128, eight graphs: the fp32 oracle lands within 1e-6 of fp64 there, the HIP path within
+            #  4.2e-5 -- context_convs.weight, 128 x 128 tile kernels and weight-resident ones alike -- an absolute floor of 5e-5)
+            floor = 5e-5 if (name, hidden) == ("CausalGAT", 128) else 1e-5
+            assert e_gpu <= 4 * e_cpu + floor * max(1.0, g64.abs().max().item()), (k, e_gpu, e_cpu)
 
 
 def test_fused_per_graph_gat_forward_with_dropout_matches_oracle():
