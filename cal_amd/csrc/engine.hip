@@ -169,6 +169,7 @@ struct Engine {
     unsigned long long perm_seed; unsigned long long* perm_ctr;   // device draw of the random-intervention permutation (mode bit 16)
     int64_t* perm_dev;          // [capB] the permutation drawn by the step itself
     P2PArgs p2p; int p2p_on;    // one-shot peer-memory gradient exchange (cal_engine_p2p_bind)
+    int num_cus;                      // compute units of the device (launch-shape decisions)
     int* host_status;                 // host-mapped mirror of the status words, refreshed by every step's last kernel (cal_engine_peek_status)
     int* p2p_host_status;             // host-mapped word k_p2p_adam sets when an exchange timed out (cal_engine_p2p_status)
     int p2p_max_polls;                // bound of k_p2p_adam's flag wait (cal_engine_create: 2^22; cal_engine_p2p_set_timeout)
@@ -260,6 +261,7 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         if (cus < 3 * ((int)H / RO_CW) + 8) e->ro_step = 0;
+        e->num_cus = cus > 0 ? cus : 256;
         if (cus < 3 * ((int)H / RO_CW) * RBK_MAXRB + 8) e->ro_rows = 0;
     }
     { const char* v = getenv("CAL_AMD_ADAM_FUSED"); e->adam_fused = !(v && v[0] == '0'); }
@@ -747,7 +749,10 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
     const dim3 grid(B, nsl, nb);
     if (rs && e->ntiles > 0) PROF_LAUNCH((k_gconv_bwd<true, 2, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
     else if (rs) PROF_LAUNCH((k_gconv_bwd<true, 2>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
+    // more workgroups than CUs (packed batches, batches of > 128 graphs): the 80 KB instantiation, two workgroups per CU
+    else if (gb[0].dout && (int64_t)B * nsl * nb > e->num_cus) PROF_LAUNCH((k_gconv_bwd<false, 0, false, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
     else if (gb[0].dout) PROF_LAUNCH((k_gconv_bwd<false, 0>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
+    else if ((int64_t)B * nsl * nb > e->num_cus) PROF_LAUNCH((k_gconv_bwd<false, 1, false, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
     else PROF_LAUNCH((k_gconv_bwd<false, 1>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
     CAL_CHECK_LAUNCH("k_gconv_bwd");
     return 0;

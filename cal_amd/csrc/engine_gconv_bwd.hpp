@@ -159,18 +159,28 @@ __device__ __forceinline__ void gb_mma_rowk2(const float* a0_row, const float* a
     }
 }
 
-template <bool RS, int MODE, bool TILED = false>      // MODE 0: dOut given; 1: UP (from the upper layer's partials); 2: POOL (+ gn / gself)
-__global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
+// LEAN (MODE 0 / 1, the single-branch launches; round 5): under 80 KB of LDS and 128 registers, so TWO workgroups share a CU
+// and a launch of more workgroups than CUs (a packed batch: 240 tiles x 2 slices at NCI1-like batches of 512 graphs) stops
+// running as two rounds of latency chains -- the W slice is not staged (waves 0-3 read their rows of it straight from L2 as
+// MFMA operands in P2: 16-byte reads of a 64 KB matrix every workgroup shares), the x_hat rows have no padding (no access to
+// them is strided by a row), CSR neighbours are 16-bit.  The POOL variant (MODE 2) also holds the z rows for the SDDMM: 140 KB,
+// one workgroup per CU.
+// Chosen per launch (gconv_bwd in engine.hip): a launch of at most one workgroup per CU keeps the staged W slice -- with one
+// workgroup on a CU the two L2 round trips of P2's operand reads are exposed (config 2: 0.2386 -> 0.2418 ms with LEAN everywhere).
+template <bool RS, int MODE, bool TILED = false, bool LEAN = false>      // MODE 0: dOut given; 1: UP (from the upper layer's partials); 2: POOL (+ gn / gself)
+__global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBwdBranch2 bb, float loop_w, int N, int H,
                                                    int K, int* __restrict__ status) {
+    static_assert(!LEAN || MODE != 2, "the POOL variant does not fit two workgroups per CU");
+    constexpr int LDX = LEAN ? GC_K : GB_LDX;
     __shared__ __attribute__((aligned(16))) float Ab[GB_T * GB_LDJ];       // adjacency block Ab[j][i]: dz_i += Ab[j][i] dOut_j
     __shared__ __attribute__((aligned(16))) float Ds[GB_T * GB_LDD];       // dOut slice [j][n]; later dz [i][n]
-    __shared__ __attribute__((aligned(16))) float Ws[GC_K * GB_LDD];       // W[:, ns] as loaded: Ws[k_in][n] (row-major in n, 16 B operand reads)
-    __shared__ __attribute__((aligned(16))) float Xs[GB_T * GB_LDX];       // x_hat rows [i][k_in] (normalised, no affine)
+    __shared__ __attribute__((aligned(16))) float Ws[LEAN ? 4 : GC_K * GB_LDD];   // POOL: W[:, ns] as loaded: Ws[k_in][n] (row-major in n, 16 B operand reads)
+    __shared__ __attribute__((aligned(16))) float Xs[GB_T * LDX];          // x_hat rows [i][k_in] (normalised, no affine)
     __shared__ float mean_s[GC_K], rstd_s[GC_K], gam_s[GC_K], bet_s[GC_K];
     __shared__ int ptr_s[GB_T + 4];
     __shared__ float dis_s[GB_T], rs_s[GB_T];
-    __shared__ int en[GB_E];
+    __shared__ short en[GB_E];                           // (local node index < 64)
     __shared__ float ec[GB_E];
     __shared__ float um_s[GC_N], ur_s[GC_N], ug_s[GC_N], u1_s[GC_N], u2_s[GC_N];     // upper BatchNorm, this slice's columns
     __shared__ float bs_s[GB_NT / 64][16][4];
@@ -232,7 +242,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         }
     }
     ro_issue<GB_NT>(bx, rows, K4, [&](int i, int k4) { return *reinterpret_cast<const float4*>(br.x + (size_t)(g0 + i) * K + 4 * k4); });
-    ro_issue<GB_NT>(bw, K, 16, [&](int k, int n4) { return *reinterpret_cast<const float4*>(br.W + (size_t)k * H + ns0 + 4 * n4); });
+    if (!LEAN) ro_issue<GB_NT>(bw, K, 16, [&](int k, int n4) { return *reinterpret_cast<const float4*>(br.W + (size_t)k * H + ns0 + 4 * n4); });
     const int pv = g.ptr[g0 + min(t, rows)];
     const int pn = g.ptr[g0 + min(t + 1, rows)];
     const float dv = br.dis[g0 + min(t, rows - 1)];
@@ -311,7 +321,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         if (s < ne) {
             const int loc = nv[u] - g0;
             const bool inb = loc >= 0 && loc < rows;
-            en[s] = inb ? loc : 0; ec[s] = inb ? cv[u] : 0.f;
+            en[s] = (short)(inb ? loc : 0); ec[s] = inb ? cv[u] : 0.f;
             if (POOL) ee[s] = ev[u];
             if (!inb) atomicOr(status, 16);
         }
@@ -322,14 +332,14 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         if (t < rows) bg_s[t] = (unsigned char)min(max((int)(bgv - tg0), 0), ng - 1);
     }
     if (MODE == 0) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
-    ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) { *reinterpret_cast<float4*>(Ws + k * GB_LDD + 4 * n4) = v; });
+    if (!LEAN) ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) { *reinterpret_cast<float4*>(Ws + k * GB_LDD + 4 * n4) = v; });
     __syncthreads();                                     // per-column BN constants, row scales, zeroed Ab, CSR
     ro_commit<GB_NT>(bx, rows, K4, [&](int i, int k4, float4 v) {
         const float s = RS ? rs_s[i] : 1.f;
         const int k = 4 * k4;
         v.x = (v.x * s - mean_s[k]) * rstd_s[k]; v.y = (v.y * s - mean_s[k + 1]) * rstd_s[k + 1];
         v.z = (v.z * s - mean_s[k + 2]) * rstd_s[k + 2]; v.w = (v.w * s - mean_s[k + 3]) * rstd_s[k + 3];
-        *reinterpret_cast<float4*>(Xs + i * GB_LDX + k) = v;
+        *reinterpret_cast<float4*>(Xs + i * LDX + k) = v;
     });
     if (POOL) {
         float cs[4] = {0.f, 0.f, 0.f, 0.f};
@@ -397,7 +407,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
     }
     // rows rows .. rowsP of dOut / x_hat: zero (they are reduced over in the products below)
     for (int i = t; i < (rowsP - rows) * GB_LDD; i += GB_NT) Ds[rows * GB_LDD + i] = 0.f;
-    for (int i = t; i < (rowsP - rows) * GB_LDX; i += GB_NT) Xs[rows * GB_LDX + i] = 0.f;
+    for (int i = t; i < (rowsP - rows) * LDX; i += GB_NT) Xs[rows * LDX + i] = 0.f;
     // one lane per CSR slot, then one per self loop (LDS atomics: duplicate edges share an entry) -- a lane per ROW walked
     // a hub's slots as a chain of dependent LDS round trips while the rest of the workgroup waited
     for (int s = t; s < ne; s += GB_NT) {
@@ -458,8 +468,10 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
         // both operands row-major in the reduction index n (dz rows in Ds, W rows in Ws, stride 68 = 4 mod 32): 16 B reads,
         // four MFMA steps per read; W is staged as loaded (no transposing scatter) and dz needs no transposed copy
-        if (R == 2) gb_mma_rowk2<true>(Ds + li * GB_LDD, Ds + (32 + li) * GB_LDD, Ws + (w * 32 + li) * GB_LDD, GC_N, lk, acc[0], acc[1]);
-        else gb_mma_rowk2<false>(Ds + li * GB_LDD, nullptr, Ws + (w * 32 + li) * GB_LDD, GC_N, lk, acc[0], acc[1]);
+        // (LEAN: the lane's W row -- 64 consecutive floats of row w * 32 + li -- comes straight from global memory / L2)
+        const float* wrow = LEAN ? br.W + (size_t)min(w * 32 + li, K - 1) * H + ns0 : Ws + (w * 32 + li) * GB_LDD;
+        if (R == 2) gb_mma_rowk2<true>(Ds + li * GB_LDD, Ds + (32 + li) * GB_LDD, wrow, GC_N, lk, acc[0], acc[1]);
+        else gb_mma_rowk2<false>(Ds + li * GB_LDD, nullptr, wrow, GC_N, lk, acc[0], acc[1]);
         const int k = w * 32 + li;
         float* dxp = sl ? br.dxp1 : br.dxp0;
         // x_hat of all rows first, as ONE batch of unconditional LDS reads (rows rows .. rowsP are zero, as are their dz;
@@ -470,7 +482,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xh[q][r] = Xs[(q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * GB_LDX + k];
+            for (int r = 0; r < 16; ++r) xh[q][r] = Xs[(q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk) * LDX + k];
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -505,7 +517,7 @@ __global__ void __launch_bounds__(GB_NT) k_gconv_bwd(const CSR g, const int* __r
         auto affine = [&](float v) { return fmaf(v, gam, bet); };
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-        gb_mma<1, 2, GB_LDX, GB_LDD>(Xs + wq * 32 + li, nullptr, Ds + li, Ds + 32 + li, rowsP, lk, affine, acc);
+        gb_mma<1, 2, LDX, GB_LDD>(Xs + wq * 32 + li, nullptr, Ds + li, Ds + 32 + li, rowsP, lk, affine, acc);
 #pragma unroll
         for (int q = 0; q < 2; ++q) gc_store_tile(acc[q], slab + (size_t)(wq * 32) * H + ns0 + q * 32, H, 32, li, lk);
     }
