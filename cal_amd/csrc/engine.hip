@@ -747,7 +747,12 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
         final_task(c, p + H, B * nsl, 2 * H, H, dprod[k]);
     }
     const dim3 grid(B, nsl, nb);
-    if (rs && e->ntiles > 0) PROF_LAUNCH((k_gconv_bwd<true, 2, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
+    // the two-branch launch: 2 x B x H/64 workgroups -- at 128 graphs twice the CUs; the 80 KB instantiation runs them as ONE round
+    // (its gn goes out in slot order: only when the per-graph attention backward consumes it)
+    const bool lean2 = rs && (int64_t)B * nsl * nb > e->num_cus && gb[0].gn_slot && gb[nb - 1].gn_slot;
+    if (lean2 && e->ntiles > 0) PROF_LAUNCH((k_gconv_bwd<true, 2, true, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
+    else if (lean2) PROF_LAUNCH((k_gconv_bwd<true, 2, false, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
+    else if (rs && e->ntiles > 0) PROF_LAUNCH((k_gconv_bwd<true, 2, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
     else if (rs) PROF_LAUNCH((k_gconv_bwd<true, 2>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);
     // more workgroups than CUs (packed batches, batches of > 128 graphs): the 80 KB instantiation, two workgroups per CU
     else if (gb[0].dout && (int64_t)B * nsl * nb > e->num_cus) PROF_LAUNCH((k_gconv_bwd<false, 0, false, true>), grid, dim3(GB_NT), 0, c.st, gd, e->gptr, e->eptr, GconvBwdBranch2{{gb[0], gb[nb - 1]}}, e->loop_w, c.N, H, H, e->status);

@@ -171,7 +171,6 @@ template <bool RS, int MODE, bool TILED = false, bool LEAN = false>      // MODE
 __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBwdBranch2 bb, float loop_w, int N, int H,
                                                    int K, int* __restrict__ status) {
-    static_assert(!LEAN || MODE != 2, "the POOL variant does not fit two workgroups per CU");
     constexpr int LDX = LEAN ? GC_K : GB_LDX;
     __shared__ __attribute__((aligned(16))) float Ab[GB_T * GB_LDJ];       // adjacency block Ab[j][i]: dz_i += Ab[j][i] dOut_j
     __shared__ __attribute__((aligned(16))) float Ds[GB_T * GB_LDD];       // dOut slice [j][n]; later dz [i][n]
@@ -180,15 +179,18 @@ __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g
     __shared__ float mean_s[GC_K], rstd_s[GC_K], gam_s[GC_K], bet_s[GC_K];
     __shared__ int ptr_s[GB_T + 4];
     __shared__ float dis_s[GB_T], rs_s[GB_T];
-    __shared__ short en[GB_E];                           // (local node index < 64)
+    __shared__ unsigned char en[GB_E];                   // (local node index < 64)
     __shared__ float ec[GB_E];
-    __shared__ float um_s[GC_N], ur_s[GC_N], ug_s[GC_N], u1_s[GC_N], u2_s[GC_N];     // upper BatchNorm, this slice's columns
+    __shared__ float um_s[MODE == 1 ? GC_N : 1], ur_s[MODE == 1 ? GC_N : 1], ug_s[MODE == 1 ? GC_N : 1], u1_s[MODE == 1 ? GC_N : 1], u2_s[MODE == 1 ? GC_N : 1];     // UP: upper BatchNorm, this slice's columns
     __shared__ float bs_s[GB_NT / 64][16][4];
-    __shared__ __attribute__((aligned(16))) float Zr[MODE == 2 ? GB_T * GB_LDD : 4];       // POOL: z slice rows [j][n]
+    __shared__ __attribute__((aligned(16))) float Zr_own[(MODE == 2 && !LEAN) ? GB_T * GB_LDD : 4];       // POOL: z slice rows [j][n]
+    // LEAN POOL: the z rows live in the x_hat stage until P1 and the SDDMM are done with them; x_hat is committed only then
+    // (its registers wait through P1) -- the two are never needed at the same time
+    float* const Zr = (MODE == 2 && LEAN) ? Xs : Zr_own;
     __shared__ float gv_s[TILED ? GC_TILE_GRAPHS * GC_N : GC_N];   // POOL: gradient of this graph's pooled row (TILED: of every graph of the tile), slice columns
     __shared__ unsigned char bg_s[TILED ? GB_T : 4];     // TILED: graph (inside the tile) of every row
-    __shared__ int ee[MODE == 2 ? GB_E : 1];             // POOL: edge id of CSR slot s
-    __shared__ short er[GB_E];                           // destination row of CSR slot s
+    __shared__ int ee[(MODE == 2 && !LEAN) ? GB_E : 1];  // POOL: edge id of CSR slot s (LEAN: gn goes out in slot order only, the caller vouches for gn_slot)
+    __shared__ unsigned char er[GB_E];                   // destination row of CSR slot s (< 64)
     constexpr bool UP = MODE == 1, POOL = MODE == 2;
     static_assert(!TILED || MODE == 2, "only the POOL variant looks at the graphs inside a tile");
     BLK_CLK(0);
@@ -313,7 +315,7 @@ __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g
     if (t <= rows) ptr_s[t] = pv - e0;
     if (t < rows) {
         dis_s[t] = dv; rs_s[t] = rv;
-        for (int s = pv - e0; s < pn - e0; ++s) er[s] = (short)t;      // destination row of every slot (stores only)
+        for (int s = pv - e0; s < pn - e0; ++s) er[s] = (unsigned char)t;      // destination row of every slot (stores only)
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -321,8 +323,8 @@ __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g
         if (s < ne) {
             const int loc = nv[u] - g0;
             const bool inb = loc >= 0 && loc < rows;
-            en[s] = (short)(inb ? loc : 0); ec[s] = inb ? cv[u] : 0.f;
-            if (POOL) ee[s] = ev[u];
+            en[s] = (unsigned char)(inb ? loc : 0); ec[s] = inb ? cv[u] : 0.f;
+            if (POOL && !LEAN) ee[s] = ev[u];
             if (!inb) atomicOr(status, 16);
         }
     }
@@ -334,13 +336,16 @@ __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g
     if (MODE == 0) ro_commit<GB_NT>(bd, rows, 16, [&](int j, int n4, const float4 v) { *reinterpret_cast<float4*>(Ds + j * GB_LDD + 4 * n4) = v; });
     if (!LEAN) ro_commit<GB_NT>(bw, K, 16, [&](int k, int n4, const float4 v) { *reinterpret_cast<float4*>(Ws + k * GB_LDD + 4 * n4) = v; });
     __syncthreads();                                     // per-column BN constants, row scales, zeroed Ab, CSR
-    ro_commit<GB_NT>(bx, rows, K4, [&](int i, int k4, float4 v) {
-        const float s = RS ? rs_s[i] : 1.f;
-        const int k = 4 * k4;
-        v.x = (v.x * s - mean_s[k]) * rstd_s[k]; v.y = (v.y * s - mean_s[k + 1]) * rstd_s[k + 1];
-        v.z = (v.z * s - mean_s[k + 2]) * rstd_s[k + 2]; v.w = (v.w * s - mean_s[k + 3]) * rstd_s[k + 3];
-        *reinterpret_cast<float4*>(Xs + i * LDX + k) = v;
-    });
+    auto commit_x = [&]() {
+        ro_commit<GB_NT>(bx, rows, K4, [&](int i, int k4, float4 v) {
+            const float s = RS ? rs_s[i] : 1.f;
+            const int k = 4 * k4;
+            v.x = (v.x * s - mean_s[k]) * rstd_s[k]; v.y = (v.y * s - mean_s[k + 1]) * rstd_s[k + 1];
+            v.z = (v.z * s - mean_s[k + 2]) * rstd_s[k + 2]; v.w = (v.w * s - mean_s[k + 3]) * rstd_s[k + 3];
+            *reinterpret_cast<float4*>(Xs + i * LDX + k) = v;
+        });
+    };
+    if (!(POOL && LEAN)) commit_x();
     if (POOL) {
         float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -448,11 +453,12 @@ __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g
                 p += __shfl_xor(p, 1, 64);
                 p += __shfl_xor(p, 2, 64);
                 if (ok && q4 == 0) {
-                    if (isedge) gn[br.gn_slot ? e0 + itc : ee[itc]] = p; else gs[g0 + itc - ne] = p;
+                    if (isedge) gn[(LEAN || br.gn_slot) ? e0 + itc : ee[itc]] = p; else gs[g0 + itc - ne] = p;
                 }
             }
         }
-        __syncthreads();                                 // every wave is done reading dOut
+        __syncthreads();                                 // every wave is done reading dOut (and the z rows)
+        if (POOL && LEAN) commit_x();                    // x_hat over the z rows (visible after the barrier below)
         if (rt < R) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
