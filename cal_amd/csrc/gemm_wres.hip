@@ -132,17 +132,27 @@ __global__ void __launch_bounds__(NT) k_wres(const GemmArgs a, const int nbatch)
             dr[u] = has_rs ? aux_rs[row * aux_rs_stride] : 1.f;
         }
     };
+    // column sums: the 16 values a lane holds per column block and row block in fp32 (f1 / f2, flushed once per row block),
+    // everything across row blocks, waves and workgroups in fp64 -- per value in fp64 it was 64 x (2 conversions + add + fma)
+    // of half-rate VALU work per block inside the MFMA stream (as in k_gconv_bwd's epilogue, engine_gconv_bwd.hpp)
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
     auto emit = [&](int nb, float acc, float* cp, size_t ofs, float av, float ar, bool ok) {
         float v = acc + bvv[nb];
         v = relu ? fmaxf(v, 0.f) : v;
         if (ok) {
             cp[ofs] = v;
-            if (want_st) { s1[nb] += (double)v; s2[nb] += (double)v * (double)v; }
+            if (want_st) { f1[nb] += v; f2[nb] = fmaf(v, v, f2[nb]); }
             if (want_dot) {
                 const float xn = (av * ar - amean[nb]) * arstd[nb];
-                s1[nb] += (double)v; s2[nb] += (double)v * (double)xn;
+                f1[nb] += v; f2[nb] = fmaf(v, xn, f2[nb]);
             }
+        }
+    };
+    auto flush_sums = [&]() {
+        if (EPI != 0) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) { s1[nb] += (double)f1[nb]; s2[nb] += (double)f2[nb]; f1[nb] = 0.f; f2[nb] = 0.f; }
         }
     };
 
@@ -251,9 +261,11 @@ __global__ void __launch_bounds__(NT) k_wres(const GemmArgs a, const int nbatch)
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) prev[nb] = acc[nb];
             block(std::true_type(), rb, pb, rb + stride);
+            flush_sums();
             pb = rb; rb += stride;
         }
         drain(acc, pb);
+        flush_sums();
     }
 
     if (EPI != 0) {
