@@ -31,6 +31,15 @@ __global__ void __launch_bounds__(256) k_final(const double* parts, int P, int c
 // consumer: every workgroup needs all columns: reads R rows x cols (atomic variant) or the final row
 __global__ void __launch_bounds__(256) k_cons(const double* acc, int cols, int R, int stride, float* out) {
     double s = 0.0;
+    if (R <= 8 && stride == 1) {           // (round 5) the R reads of a column issued together, as a consumer prologue would
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            double v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = acc[(size_t)(r < R ? r : 0) * cols + c];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += r < R ? v[r] : 0.0;
+        }
+    } else
     for (int c = threadIdx.x; c < cols; c += 256)
         for (int r = 0; r < R; ++r) s += acc[((size_t)r * cols + c) * stride];
     float v = (float)s;
@@ -59,7 +68,7 @@ int main() {
     double *acc, *parts; float *x, *out;
     hipMalloc(&acc, (size_t)64 * 512 * 16 * 8); hipMalloc(&parts, (size_t)WG * 512 * 8); hipMalloc(&x, 1024); hipMalloc(&out, 4096);
     hipMemset(x, 0, 1024); hipMemset(acc, 0, (size_t)64 * 512 * 16 * 8);
-    for (int cols : {256, 512}) {
+    for (int cols : {128, 256, 512}) {
         float base = run_graph([&](hipStream_t st) {
             k_prod_rows<<<WG, 256, 0, st>>>(parts, 0, x);
             k_cons<<<WG, 256, 0, st>>>(acc, 0, 1, 1, out); }, chain);
@@ -69,7 +78,7 @@ int main() {
             k_final<<<(cols + 7) / 8, 256, 0, st>>>(parts, WG, cols, acc);
             k_cons<<<WG, 256, 0, st>>>(acc, cols, 1, 1, out); }, chain);
         printf("cols %d: partial rows + k_final + consumer:        %.2f us per pair (+%.2f)\n", cols, rows, rows - base);
-        for (int R : {1, 4, 16, 64}) for (int stride : {1, 16}) {
+        for (int R : {1, 2, 4, 8, 16}) for (int stride : {1}) {
             float t = run_graph([&](hipStream_t st) {
                 k_prod_atomic<<<WG, 256, 0, st>>>(acc, cols, R, stride, x);
                 k_cons<<<WG, 256, 0, st>>>(acc, cols, R, stride, out); }, chain);
