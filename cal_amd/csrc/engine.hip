@@ -184,7 +184,7 @@ struct Engine {
     BNSlot bn[MAX_LAYERS + 9];
     int nbn;
     // arena offsets (doubles)
-    int a_convb[MAX_LAYERS], a_cb, a_ob, a_dwn, a_dwe, a_db1, a_db2, a_sync, arena_n;
+    int a_convb[MAX_LAYERS], a_cb, a_ob, a_dwn, a_dwe, a_db1, a_db2, a_sync, arena_n, bn_plane;
     // workspace
     char* ws; size_t ws_bytes;
     int64_t capN, capE, capB;
@@ -192,6 +192,8 @@ struct Engine {
     float *h, *z, *zco, *hco, *anode, *pq, *att, *dis_unit, *dis_co, *pooled, *pcnt, *xco, *y1, *zl, *logp, *stats, *zpart;
     int adam_fused;          // 1: mode-4 steps apply Adam inside k_finish; CAL_AMD_ADAM_FUSED=0 keeps the k_adam launch
     int ro_rows;             // 1: ... also for 129 .. 512 graphs, in row blocks (k_ro_step<true>); CAL_AMD_RO_ROWS=0: the GEMM chain there
+    int striped;             // 1: the per-graph kernels exchange their BatchNorm sums through NSTRIPE accumulator planes (engine.hpp: stripe_sum)
+                             // instead of partial rows + k_stats_final; CAL_AMD_STRIPED=0 keeps the finishing launches
     int ro_step;             // 1: training steps run the readout as one launch (k_ro_step); CAL_AMD_RO_STEP=0 keeps the four kernels
     float *dzl, *dyh1, *dy1, *dxh, *dpool, *dZco, *gn, *gself, *ddeg, *dl, *dzco, *dXhco, *dZ, *dzi, *dXh, *slabs;
     size_t slab_floats;
@@ -255,6 +257,7 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     else { (void)hipGetLastError(); e->host_status = nullptr; }       // (no mirror: cal_engine_peek_status reports 0, check_status still works)
     { const char* v = getenv("CAL_AMD_RO_STEP"); e->ro_step = !(v && v[0] == '0'); }
     { const char* v = getenv("CAL_AMD_RO_ROWS"); e->ro_rows = !(v && v[0] == '0'); }
+    { const char* v = getenv("CAL_AMD_STRIPED"); e->striped = !(v && v[0] == '0'); }
     {
         // k_ro_step's 3 * H / 16 workgroups (133 KB of LDS each: one per CU) meet at spin barriers: they must all be
         // resident.  A device (or CU mask / partition) with fewer compute units than that takes the four-kernel readout.
@@ -332,13 +335,6 @@ CAL_EXPORT int cal_engine_bind(void* h, float* P, float* G, float* M1, float* M2
         e->o_fc2_w[hd] = (int)offs[s++]; e->o_fc2_b[hd] = (int)offs[s++];
     }
     int a = 0;
-    for (int i = 0; i < e->nbn; ++i) {
-        BNSlot& b = e->bn[i];
-        b.gamma = bn_g[i]; b.beta = bn_b[i]; b.width = bn_w[i];
-        b.rm = (float*)bn_ptrs[3 * i]; b.rv = (float*)bn_ptrs[3 * i + 1]; b.nbt = (int64_t*)bn_ptrs[3 * i + 2];
-        b.arena = a;
-        a += 4 * ((b.width + 3) / 4 * 4);
-    }
     for (int i = 0; i < L; ++i) { e->a_convb[i] = a; a += H; }
     e->a_cb = a; a += H;
     e->a_ob = a; a += H;
@@ -347,6 +343,18 @@ CAL_EXPORT int cal_engine_bind(void* h, float* P, float* G, float* M1, float* M2
     e->a_db1 = a; a += 3 * H;
     e->a_db2 = a; a += (3 * C + 3) / 4 * 4;
     e->a_sync = a; a += (RBK_SYNC_INTS + 1) / 2 + 2;  // barrier counters of k_ro_step (ints: 6, or RBK_SYNC_INTS row-blocked), zeroed with the arena
+    // the BatchNorm sums last: NSTRIPE planes of them, bn_plane doubles apart (engine.hpp: stripe_sum); BNSlot::arena is plane 0
+    a = (a + 3) / 4 * 4;
+    const int a_bn = a;
+    for (int i = 0; i < e->nbn; ++i) {
+        BNSlot& b = e->bn[i];
+        b.gamma = bn_g[i]; b.beta = bn_b[i]; b.width = bn_w[i];
+        b.rm = (float*)bn_ptrs[3 * i]; b.rv = (float*)bn_ptrs[3 * i + 1]; b.nbt = (int64_t*)bn_ptrs[3 * i + 2];
+        b.arena = a;
+        a += 4 * ((b.width + 3) / 4 * 4);
+    }
+    e->bn_plane = a - a_bn;
+    a = a_bn + NSTRIPE * e->bn_plane;
     e->arena_n = a;
     (void)C;
     return 0;
@@ -491,6 +499,7 @@ BNRef bnref(const Ctx& c, int k, int rows, int update) {
     r.unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
     r.update = (update && c.training) ? 1 : 0;
     r.use_running = c.training ? 0 : 1;
+    r.ss = e->bn_plane;
     return r;
 }
 double* bn_stsum(const Ctx& c, int k) { return c.e->arena + c.e->bn[k].arena; }
@@ -719,8 +728,21 @@ bool use_gc(const Ctx& c) {
 bool gc_small(const Ctx& c) { return c.e->max_nodes <= 64 && c.e->max_edges <= gc_edge_cap(64); }
 // per-graph fused backward (engine_gconv_bwd.hpp): 64-node graphs only
 bool use_gcb(const Ctx& c) { return use_gc(c) && gc_small(c) && c.T <= 128 * 4; }
-// partial-row statistics of a per-graph kernel: one row per graph
-Acc graph_acc(Ctx& c, double* dst, int cols) {
+// Which BatchNorm sites of a step go through the accumulator planes (engine.hpp: stripe_sum): those whose producers are per-graph
+// kernels and whose EVERY reader is a striped reader (k_gconv_fwd, k_gconv_bwd, k_att_bwd_graph, k_feat_bwd*, the final commit).
+//   co: bnc / bno -- statistics from k_att_fwd_graph, backward sums from the two-branch k_gconv_bwd; read by the two-branch
+//       k_gconv_fwd / k_gconv_bwd and by k_att_bwd_graph (the node-level k_att_bwd of > 256 units is a plain reader)
+//   bb: the GCNConv backbone -- statistics of layers 2..L from k_gconv_fwd, backward sums of layers L..1 from k_gconv_bwd
+//       (a GAT / GIN backbone has its own per-graph kernels: plain readers)
+bool att_graph_fwd(const Ctx& c) {
+    const Engine* e = c.e;
+    return use_gc(c) && e->max_nodes <= 4 * (512 / group_for(e->H, 4)) && e->max_edges <= GP_E;
+}
+bool striped_co(const Ctx& c) { return c.e->striped && c.training && att_graph_fwd(c) && use_gcb(c) && c.T <= 256; }
+bool striped_bb(const Ctx& c) { return c.e->striped && c.training && use_gc(c) && use_gcb(c) && c.e->K == 0 && !c.e->gin; }
+// partial-row statistics of a per-graph kernel: one row per graph; st: into the workgroup's accumulator plane, no finishing launch
+Acc graph_acc(Ctx& c, double* dst, int cols, bool st = false) {
+    if (st) return Acc(dst, nullptr, c.e->bn_plane);
     double* p = parts_alloc(c, (size_t)c.T * cols);
     if (!p) return Acc(dst);
     final_task(c, p, c.T, cols, cols, dst);
@@ -730,7 +752,7 @@ Acc graph_acc(Ctx& c, double* dst, int cols) {
 // Launch the per-graph fused backward for nb branches: slabs (one per graph) and the BatchNorm-backward partial
 // rows are registered like those of the GEMM path.  gb[k].dot_parts / .slab are filled in here.
 int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, double** dsum, double** dprod,
-              FinishArgs& fa, size_t& slab_off, bool rs) {
+              FinishArgs& fa, size_t& slab_off, bool rs, bool st) {
     Engine* e = c.e;
     const int H = e->H, B = c.T, nsl = H / GC_N;         // (B: units of this launch -- tiles or graphs)
     for (int k = 0; k < nb; ++k) {
@@ -740,6 +762,10 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
         gb[k].slab = e->slabs + slab_off;
         fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, dst[k], H * H, B};
         slab_off += need;
+        if (st) {        // the BatchNorm-backward sums go into the accumulator planes of the site (every reader adds them)
+            gb[k].dacc_sum = dsum[k]; gb[k].dacc_prod = dprod[k]; gb[k].dacc_ss = e->bn_plane;
+            continue;
+        }
         double* p = parts_alloc(c, (size_t)B * nsl * 2 * H);
         if (!p) { set_error("engine: partial-row workspace exhausted"); return 2; }
         gb[k].dot_parts = p;
@@ -1065,7 +1091,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             gb.x = e->h + (size_t)(i - 1) * NH; gb.W = e->P + e->o_conv_w[i - 1]; gb.bias = e->P + e->o_conv_b[i - 1];
             gb.dis = e->dis_unit; gb.bn = bnref(c, i, N, 1); gb.out = e->h + (size_t)i * NH;
             if (i == 1) gb.coef_out = e->coef; else gb.coef_in = e->coef;
-            if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H); }
+            if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H, striped_bb(c)); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H, striped_bb(c)); }
             {
                 ProfScope ps(st, 2, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
                 if (gc_small(c)) PROF_LAUNCH((k_gconv_fwd<false, 64, 512>), dim3(T, H / GC_N, 1), dim3(512), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1,
@@ -1094,10 +1120,11 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     }
     const float* x = e->h + (size_t)L * NH;
     // 5+6 per graph: node attention, edge softmax and weighted degrees in one kernel (4 rows per lane group)
-    const bool att_graph = gc && e->max_nodes <= 4 * (512 / group_for(H, 4)) && e->max_edges <= GP_E;
+    const bool att_graph = att_graph_fwd(c);
     if (att_graph) {
-        const Acc a0 = graph_acc(c, bn_stsum(c, L + 1), H), a1 = graph_acc(c, bn_stsq(c, L + 1), H);
-        const Acc a2 = graph_acc(c, bn_stsum(c, L + 2), H), a3 = graph_acc(c, bn_stsq(c, L + 2), H);
+        const bool sco = striped_co(c);
+        const Acc a0 = graph_acc(c, bn_stsum(c, L + 1), H, sco), a1 = graph_acc(c, bn_stsq(c, L + 1), H, sco);
+        const Acc a2 = graph_acc(c, bn_stsum(c, L + 2), H, sco), a3 = graph_acc(c, bn_stsq(c, L + 2), H, sco);
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
             hipLaunchKernelGGL((k_att_fwd_graph<4, G>), dim3(T), dim3(512), 0, st, e->gptr, gs, x, e->P + e->o_natt_w, e->P + e->o_natt_b,
@@ -1457,7 +1484,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             gb[k].gn_slot = agb ? 1 : 0;        // consumed by k_att_bwd_graph in slot order (else by k_normbwd_* in edge-id order)
             dst[k] = e->G + (k ? e->o_ow : e->o_cw); dsum[k] = bn_dsum(c, L + 1 + k); dprod[k] = bn_dprod(c, L + 1 + k);
         }
-        RC(gconv_bwd(c, gd, gb, 2, dst, dsum, dprod, fa, slab_off, true)); STAGE();
+        RC(gconv_bwd(c, gd, gb, 2, dst, dsum, dprod, fa, slab_off, true, striped_co(c))); STAGE();
         RC(flush_finals(c)); STAGE();
         // the edge-weight gradients through the normalisation are part of the per-graph attention backward below; big
         // batches (a per-graph launch would be several waves of one-per-CU workgroups) keep the node- / edge-parallel kernels
@@ -1495,7 +1522,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         const bool two = gcb && H > GC_N;               // second output-column slice of the fused backward
         aa.dxhc2 = two ? e->dzco : nullptr; aa.dxho2 = two ? e->dzco + NH : nullptr;
         aa.bnc = bnref(c, L + 1, N, 0); aa.bno = bnref(c, L + 2, N, 0);
-        aa.dsc = bn_dsum(c, L + 1); aa.dpc = bn_dprod(c, L + 1); aa.dso = bn_dsum(c, L + 2); aa.dpo = bn_dprod(c, L + 2);
+        aa.dsc = bn_dsum(c, L + 1); aa.dpc = bn_dprod(c, L + 1); aa.dso = bn_dsum(c, L + 2); aa.dpo = bn_dprod(c, L + 2); aa.dss = e->bn_plane;
         aa.Wn = e->P + e->o_natt_w; aa.We = e->P + e->o_eatt_w; aa.dl = e->dl;
         aa.fnode = e->no_node_att ? 0.f : 1.f; aa.fedge = e->no_edge_att ? 0.f : 1.f;
         aa.gs = gs; aa.gd = gd; aa.dZ = e->dZ;
@@ -1776,7 +1803,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             }
             float* dst[1] = {e->G + e->o_conv_w[i - 1]};
             double* dsum[1] = {bn_dsum(c, i)}; double* dprod[1] = {bn_dprod(c, i)};
-            { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false)); } STAGE();
+            { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false, striped_bb(c) && (i > 1 || (F <= FM_F && H <= FB_H)))); } STAGE();
             RC(flush_finals(c)); STAGE();
             if (i == 1 && F <= FM_F && H <= FB_H) {
                 // the feature layer's backward per graph, fed from this layer's partial dX' (no k_bn_bwd, no dZ round trip)
@@ -1890,8 +1917,9 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             commit_p(d_bn0.p, d_bn0.P, d_bn0.stride, b.beta, F, 1.f);
             continue;
         }
-        commit(b.arena + 3 * wp, b.gamma, b.width, 1.f);   // d gamma = sum dyh * x_n
-        commit(b.arena + 2 * wp, b.beta, b.width, 1.f);    // d beta  = sum dyh
+        // (the NSTRIPE accumulator planes of the site: engine.hpp, stripe_sum)
+        commit_p(e->arena + b.arena + 3 * wp, NSTRIPE, e->bn_plane, b.gamma, b.width, 1.f);   // d gamma = sum dyh * x_n
+        commit_p(e->arena + b.arena + 2 * wp, NSTRIPE, e->bn_plane, b.beta, b.width, 1.f);    // d beta  = sum dyh
     }
     for (int i = 0; i < L; ++i) {
         if (!d_convb[i].p) { set_error("engine: missing bias-gradient partials"); return 2; }

@@ -23,7 +23,51 @@ struct BNRef {
     float unbias;          // n / (n - 1)
     int update;
     int use_running;       // eval mode: normalise with running statistics instead of batch statistics
+    int ss;                // distance in doubles of the site's NSTRIPE accumulator planes (sum / sq point at plane 0)
 };
+
+// Striped fp64 accumulators (round 5).  A BatchNorm's column sums were one partial row per producer workgroup plus a finishing
+// launch (k_stats_final: 8 x 4.7 us of the 233 us headline step).  Where producers AND consumers are the per-graph kernels
+// (128-512 workgroups ending together) the producers now add their sums atomically into ONE OF NSTRIPE ROWS (row = workgroup %
+// NSTRIPE; the rows -- "planes" of the whole BatchNorm-sum region -- are `ss` doubles apart in the arena and zeroed with it), and
+// the consumers add the NSTRIPE rows in one fixed order: a chain of 32-128 same-address atomics per column instead of 256-512
+// (scripts/micro/atomics64.hip, profiles/r5/micro_atomics64.txt: +1.5 / +2.1 us per producer / consumer pair at eight / four
+// rows against +5.0 us for partial rows + finishing kernel and +6.1 us for one row).  Producers that finish into a single row
+// (k_stats_final, plain atomics, plain stores) write plane 0 and leave the others zero, so a STRIPED reader (the *_st helpers
+// below) is right for either kind; the plain readers are right only for single-row sites -- the engine stripes a site only
+// when every kernel that reads it is a striped reader (engine.hip: Ctx::striped).  ss == 0 (no planes): the same value read
+// NSTRIPE times and scaled back, exactly -- no branch in a kernel prologue (see bn_raw_load).
+constexpr int NSTRIPE = 4;
+__device__ __forceinline__ double stripe_sum(const double* __restrict__ p, int c, int ss) {
+    double v[NSTRIPE];
+#pragma unroll
+    for (int r = 0; r < NSTRIPE; ++r) v[r] = p[(size_t)r * ss + c];
+    double t = v[0];
+#pragma unroll
+    for (int r = 1; r < NSTRIPE; ++r) t += v[r];
+    return ss ? t : t * (1.0 / NSTRIPE);
+}
+// The same in three steps for kernel prologues: request (no arithmetic on the values: an add placed right behind the loads is
+// an s_waitcnt in front of every LATER load of the prologue -- a whole memory round trip per kernel, 6.7 us per headline step
+// when stripe_sum was used there), pin with the prologue's other loads, add afterwards.
+struct StripeVal { double v[NSTRIPE]; };
+__device__ __forceinline__ StripeVal stripe_load(const double* __restrict__ p, int c, int ss) {
+    StripeVal s;
+#pragma unroll
+    for (int r = 0; r < NSTRIPE; ++r) s.v[r] = p[(size_t)r * ss + c];
+    return s;
+}
+__device__ __forceinline__ void stripe_pin(StripeVal& s) {
+#pragma unroll
+    for (int r = 0; r < NSTRIPE; ++r) asm volatile("" : "+v"(s.v[r]));
+}
+__device__ __forceinline__ double stripe_total(const StripeVal& s, int ss) {
+    double t = s.v[0];
+#pragma unroll
+    for (int r = 1; r < NSTRIPE; ++r) t += s.v[r];
+    return ss ? t : t * (1.0 / NSTRIPE);
+}
+__device__ __forceinline__ int stripe_of_block() { return (int)((blockIdx.x + blockIdx.y + blockIdx.z) % NSTRIPE); }
 
 __device__ __forceinline__ void bn_scale_shift(const BNRef& bn, int c, float& sc, float& sh) {
     float mean, var;
@@ -101,6 +145,39 @@ struct BNRaw { double s, q; float rm, rv, g, b; };
 __device__ __forceinline__ BNRaw bn_raw_load(const BNRef& bn, int c) {
     BNRaw r;
     r.s = bn.sum[c]; r.q = bn.sq[c]; r.rm = bn.run_mean[c]; r.rv = bn.run_var[c]; r.g = bn.gamma[c]; r.b = bn.beta[c];
+    return r;
+}
+struct BNRawS { StripeVal s, q; float rm, rv, g, b; };       // striped reader of a kernel prologue: load, pin, then bn_raws_sum
+__device__ __forceinline__ BNRawS bn_raws_load(const BNRef& bn, int c) {
+    BNRawS r;
+    r.s = stripe_load(bn.sum, c, bn.ss); r.q = stripe_load(bn.sq, c, bn.ss);
+    r.rm = bn.run_mean[c]; r.rv = bn.run_var[c]; r.g = bn.gamma[c]; r.b = bn.beta[c];
+    return r;
+}
+// one register set for two BatchNorms read by disjoint lanes of a workgroup (lane-wise choice of the pointers, not a branch)
+__device__ __forceinline__ BNRawS bn_raws_load2(const BNRef& a, int ca, const BNRef& b, int cb, bool use_b) {
+    const double* ps = use_b ? b.sum : a.sum; const double* pq = use_b ? b.sq : a.sq;
+    const float* prm = use_b ? b.run_mean : a.run_mean; const float* prv = use_b ? b.run_var : a.run_var;
+    const float* pg = use_b ? b.gamma : a.gamma; const float* pb = use_b ? b.beta : a.beta;
+    const int c = use_b ? cb : ca, ss = use_b ? b.ss : a.ss;
+    BNRawS r;
+    r.s = stripe_load(ps, c, ss); r.q = stripe_load(pq, c, ss);
+    r.rm = prm[c]; r.rv = prv[c]; r.g = pg[c]; r.b = pb[c];
+    return r;
+}
+__device__ __forceinline__ void bn_raws_pin(BNRawS& r) {
+    stripe_pin(r.s); stripe_pin(r.q);
+    asm volatile("" : "+v"(r.rm), "+v"(r.rv), "+v"(r.g), "+v"(r.b));
+}
+__device__ __forceinline__ BNRaw bn_raws_sum(const BNRef& bn, const BNRawS& r) {
+    BNRaw o;
+    o.s = stripe_total(r.s, bn.ss); o.q = stripe_total(r.q, bn.ss); o.rm = r.rm; o.rv = r.rv; o.g = r.g; o.b = r.b;
+    return o;
+}
+__device__ __forceinline__ BNRaw bn_raw_load_st(const BNRef& bn, int c) {      // striped reader (outside a prologue)
+    BNRaw r;
+    r.s = stripe_sum(bn.sum, c, bn.ss); r.q = stripe_sum(bn.sq, c, bn.ss);
+    r.rm = bn.run_mean[c]; r.rv = bn.run_var[c]; r.g = bn.gamma[c]; r.b = bn.beta[c];
     return r;
 }
 __device__ __forceinline__ void bn_raw_pin(BNRaw& r) {

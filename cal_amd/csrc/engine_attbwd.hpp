@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
     __shared__ float Tc[AG_T * AG_LD], To[AG_T * AG_LD], Dm[AG_T * AG_LD];
     __shared__ double red[8][4][G * VEC];                                 // column sums: [wave][quantity][column]
     __shared__ double sc_lds[2][8];
+    __shared__ float bnk_s[8][G * VEC];                                   // per column: mean / rstd of bnc, bno; their backward means m1, m2
     __shared__ int dp_s[AG_T + 1];
     __shared__ short d_oth[GP_E], d_own[GP_E];                            // source / destination row of every by-destination slot
     __shared__ float dis_c_s[AG_T], dis_o_s[AG_T], dd_c_s[AG_T], dd_o_s[AG_T], spv_s[AG_T], sqv_s[AG_T], gs_c_s[AG_T], gs_o_s[AG_T];
@@ -85,13 +86,19 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
         // ---- round 1 (independent of the graph): per-column constants --------------------------------------------------
         float mc[VEC], rc[VEC], gc[VEC], m1c[VEC], m2c[VEC], mo[VEC], ro[VEC], go[VEC], m1o[VEC], m2o[VEC];
         float wn[VEC], wp[VEC], wq[VEC];
-        double d1c[VEC], d2c[VEC], d1o[VEC], d2o[VEC], bsc[VEC], bqc[VEC], bso[VEC], bqo[VEC];
         float w0[VEC], w1[VEC], w2[VEC], w3[VEC], w4[VEC], w5[VEC];
+        // the eight BatchNorm sums per column (statistics and backward sums of bnc / bno): a STRIPED reader (engine.hpp) -- thread
+        // t takes column t's NSTRIPE accumulator planes of each (as many registers as the VEC columns x one row it held before),
+        // and the column constants reach the lanes through LDS behind the first barrier
+        const int oc = min(t, H - 1);
+        StripeVal sv[8];
+        sv[0] = stripe_load(a.bnc.sum, oc, a.bnc.ss); sv[1] = stripe_load(a.bnc.sq, oc, a.bnc.ss);
+        sv[2] = stripe_load(a.bno.sum, oc, a.bno.ss); sv[3] = stripe_load(a.bno.sq, oc, a.bno.ss);
+        sv[4] = stripe_load(a.dsc, oc, a.dss); sv[5] = stripe_load(a.dpc, oc, a.dss);
+        sv[6] = stripe_load(a.dso, oc, a.dss); sv[7] = stripe_load(a.dpo, oc, a.dss);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             gc[j] = a.bnc.gamma[cc + j]; go[j] = a.bno.gamma[cc + j];
-            bsc[j] = a.bnc.sum[cc + j]; bqc[j] = a.bnc.sq[cc + j]; bso[j] = a.bno.sum[cc + j]; bqo[j] = a.bno.sq[cc + j];
-            d1c[j] = a.dsc[cc + j]; d2c[j] = a.dpc[cc + j]; d1o[j] = a.dso[cc + j]; d2o[j] = a.dpo[cc + j];
             w0[j] = a.Wn[cc + j]; w1[j] = a.Wn[H + cc + j];
             w2[j] = a.We[cc + j]; w3[j] = a.We[2 * H + cc + j]; w4[j] = a.We[H + cc + j]; w5[j] = a.We[3 * H + cc + j];
         }
@@ -130,10 +137,10 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
         }
         // pins: nothing above may sink below this point
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
+        for (int j = 0; j < VEC; ++j)
             asm volatile("" : "+v"(gc[j]), "+v"(go[j]), "+v"(w0[j]), "+v"(w1[j]), "+v"(w2[j]), "+v"(w3[j]), "+v"(w4[j]), "+v"(w5[j]));
-            asm volatile("" : "+v"(bsc[j]), "+v"(bqc[j]), "+v"(bso[j]), "+v"(bqo[j]), "+v"(d1c[j]), "+v"(d2c[j]), "+v"(d1o[j]), "+v"(d2o[j]));
-        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) stripe_pin(sv[q]);
         asm volatile("" : "+v"(pdv), "+v"(pdn), "+v"(dcv), "+v"(dov), "+v"(gsc), "+v"(gso), "+v"(gsc2), "+v"(gso2));
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -141,14 +148,15 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
 #pragma unroll
         for (int u = 0; u < 2; ++u) { dgc[u] = fmaf(f2, dgc2[u], dgc[u]); dgo[u] = fmaf(f2, dgo2[u], dgo[u]); }
         gsc = fmaf(f2, gsc2, gsc); gso = fmaf(f2, gso2, gso);
-        {   // BatchNorm mean / rstd of bnc and bno from their batch statistics (training-mode backward: never running stats)
+        if (t < H) {   // BatchNorm mean / rstd of bnc and bno from their batch statistics (training-mode backward: never running stats)
             const double inv = (double)a.bnc.inv_n;
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const double m_c = bsc[j] * inv, v_c = bqc[j] * inv - m_c * m_c, m_o = bso[j] * inv, v_o = bqo[j] * inv - m_o * m_o;
-                mc[j] = (float)m_c; rc[j] = 1.0f / sqrtf((float)(v_c > 0.0 ? v_c : 0.0) + a.bnc.eps);
-                mo[j] = (float)m_o; ro[j] = 1.0f / sqrtf((float)(v_o > 0.0 ? v_o : 0.0) + a.bno.eps);
-            }
+            const double bsc = stripe_total(sv[0], a.bnc.ss), bqc = stripe_total(sv[1], a.bnc.ss);
+            const double bso = stripe_total(sv[2], a.bno.ss), bqo = stripe_total(sv[3], a.bno.ss);
+            const double m_c = bsc * inv, v_c = bqc * inv - m_c * m_c, m_o = bso * inv, v_o = bqo * inv - m_o * m_o;
+            bnk_s[0][t] = (float)m_c; bnk_s[1][t] = 1.0f / sqrtf((float)(v_c > 0.0 ? v_c : 0.0) + a.bnc.eps);
+            bnk_s[2][t] = (float)m_o; bnk_s[3][t] = 1.0f / sqrtf((float)(v_o > 0.0 ? v_o : 0.0) + a.bno.eps);
+            bnk_s[4][t] = (float)(stripe_total(sv[4], a.dss) * inv); bnk_s[5][t] = (float)(stripe_total(sv[5], a.dss) * inv);
+            bnk_s[6][t] = (float)(stripe_total(sv[6], a.dss) * inv); bnk_s[7][t] = (float)(stripe_total(sv[7], a.dss) * inv);
         }
         // the dense blocks are cleared while the loads are in flight
         for (int i = t; i < AG_T * AG_LD; i += 512) { Tc[i] = 0.f; To[i] = 0.f; Dm[i] = 0.f; }
@@ -232,13 +240,13 @@ __global__ void __launch_bounds__(512) k_att_bwd_graph(const AttBwdGraphArgs ga,
         __syncthreads();
         BLK_CLK(3);
         // ---- row phase (k_att_bwd) -----------------------------------------------------------------------------------
-        const float inv_n = a.bnc.inv_n;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const bool on = cok && c + j < H;
+            mc[j] = bnk_s[0][cc + j]; rc[j] = bnk_s[1][cc + j]; mo[j] = bnk_s[2][cc + j]; ro[j] = bnk_s[3][cc + j];
             gc[j] = on ? gc[j] * rc[j] : 0.f; go[j] = on ? go[j] * ro[j] : 0.f;
-            m1c[j] = (float)(d1c[j] * (double)inv_n); m2c[j] = (float)(d2c[j] * (double)inv_n);
-            m1o[j] = (float)(d1o[j] * (double)inv_n); m2o[j] = (float)(d2o[j] * (double)inv_n);
+            m1c[j] = bnk_s[4][cc + j]; m2c[j] = bnk_s[5][cc + j];
+            m1o[j] = bnk_s[6][cc + j]; m2o[j] = bnk_s[7][cc + j];
             wn[j] = on ? w0[j] - w1[j] : 0.f; wp[j] = on ? w2[j] - w3[j] : 0.f; wq[j] = on ? w4[j] - w5[j] : 0.f;
         }
         for (int i0 = rbeg + grp; i0 < rend; i0 += RPB * UR) {

@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
     const int tg0 = TILED ? (int)br.tile_gptr[b] : b, ng = TILED ? (int)br.tile_gptr[b + 1] - tg0 : 1;
     const bool want = br.st_sum.on();
     if (rows <= 0) {                                     // empty graph: its partial rows still have to exist
-        if (br.bn.update && blockIdx.x == 0 && blockIdx.y == 0 && t < K) bn_update_running(br.bn, t);
+        if (br.bn.update && blockIdx.x == 0 && blockIdx.y == 0 && t < K) { const BNRaw r0 = bn_raw_load_st(br.bn, t); bn_raw_update_running(br.bn, r0, t); }
         if (t < GC_N) {
             if (want) { br.st_sum.add(n0 + t, 0.0); br.st_sq.add(n0 + t, 0.0); }
             if (br.pooled) for (int q = 0; q < ng; ++q) br.pooled[(size_t)(tg0 + q) * H + n0 + t] = 0.f;
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
     const int kh = w >> 2, ct = w & 1, r0 = (w & 3) >> 1;     // kh: half of the first product's reduction range (NT = 512)
     const float* biasp = br.bias ? br.bias : br.W;       // W: any valid [>= H] float array; the value is masked below
     float bias = biasp[n0 + ct * 32 + li];
-    BNRaw braw = bn_raw_load(br.bn, min(t, K - 1));
+    BNRawS braws = bn_raws_load(br.bn, min(t, K - 1));       // (striped reader: the producer may be a per-graph kernel)
     const float* coefp = br.coef_in ? br.coef_in : br.dis;
     const int coef_hi = br.coef_in ? slot_hi : 0;
     float cin[CU];                                       // coefficients of an earlier kernel of this step, if any
@@ -327,9 +327,10 @@ __global__ void __launch_bounds__(NT, (T == 64 ? 2 : 1)) k_gconv_fwd(const CSR g
     for (int u = 0; u < UA; ++u) ro_pin(va[u]);
 #pragma unroll
     for (int u = 0; u < WU; ++u) ro_pin(vb[u]);
-    bn_raw_pin(braw);
+    bn_raws_pin(braws);
 #pragma unroll
     for (int u = 0; u < CU; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]), "+v"(cin[u]));
+    const BNRaw braw = bn_raws_sum(br.bn, braws);
     asm volatile("" : "+v"(bias));
     if (!br.bias) bias = 0.f;
     if (ne <= 0) {                                       // no slot of this graph exists: what the clamped loads fetched is not an index

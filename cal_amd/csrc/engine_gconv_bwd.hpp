@@ -40,6 +40,8 @@ struct GconvBwdBranch {
     float* dxp0; float* dxp1; // [N,K] partial dX' of output-column slice 0 / 1
     float* slab;             // [B][K,H] per-graph dW
     double* dot_parts;       // [B * H/64][2K]: (sum dX', sum dX' * x_hat) partial rows
+    double* dacc_sum; double* dacc_prod; int dacc_ss;    // or (non-null): added atomically into the workgroup's plane of the site's
+                                                         // NSTRIPE accumulator planes (engine.hpp: stripe_sum; no finishing launch)
     const float* coef_in;    // edge coefficients dis_j * w_e in CSR-slot order, written by the forward kernel, or null
     // UP variant: dOut is not materialised.  It is the BatchNorm-backward (+ ReLU mask) of the layer ABOVE,
     //     dOut = relu'(y) * gamma_u rstd_u (dY - m1_u - y_hat m2_u),   dY = dy0 + dy1,
@@ -168,7 +170,7 @@ __device__ __forceinline__ void gb_mma_rowk2(const float* a0_row, const float* a
 // Chosen per launch (gconv_bwd in engine.hip): a launch of at most one workgroup per CU keeps the staged W slice -- with one
 // workgroup on a CU the two L2 round trips of P2's operand reads are exposed (config 2: 0.2386 -> 0.2418 ms with LEAN everywhere).
 template <bool RS, int MODE, bool TILED = false, bool LEAN = false>      // MODE 0: dOut given; 1: UP (from the upper layer's partials); 2: POOL (+ gn / gself)
-__global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
+__global__ void __launch_bounds__(GB_NT, (LEAN ? 4 : 1)) k_gconv_bwd(const CSR g, const int* __restrict__ gptr, const int* __restrict__ eptr,
                                                    const GconvBwdBranch2 bb, float loop_w, int N, int H,
                                                    int K, int* __restrict__ status) {
     constexpr int LDX = LEAN ? GC_K : GB_LDX;
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g
     if (rows <= 0 || rows > GB_T || ne > GB_E || ne < 0 || (TILED && (ng < 1 || ng > GC_TILE_GRAPHS))) {
         // empty graph (or a violated bound, flagged): its partial row and its slab slice must still exist
         if (rows > 0 && t == 0) atomicOr(status, 8);
-        for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
+        if (!br.dacc_sum) for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
         if ((UP || POOL) && t < GC_N) br.bias_parts[(size_t)b * H + ns0 + t] = 0.0;
         for (int i = t; i < K * GC_N; i += GB_NT) slab[(size_t)(i / GC_N) * H + ns0 + i % GC_N] = 0.f;
         return;
@@ -263,16 +265,17 @@ __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g
         ev[u] = g.eid[s];
         cin[u] = coefp[min(s, coef_hi)];
     }
-    BNRaw braw = bn_raw_load(br.bn, min(t, K - 1));
-    BNRaw uraw;
-    double ud1 = 0.0, ud2 = 0.0;
-    if (UP) {                                            // upper BatchNorm constants of this slice's 64 columns
+    // (striped readers, engine.hpp: the producers may be per-graph kernels.  Lanes 0 .. K-1 need this layer's BatchNorm, lanes
+    //  256 .. 319 the upper one's constants of this slice's 64 columns: ONE register set, the pointers chosen per lane)
+    const bool ulane = UP && t >= 256;
+    BNRawS braws = UP ? bn_raws_load2(br.bn, min(t, K - 1), br.ubn, ns0 + (t & (GC_N - 1)), ulane) : bn_raws_load(br.bn, min(t, K - 1));
+    StripeVal ud1s, ud2s;
+    if (UP) {
         const int c = ns0 + (t & (GC_N - 1));
-        uraw = bn_raw_load(br.ubn, c);
-        ud1 = br.udot_sum[c]; ud2 = br.udot_prod[c];
+        ud1s = stripe_load(br.udot_sum, c, br.ubn.ss); ud2s = stripe_load(br.udot_prod, c, br.ubn.ss);
     }
-    bn_raw_pin(braw);
-    if (UP) { bn_raw_pin(uraw); asm volatile("" : "+v"(ud1), "+v"(ud2)); }
+    bn_raws_pin(braws);
+    if (UP) { stripe_pin(ud1s); stripe_pin(ud2s); }
 #pragma unroll
     for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]), "+v"(cin[u]));
     if (POOL && !TILED) { asm volatile("" : "+v"(gv), "+v"(gv1)); gv += br.gp1 ? gv1 : 0.f; }
@@ -284,6 +287,8 @@ __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g
     if (ne <= 0) { nv[0] = g0; nv[1] = g0; ev[0] = 0; ev[1] = 0; }   // no slot of this graph exists: the clamped loads fetched no index
     if (UP && t >= 256 && t < 256 + GC_N) {
         float m1, r1;
+        const BNRaw uraw = bn_raws_sum(br.ubn, braws);
+        const double ud1 = stripe_total(ud1s, br.ubn.ss), ud2 = stripe_total(ud2s, br.ubn.ss);
         bn_raw_mean_rstd(br.ubn, uraw, m1, r1);
         um_s[t - 256] = m1; ur_s[t - 256] = r1;
         ug_s[t - 256] = uraw.g * r1;
@@ -292,6 +297,7 @@ __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g
     }
     if (t < K) {
         float m1, r1;
+        const BNRaw braw = bn_raws_sum(br.bn, braws);
         bn_raw_mean_rstd(br.bn, braw, m1, r1);
         mean_s[t] = m1; rstd_s[t] = r1;
         gam_s[t] = braw.g;
@@ -513,7 +519,12 @@ __global__ void __launch_bounds__(GB_NT, (LEAN ? 2 : 1)) k_gconv_bwd(const CSR g
         double s2 = ((double)f2[0] + (double)f2[1]) + ((double)f2[2] + (double)f2[3]);
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
-        if (lk == 0) { parts[k] = s1; parts[K + k] = s2; }
+        if (lk == 0) {
+            if (br.dacc_sum) {
+                const size_t po = (size_t)stripe_of_block() * br.dacc_ss + k;
+                atomicAdd(br.dacc_sum + po, s1); atomicAdd(br.dacc_prod + po, s2);
+            } else { parts[k] = s1; parts[K + k] = s2; }
+        }
     }
     BLK_CLK(3);
     // ---- P3: dW[:, ns] (this graph) = x'^T dz[:, ns]   (K rows x 64 columns, reduction over the graph's nodes) ---------
@@ -583,11 +594,12 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
     // BatchNorm constants: unconditional loads on clamped columns, pinned with the tile loads (BNRaw, engine.hpp)
     const int uc = min(t, H - 1), fc = min(max(t - 128, 0), F - 1);
     BNRaw uraw = bn_raw_load(a.ubn, uc), raw0 = bn_raw_load(a.bn0, fc);
-    double ud1 = a.udot_sum[uc], ud2 = a.udot_prod[uc];
+    StripeVal ud1s = stripe_load(a.udot_sum, uc, a.ubn.ss), ud2s = stripe_load(a.udot_prod, uc, a.ubn.ss);      // (striped reader)
     bn_raw_pin(uraw); bn_raw_pin(raw0);
-    asm volatile("" : "+v"(ud1), "+v"(ud2));
+    stripe_pin(ud1s); stripe_pin(ud2s);
     if (t < H) {
         float m1, r1;
+        const double ud1 = stripe_total(ud1s, a.ubn.ss), ud2 = stripe_total(ud2s, a.ubn.ss);
         bn_raw_mean_rstd(a.ubn, uraw, m1, r1);
         um_s[t] = m1; ur_s[t] = r1;
         ug_s[t] = uraw.g * r1;
@@ -763,11 +775,12 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd_mma(const int* __restrict__ 
     load_w(w / nct);
     const int uc = min(t, H - 1), fc = min(max(t - 128, 0), F - 1);
     BNRaw uraw, raw0 = bn_raw_load(a.bn0, fc);
-    double ud1 = 0.0, ud2 = 0.0;
-    if (!NOBN) { uraw = bn_raw_load(a.ubn, uc); ud1 = a.udot_sum[uc]; ud2 = a.udot_prod[uc]; bn_raw_pin(uraw); asm volatile("" : "+v"(ud1), "+v"(ud2)); }
+    StripeVal ud1s, ud2s;
+    if (!NOBN) { uraw = bn_raw_load(a.ubn, uc); ud1s = stripe_load(a.udot_sum, uc, a.ubn.ss); ud2s = stripe_load(a.udot_prod, uc, a.ubn.ss); bn_raw_pin(uraw); stripe_pin(ud1s); stripe_pin(ud2s); }
     bn_raw_pin(raw0);
     if (!NOBN && t < H) {
         float m1, r1;
+        const double ud1 = stripe_total(ud1s, a.ubn.ss), ud2 = stripe_total(ud2s, a.ubn.ss);
         bn_raw_mean_rstd(a.ubn, uraw, m1, r1);
         um_s[t] = m1; ur_s[t] = r1;
         ug_s[t] = uraw.g * r1;

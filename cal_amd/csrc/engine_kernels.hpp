@@ -35,7 +35,9 @@ struct CSR {
 // helpers
 // ------------------------------------------------------------------------------------------------
 // Destination of a per-column cross-row sum.  Two modes:
-//   atomic : dst[col] += t with one fp64 atomic per (block, column) -- fine for small launches;
+//   atomic : dst[col] += t with one fp64 atomic per (block, column) -- fine for small launches; with stride != 0 the
+//            workgroup adds into ITS plane of the site's NSTRIPE accumulator planes, `stride` doubles apart (engine.hpp:
+//            stripe_sum -- the per-graph kernels, whose consumers add the planes themselves: no finishing launch);
 //   partial: parts[blockIdx.x * stride + col] = t, one plain store; k_stats_final (or the final
 //            commit) sums the rows.  Hot-address fp64 atomics run at only ~1.5 per ns chip-wide on
 //            MI355X, so the ~230-block node-level kernels use partial rows.
@@ -49,7 +51,7 @@ struct Acc {
     __host__ __device__ bool on() const { return dst != nullptr || parts != nullptr; }
     __device__ __forceinline__ void add(int col, double t) const {
         if (parts) parts[(size_t)blockIdx.x * stride + col] = t;
-        else atomicAdd(dst + col, t);
+        else atomicAdd(dst + (size_t)stripe_of_block() * stride + col, t);
     }
 };
 
@@ -1086,7 +1088,8 @@ __global__ void k_normbwd_edge(const int* __restrict__ row32, const int* __restr
 struct AttBwdArgs {
     const float* x; const float* anode; const float* dxhc; const float* dxho;
     BNRef bnc, bno;
-    const double *dsc, *dpc, *dso, *dpo;    // dot sums of bnc / bno
+    const double *dsc, *dpc, *dso, *dpo;    // dot sums of bnc / bno (plane 0 of the NSTRIPE planes dss doubles apart: k_att_bwd_graph adds them)
+    int dss;
     const float* Wn; const float* We; const float* dl;
     CSR gs, gd;
     float* dZ;
