@@ -565,8 +565,10 @@ int fwd_gemm(Ctx& c, bool transB, const GemmArgs& a, int nbatch) {
     return use_ks(a.M) ? launch_gemm_ks(transB, a, nbatch, c.st) : launch_gemm(false, transB, a, nbatch, c.st);
 }
 // same for a GEMM epilogue (two sums per column, P = row tiles)
-void gemm_stats(Ctx& c, GemmProb& pr, int M, int N, double* d0, double* d1, bool dot, int K = 0) {
+// st: the site's readers are striped readers (engine.hpp) -- k_gemm's row tiles add into the accumulator planes, no finishing launch
+void gemm_stats(Ctx& c, GemmProb& pr, int M, int N, double* d0, double* d1, bool dot, int K = 0, bool st = false) {
     if (dot) { pr.dot_sum = d0; pr.dot_prod = d1; } else { pr.st_sum = d0; pr.st_sq = d1; }
+    if (st && (use_ks(M) || (!gemm_wres_rows(M, N, K) && !gemm_big_rows(M, K)))) { pr.st_ss = c.e->bn_plane; return; }
     const int P = use_ks(M) ? gemm_ks_row_tiles(M) : gemm_row_tiles(M, N, K);
     if ((size_t)P * N * 2 <= 4096) return;
     double* p = parts_alloc(c, (size_t)P * 2 * N);
@@ -740,6 +742,15 @@ bool att_graph_fwd(const Ctx& c) {
 }
 bool striped_co(const Ctx& c) { return c.e->striped && c.training && att_graph_fwd(c) && use_gcb(c) && c.T <= 256; }
 bool striped_bb(const Ctx& c) { return c.e->striped && c.training && use_gc(c) && use_gcb(c) && c.e->K == 0 && !c.e->gin; }
+//   gat: the same for a GATConv backbone whose layers run per graph both ways (k_ggat_fwd / k_ggat_bwd)
+bool striped_gat(const Ctx& c) {
+    const Engine* e = c.e;
+    if (!(e->striped && c.training && e->K > 0 && use_gc(c) && gc_small(c) && use_gcb(c))) return false;
+    const int D = e->H / e->K;
+    return (D == 32 || D == 64) && e->max_edges <= GG_E && e->max_edges <= GGB_E;
+}
+// the feature layer's output statistics (BatchNorm_1): read by the first backbone layer both ways and by k_feat_bwd*
+bool striped_feat(const Ctx& c) { return (striped_bb(c) || striped_gat(c)) && c.e->F <= FM_F && c.e->H <= FB_H; }
 // partial-row statistics of a per-graph kernel: one row per graph; st: into the workgroup's accumulator plane, no finishing launch
 Acc graph_acc(Ctx& c, double* dst, int cols, bool st = false) {
     if (st) return Acc(dst, nullptr, c.e->bn_plane);
@@ -977,7 +988,8 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         GemmArgs a = gemm_args(N, H, F, false, false, 1);
         a.p[0].A = x0; a.p[0].B = e->P + e->o_feat_w; a.p[0].C = e->h;
         a.p[0].xa.has_bn = 1; a.p[0].xa.bn = bnref(c, 0, N, 1);
-        if (c.training && L > 0 && !e->gin) gemm_stats(c, a.p[0], N, H, bn_stsum(c, 1), bn_stsq(c, 1), false, F);    // (a GIN layer starts with the aggregation, not a BatchNorm)
+        // (a GIN layer starts with the aggregation, not a BatchNorm; striped: BatchNorm_1 is read by k_gconv_fwd / k_gconv_bwd / k_feat_bwd* only)
+        if (c.training && L > 0 && !e->gin) gemm_stats(c, a.p[0], N, H, bn_stsum(c, 1), bn_stsq(c, 1), false, F, striped_feat(c));
         RC(fwd_gemm(c, false, a, 1)); STAGE();
         RC(flush_finals(c)); STAGE();
     }
@@ -1051,7 +1063,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
                 ga.x = e->h + (size_t)(i - 1) * NH; ga.W = e->P + e->o_conv_w[i - 1]; ga.bias = e->P + e->o_conv_b[i - 1];
                 ga.att = e->P + e->o_conv_att[i - 1]; ga.bn = bnref(c, i, N, 1); ga.out = e->h + (size_t)i * NH; ga.z = zi;
                 ga.adst = sc; ga.asrc = sc + nk; ga.mx = sc + 2 * nk; ga.den = sc + 3 * nk;
-                if (c.training && i < L) { ga.st_sum = graph_acc(c, bn_stsum(c, i + 1), H); ga.st_sq = graph_acc(c, bn_stsq(c, i + 1), H); }
+                if (c.training && i < L) { ga.st_sum = graph_acc(c, bn_stsum(c, i + 1), H, striped_gat(c)); ga.st_sq = graph_acc(c, bn_stsq(c, i + 1), H, striped_gat(c)); }
                 ga.heads = K; ga.D = D; ga.slope = e->gat_slope; ga.p = c.training ? e->gat_p : 0.f;
                 ga.seed = e->gat_seed[i - 1]; ga.ctr = (const uint64_t*)e->gat_ctr; ga.E = E;
                 {
@@ -1753,11 +1765,15 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             ga.att_slab = e->slabs + slab_off;
             fa.st[fa.nst++] = SlabTask{ga.att_slab, e->G + e->o_conv_att[i - 1], 2 * H, T};
             slab_off += need_a;
-            double* pp = parts_alloc(c, (size_t)T * nsl * 2 * H);
-            if (!pp) { set_error("engine: partial-row workspace exhausted"); return 2; }
-            ga.dot_parts = pp;
-            final_task(c, pp, T * nsl, 2 * H, H, bn_dsum(c, i));
-            final_task(c, pp + H, T * nsl, 2 * H, H, bn_dprod(c, i));
+            if (striped_gat(c) && (i > 1 || (F <= FM_F && H <= FB_H))) {      // accumulator planes: the readers below are striped readers
+                ga.dacc_sum = bn_dsum(c, i); ga.dacc_prod = bn_dprod(c, i); ga.dacc_ss = e->bn_plane;
+            } else {
+                double* pp = parts_alloc(c, (size_t)T * nsl * 2 * H);
+                if (!pp) { set_error("engine: partial-row workspace exhausted"); return 2; }
+                ga.dot_parts = pp;
+                final_task(c, pp, T * nsl, 2 * H, H, bn_dsum(c, i));
+                final_task(c, pp + H, T * nsl, 2 * H, H, bn_dprod(c, i));
+            }
             {
                 ProfScope ps(st, 8, 4.0 * N * H * H + 4.0 * (double)(c.E + N) * H, true);
                 if (i == L) PROF_LAUNCH((k_ggat_bwd<false>), dim3(T, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);

@@ -238,6 +238,9 @@ struct GemmProb {
     // parts[(row_tile * 2 + {0,1}) * N + col], instead of being added atomically (k_stats_final
     // sums them): hot-address fp64 atomics cost ~0.65 ns each chip-wide on MI355X
     double* parts;
+    // ... or (st_ss != 0, atomic mode) into the row tile's plane of the site's NSTRIPE accumulator planes, st_ss doubles apart
+    // (stripe_sum above: every reader of the site adds the planes; k_gemm and k_gemm_ks)
+    int st_ss;
 };
 
 struct GemmArgs {

@@ -593,12 +593,14 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
     for (int u = 0; u < 8; ++u) xr[u] = a.x0[(size_t)g0 * F + min(t + u * GB_NT, rows * F - 1)];
     // BatchNorm constants: unconditional loads on clamped columns, pinned with the tile loads (BNRaw, engine.hpp)
     const int uc = min(t, H - 1), fc = min(max(t - 128, 0), F - 1);
-    BNRaw uraw = bn_raw_load(a.ubn, uc), raw0 = bn_raw_load(a.bn0, fc);
-    StripeVal ud1s = stripe_load(a.udot_sum, uc, a.ubn.ss), ud2s = stripe_load(a.udot_prod, uc, a.ubn.ss);      // (striped reader)
-    bn_raw_pin(uraw); bn_raw_pin(raw0);
+    BNRawS uraws = bn_raws_load(a.ubn, uc);              // (striped readers, engine.hpp)
+    BNRaw raw0 = bn_raw_load(a.bn0, fc);
+    StripeVal ud1s = stripe_load(a.udot_sum, uc, a.ubn.ss), ud2s = stripe_load(a.udot_prod, uc, a.ubn.ss);
+    bn_raws_pin(uraws); bn_raw_pin(raw0);
     stripe_pin(ud1s); stripe_pin(ud2s);
     if (t < H) {
         float m1, r1;
+        const BNRaw uraw = bn_raws_sum(a.ubn, uraws);
         const double ud1 = stripe_total(ud1s, a.ubn.ss), ud2 = stripe_total(ud2s, a.ubn.ss);
         bn_raw_mean_rstd(a.ubn, uraw, m1, r1);
         um_s[t] = m1; ur_s[t] = r1;
@@ -774,13 +776,15 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd_mma(const int* __restrict__ 
     };
     load_w(w / nct);
     const int uc = min(t, H - 1), fc = min(max(t - 128, 0), F - 1);
-    BNRaw uraw, raw0 = bn_raw_load(a.bn0, fc);
+    BNRawS uraws;
+    BNRaw raw0 = bn_raw_load(a.bn0, fc);
     StripeVal ud1s, ud2s;
-    if (!NOBN) { uraw = bn_raw_load(a.ubn, uc); ud1s = stripe_load(a.udot_sum, uc, a.ubn.ss); ud2s = stripe_load(a.udot_prod, uc, a.ubn.ss); bn_raw_pin(uraw); stripe_pin(ud1s); stripe_pin(ud2s); }
+    if (!NOBN) { uraws = bn_raws_load(a.ubn, uc); ud1s = stripe_load(a.udot_sum, uc, a.ubn.ss); ud2s = stripe_load(a.udot_prod, uc, a.ubn.ss); bn_raws_pin(uraws); stripe_pin(ud1s); stripe_pin(ud2s); }
     bn_raw_pin(raw0);
     if (!NOBN && t < H) {
         float m1, r1;
         const double ud1 = stripe_total(ud1s, a.ubn.ss), ud2 = stripe_total(ud2s, a.ubn.ss);
+        const BNRaw uraw = bn_raws_sum(a.ubn, uraws);
         bn_raw_mean_rstd(a.ubn, uraw, m1, r1);
         um_s[t] = m1; ur_s[t] = r1;
         ug_s[t] = uraw.g * r1;

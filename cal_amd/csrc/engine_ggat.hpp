@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
     const bool want = a.st_sum.on();
     if (rows <= 0) {
-        if (a.bn.update && blockIdx.x == 0 && blockIdx.y == 0 && t < K) bn_update_running(a.bn, t);
+        if (a.bn.update && blockIdx.x == 0 && blockIdx.y == 0 && t < K) { const BNRaw r0 = bn_raw_load_st(a.bn, t); bn_raw_update_running(a.bn, r0, t); }
         if (t < GC_N && want) { a.st_sum.add(n0 + t, 0.0); a.st_sq.add(n0 + t, 0.0); }
         return;
     }
@@ -108,15 +108,16 @@ __global__ void __launch_bounds__(256) k_ggat_fwd(const CSR g, const int* __rest
     const int ct = w & 1, r0 = w >> 1;
     const float* biasp = a.bias ? a.bias : a.W;          // W: any valid [>= H] float array; the value is masked below
     float bias = biasp[n0 + ct * 32 + li];
-    BNRaw braw = bn_raw_load(a.bn, min(t, K - 1));
+    BNRawS braws = bn_raws_load(a.bn, min(t, K - 1));     // (striped reader, engine.hpp)
 #pragma unroll
     for (int u = 0; u < UA; ++u) ro_pin(va[u]);
 #pragma unroll
     for (int u = 0; u < 8; ++u) ro_pin(vb[u]);
-    bn_raw_pin(braw);
+    bn_raws_pin(braws);
 #pragma unroll
     for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]));
     asm volatile("" : "+v"(pv), "+v"(attv), "+v"(bias));
+    const BNRaw braw = bn_raws_sum(a.bn, braws);
     if (!a.bias) bias = 0.f;
     if (t >= 2 * GC_N) attv = 0.f;
     if (ne <= 0) {                                       // no slot of this graph exists: the clamped loads fetched no index
@@ -322,6 +323,7 @@ struct GgatBwdArgs {
     float* slab;             // [B][K,H] per-graph dW
     float* att_slab;         // [B][heads * 2 D] per-graph d att
     double* dot_parts;       // [B * H/64][2K]
+    double* dacc_sum; double* dacc_prod; int dacc_ss;    // or (non-null): into the workgroup's accumulator plane (engine.hpp: stripe_sum)
     int heads, D;
     float slope, p;
     uint64_t seed;
@@ -368,7 +370,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     float* aslab = a.att_slab + (size_t)b * a.heads * 2 * D + (size_t)h0 * 2 * D;      // this slice's hs * 2 D = 128 entries
     if (rows <= 0 || rows > T || ne > GGB_E || ne < 0) {
         if (rows > 0 && t == 0) atomicOr(status, 8);
-        for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
+        if (!a.dacc_sum) for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
         for (int i = t; i < K * GC_N; i += GB_NT) slab[(size_t)(i / GC_N) * H + ns0 + i % GC_N] = 0.f;
         if (t < 2 * GC_N) aslab[t] = 0.f;
         if (UP && t < GC_N) a.bias_parts[(size_t)b * H + ns0 + t] = 0.0;
@@ -406,22 +408,23 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     const float* ssrc = sk == 0 ? a.adst : (sk == 1 ? a.asrc : (sk == 2 ? a.mx : a.den));
     float scv = ssrc[(size_t)(g0 + min(sn, rows - 1)) * a.heads + h0 + min(sh, hs - 1)];
     float attv = a.att[(size_t)h0 * 2 * D + min(t, 2 * GC_N - 1)];
-    BNRaw braw = bn_raw_load(a.bn, min(t, K - 1));
-    BNRaw uraw;
-    double ud1 = 0.0, ud2 = 0.0;
+    // (striped readers, engine.hpp; one register set for the two BatchNorms: lanes 0 .. K-1 this layer's, 256 .. 319 the upper one's)
+    const bool ulane = UP && t >= 256;
+    BNRawS braws = UP ? bn_raws_load2(a.bn, min(t, K - 1), a.ubn, ns0 + (t & (GC_N - 1)), ulane) : bn_raws_load(a.bn, min(t, K - 1));
+    StripeVal ud1s, ud2s;
     if (UP) {
         const int c = ns0 + (t & (GC_N - 1));
-        uraw = bn_raw_load(a.ubn, c);
-        ud1 = a.udot_sum[c]; ud2 = a.udot_prod[c];
+        ud1s = stripe_load(a.udot_sum, c, a.ubn.ss); ud2s = stripe_load(a.udot_prod, c, a.ubn.ss);
     }
-    bn_raw_pin(braw);
-    if (UP) { bn_raw_pin(uraw); asm volatile("" : "+v"(ud1), "+v"(ud2)); }
+    bn_raws_pin(braws);
+    if (UP) { stripe_pin(ud1s); stripe_pin(ud2s); }
     asm volatile("" : "+v"(pv), "+v"(pn), "+v"(nv[0]), "+v"(nv[1]), "+v"(ev[0]), "+v"(ev[1]), "+v"(scv), "+v"(attv));
     if (ne <= 0) { nv[0] = g0; nv[1] = g0; ev[0] = 0; ev[1] = 0; }   // no slot of this graph exists: the clamped loads fetched no index
     if (sh >= hs) scv = 0.f;
     if (t >= 2 * GC_N) attv = 0.f;
     if (t < K) {
         float m1, r1;
+        const BNRaw braw = bn_raws_sum(a.bn, braws);
         bn_raw_mean_rstd(a.bn, braw, m1, r1);
         mean_s[t] = m1; rstd_s[t] = r1;
         gam_s[t] = braw.g;
@@ -448,6 +451,8 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
     if (t < 2 * T) { dad_s[t >> 6][t & 63] = 0.f; das_s[t >> 6][t & 63] = 0.f; }
     if (UP && t >= 256 && t < 256 + GC_N) {              // upper BatchNorm constants of this slice's 64 columns
         float m1, r1;
+        const BNRaw uraw = bn_raws_sum(a.ubn, braws);
+        const double ud1 = stripe_total(ud1s, a.ubn.ss), ud2 = stripe_total(ud2s, a.ubn.ss);
         bn_raw_mean_rstd(a.ubn, uraw, m1, r1);
         um_s[t - 256] = m1; ur_s[t - 256] = r1;
         ug_s[t - 256] = uraw.g * r1;
@@ -710,7 +715,12 @@ __global__ void __launch_bounds__(GB_NT) k_ggat_bwd(const CSR g, const int* __re
         double s2 = ((double)f2[0] + (double)f2[1]) + ((double)f2[2] + (double)f2[3]);
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
-        if (lk == 0) { parts[k] = s1; parts[K + k] = s2; }
+        if (lk == 0) {
+            if (a.dacc_sum) {
+                const size_t po = (size_t)stripe_of_block() * a.dacc_ss + k;
+                atomicAdd(a.dacc_sum + po, s1); atomicAdd(a.dacc_prod + po, s2);
+            } else { parts[k] = s1; parts[K + k] = s2; }
+        }
     }
     // ---- P3: dW[:, ns] (this graph) = x'^T dz[:, ns] ------------------------------------------------------------------------
     if (w >= 4 && (w - 4) * 32 < K) {

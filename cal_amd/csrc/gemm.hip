@@ -374,8 +374,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int vecA, int vecB
                 pr.parts[((size_t)bx * 2 + 0) * N + col] = t1;
                 pr.parts[((size_t)bx * 2 + 1) * N + col] = t2;
             } else {
-                atomicAdd((want_st ? pr.st_sum : pr.dot_sum) + col, t1);
-                atomicAdd((want_st ? pr.st_sq : pr.dot_prod) + col, t2);
+                const size_t po = (size_t)(bx % NSTRIPE) * pr.st_ss + col;
+                atomicAdd((want_st ? pr.st_sum : pr.dot_sum) + po, t1);
+                atomicAdd((want_st ? pr.st_sq : pr.dot_prod) + po, t2);
             }
         }
     }

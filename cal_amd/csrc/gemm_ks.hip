@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) k_gemm_ks(const GemmArgs a) {
             if (n0 + c < N) {
                 const double t = cred[0][which][c] + cred[1][which][c] + cred[2][which][c] + cred[3][which][c];
                 if (pr.parts) pr.parts[((size_t)blockIdx.x * 2 + which) * N + n0 + c] = t;
-                else atomicAdd((which ? (want_st ? pr.st_sq : pr.dot_prod) : (want_st ? pr.st_sum : pr.dot_sum)) + n0 + c, t);
+                else atomicAdd((which ? (want_st ? pr.st_sq : pr.dot_prod) : (want_st ? pr.st_sum : pr.dot_sum)) + (size_t)(blockIdx.x % NSTRIPE) * pr.st_ss + n0 + c, t);
             }
         }
     }
