@@ -13,6 +13,17 @@ __global__ void __launch_bounds__(256) k_prod_atomic(double* acc, int cols, int 
     double* row = acc + (size_t)(blockIdx.x % R) * cols * stride;
     for (int c = threadIdx.x; c < cols; c += 256) atomicAdd(row + (size_t)c * stride, (double)v);
 }
+// (round 5) plane = the XCD the workgroup runs on (HW_REG_XCC_ID), workgroup-scope atomics: every add to a plane comes from ONE
+// XCD, so its L2 can perform it (the L2s are not coherent with each other, which is why agent-scope atomics go to memory); the
+// kernel boundary writes the planes back like any other store
+__global__ void __launch_bounds__(256) k_prod_atomic_xcc(double* acc, int cols, const float* x, int* xcc_seen) {
+    float v = x[threadIdx.x];
+    for (int i = 0; i < 300; ++i) v = fmaf(v, 1.0001f, 0.5f);
+    const int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15;          // HW_REG_XCC_ID[3:0]
+    if (threadIdx.x == 0 && xcc_seen) xcc_seen[blockIdx.x] = xcc;
+    double* row = acc + (size_t)(xcc & 7) * cols;
+    for (int c = threadIdx.x; c < cols; c += 256) __hip_atomic_fetch_add(row + c, (double)v + 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __global__ void __launch_bounds__(256) k_prod_rows(double* parts, int cols, const float* x) {
     float v = x[threadIdx.x];
     for (int i = 0; i < 300; ++i) v = fmaf(v, 1.0001f, 0.5f);
@@ -83,6 +94,26 @@ int main() {
                 k_prod_atomic<<<WG, 256, 0, st>>>(acc, cols, R, stride, x);
                 k_cons<<<WG, 256, 0, st>>>(acc, cols, R, stride, out); }, chain);
             printf("cols %d: fp64 atomics into R=%2d rows, column stride %2d doubles: %.2f us per pair (+%.2f)\n", cols, R, stride, t, t - base);
+        }
+        {
+            float t = run_graph([&](hipStream_t st) {
+                k_prod_atomic_xcc<<<WG, 256, 0, st>>>(acc, cols, x, nullptr);
+                k_cons<<<WG, 256, 0, st>>>(acc, cols, 8, 1, out); }, chain);
+            printf("cols %d: fp64 atomics, workgroup scope, plane = XCC_ID (8 rows): %.2f us per pair (+%.2f)\n", cols, t, t - base);
+            // check: one launch on zeroed planes -> every column sums to WG * (v + 1) = WG (x = 0 -> v converges to a constant; compare planes' total across columns)
+            int* seen; hipMalloc(&seen, WG * 4);
+            hipMemset(acc, 0, (size_t)8 * cols * 8);
+            k_prod_atomic_xcc<<<WG, 256>>>(acc, cols, x, seen);
+            hipDeviceSynchronize();
+            std::vector<double> h(8 * cols); std::vector<int> hs(WG);
+            hipMemcpy(h.data(), acc, h.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(hs.data(), seen, WG * 4, hipMemcpyDeviceToHost);
+            double tot0 = 0, totl = 0; int cnt[16] = {0};
+            for (int r = 0; r < 8; ++r) { tot0 += h[(size_t)r * cols]; totl += h[(size_t)r * cols + cols - 1]; }
+            for (int i = 0; i < WG; ++i) cnt[hs[i] & 15]++;
+            printf("   check: column 0 total %.6f, last column total %.6f over 8 planes (expect equal, = %d contributions); workgroups per XCC:", tot0, totl, WG);
+            for (int i = 0; i < 16; ++i) if (cnt[i]) printf(" %d:%d", i, cnt[i]);
+            printf("\n");
+            hipMemset(acc, 0, (size_t)64 * 512 * 16 * 8);
         }
     }
     return 0;

@@ -659,3 +659,37 @@ def test_large_graph_plan_equals_the_generic_plan():
     assert int(deg.max()) > 64                          # hub rows are ranked too
     assert torch.allclose(got["big"][1][:4], got["generic"][1][:4], atol=1e-5)
     assert torch.allclose(got["big"][2], got["generic"][2], atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["CausalGCN", "CausalGAT"])
+def test_striped_batchnorm_sums_match_the_finishing_launches(name, monkeypatch):
+    """The per-graph kernels hand their BatchNorm column sums over through the accumulator planes of engine.hpp (stripe_sum:
+    producers add atomically into one of NSTRIPE rows, consumers add the rows) instead of partial rows + k_stats_final
+    (model.py:38,44,49-50: torch BatchNorm1d over all nodes of the batch).  One train step of the headline shape with
+    CAL_AMD_STRIPED=1 (default) and =0: the same loss, log-probabilities and gradients up to the order of the fp64 additions,
+    no finishing launch left in the striped step, and the running statistics updated alike."""
+    from cal_amd import spmotif
+    from cal_amd.data import Batch
+    bd = Batch.from_data_list(spmotif.train_mix(128, seed=11)).to(DEV)
+    perm = torch.randperm(128, generator=torch.Generator().manual_seed(3)).to(DEV)
+    torch.manual_seed(23)
+    sd = O.init_state(name, 10, 4, hidden=128, layers=3, **({"heads": 4} if name == "CausalGAT" else {}))
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CAL_AMD_STRIPED", flag)
+        m, eng = _engine(name, {k: v.clone() for k, v in sd.items()}, _args(hidden=128))
+        eng.train_step(bd, perm, adam=False)
+        eng.check_status()
+        names = _stage_names()
+        out[flag] = (eng.buffer("stats", 5).cpu().clone(), eng.buffer("logp", 3 * 128 * 4).cpu().clone(),
+                     {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None},
+                     {k: v.detach().cpu().clone() for k, v in m.state_dict().items() if "running" in k}, names)
+    s1, s0 = out["1"], out["0"]
+    assert "k_stats_final" not in s1[4], s1[4]
+    assert s0[4].count("k_stats_final") >= 6, s0[4]
+    assert torch.allclose(s1[0], s0[0], rtol=1e-6, atol=1e-7)
+    assert (s1[1] - s0[1]).abs().max().item() < 1e-6
+    for k in s0[2]:
+        scale = max(1.0, s0[2][k].abs().max().item())
+        assert (s1[2][k] - s0[2][k]).abs().max().item() <= 2e-5 * scale, k
+    assert s0[3] and all(torch.allclose(s1[3][k], s0[3][k], rtol=1e-6, atol=1e-7) for k in s0[3])
