@@ -749,8 +749,16 @@ bool striped_gat(const Ctx& c) {
     const int D = e->H / e->K;
     return (D == 32 || D == 64) && e->max_edges <= GG_E && e->max_edges <= GGB_E;
 }
+//   node: the node-level GCNConv chain of a SMALL batch (graphs beyond the per-graph kernels: configs[0], 230-250 nodes each) -- the
+//       sums that leave a GEMM epilogue (feature-layer statistics, every backward sum) go into the planes; their readers are the
+//       small-batch GEMMs' prologues (gemm.hip / gemm_ks.hip: striped readers), k_bn_bwd<.., ST> and k_att_bwd<.., ST>.  The
+//       aggregation / attention kernels' statistics keep their partial rows (thousands of short workgroups).
+bool striped_node(const Ctx& c) {
+    const Engine* e = c.e;
+    return e->striped && c.training && !use_gc(c) && e->K == 0 && !e->gin && c.N < 16384 && c.N > 0;
+}
 // the feature layer's output statistics (BatchNorm_1): read by the first backbone layer both ways and by k_feat_bwd*
-bool striped_feat(const Ctx& c) { return (striped_bb(c) || striped_gat(c)) && c.e->F <= FM_F && c.e->H <= FB_H; }
+bool striped_feat(const Ctx& c) { return ((striped_bb(c) || striped_gat(c)) && c.e->F <= FM_F && c.e->H <= FB_H) || striped_node(c); }
 // partial-row statistics of a per-graph kernel: one row per graph; st: into the workgroup's accumulator plane, no finishing launch
 Acc graph_acc(Ctx& c, double* dst, int cols, bool st = false) {
     if (st) return Acc(dst, nullptr, c.e->bn_plane);
@@ -1522,7 +1530,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a.p[k].A = e->dzco + (size_t)k * NH; a.p[k].B = e->P + (k ? e->o_ow : e->o_cw); a.p[k].C = e->dXhco + (size_t)k * NH;
             a.p[k].aux = x; a.p[k].aux_rs = e->anode + k; a.p[k].aux_rs_stride = 2; a.p[k].has_aux = 1;
             a.p[k].aux_bn = bnref(c, L + 1 + k, N, 0);
-            gemm_stats(c, a.p[k], N, H, bn_dsum(c, L + 1 + k), bn_dprod(c, L + 1 + k), true, H);
+            gemm_stats(c, a.p[k], N, H, bn_dsum(c, L + 1 + k), bn_dprod(c, L + 1 + k), true, H, striped_node(c));
         }
         RC(dual_gemm(c, a, 2, aw, 2, dst, fa, slab_off)); STAGE();
         RC(flush_finals(c)); STAGE();
@@ -1559,7 +1567,8 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         if (!aa.dWn.on() || !aa.dWe.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            hipLaunchKernelGGL((k_att_bwd<4, G>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, aa, 1, N, H, c.rpb_n);
+            if (striped_node(c)) hipLaunchKernelGGL((k_att_bwd<4, G, true>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, aa, 1, N, H, c.rpb_n);
+            else hipLaunchKernelGGL((k_att_bwd<4, G>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, aa, 1, N, H, c.rpb_n);
             return 0;
         }));
         CAL_CHECK_LAUNCH("k_att_bwd"); STAGE();
@@ -1868,7 +1877,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             a = gemm_args(N, H, H, false, true, 0);
             a.p[0].A = dzi; a.p[0].B = e->P + e->o_conv_w[i - 1]; a.p[0].C = e->dXh;
             a.p[0].aux = hin; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, i, N, 0);
-            gemm_stats(c, a.p[0], N, H, bn_dsum(c, i), bn_dprod(c, i), true, H);
+            gemm_stats(c, a.p[0], N, H, bn_dsum(c, i), bn_dprod(c, i), true, H, striped_node(c));
             { ProfScope ps(st, 3, 4.0 * N * H * H); RC(dual_gemm(c, a, 1, aw, 1, dst, fa, slab_off)); } STAGE();
             RC(flush_finals(c)); STAGE();
         }
@@ -1898,7 +1907,8 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
                         i >= 2 ? deferred(H, d_convb[i - 2]) : Acc()};
             RC(with_g(H, [&](auto g) {
                 constexpr int G = decltype(g)::value;
-                hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, BnBwdProb3{{p, p, p}}, 1, N, H, c.rpb_n);
+                if (striped_node(c)) hipLaunchKernelGGL((k_bn_bwd<4, G, true>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, BnBwdProb3{{p, p, p}}, 1, N, H, c.rpb_n);
+                else hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, BnBwdProb3{{p, p, p}}, 1, N, H, c.rpb_n);
                 return 0;
             }));
             CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();

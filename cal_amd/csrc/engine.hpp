@@ -69,14 +69,16 @@ __device__ __forceinline__ double stripe_total(const StripeVal& s, int ss) {
 }
 __device__ __forceinline__ int stripe_of_block() { return (int)((blockIdx.x + blockIdx.y + blockIdx.z) % NSTRIPE); }
 
+// (ST: striped reader -- the site's NSTRIPE accumulator planes are added here: the small-batch GEMMs, k_bn_bwd<.., ST>)
+template <bool ST = false>
 __device__ __forceinline__ void bn_scale_shift(const BNRef& bn, int c, float& sc, float& sh) {
     float mean, var;
     if (bn.use_running) {
         mean = bn.run_mean[c];
         var = bn.run_var[c];
     } else {
-        double m = bn.sum[c] * (double)bn.inv_n;
-        double v = bn.sq[c] * (double)bn.inv_n - m * m;
+        double m = (ST ? stripe_sum(bn.sum, c, bn.ss) : bn.sum[c]) * (double)bn.inv_n;
+        double v = (ST ? stripe_sum(bn.sq, c, bn.ss) : bn.sq[c]) * (double)bn.inv_n - m * m;
         mean = (float)m;
         var = (float)(v > 0.0 ? v : 0.0);
     }
@@ -88,14 +90,15 @@ __device__ __forceinline__ void bn_scale_shift(const BNRef& bn, int c, float& sc
 }
 
 // mean / rstd only (for the normalised value x_n = (x - mean) * rstd used by BN backward)
+template <bool ST = false>
 __device__ __forceinline__ void bn_mean_rstd(const BNRef& bn, int c, float& mean, float& rstd) {
     float var;
     if (bn.use_running) {
         mean = bn.run_mean[c];
         var = bn.run_var[c];
     } else {
-        double m = bn.sum[c] * (double)bn.inv_n;
-        double v = bn.sq[c] * (double)bn.inv_n - m * m;
+        double m = (ST ? stripe_sum(bn.sum, c, bn.ss) : bn.sum[c]) * (double)bn.inv_n;
+        double v = (ST ? stripe_sum(bn.sq, c, bn.ss) : bn.sq[c]) * (double)bn.inv_n - m * m;
         mean = (float)m;
         var = (float)(v > 0.0 ? v : 0.0);
     }
@@ -105,7 +108,7 @@ __device__ __forceinline__ void bn_mean_rstd(const BNRef& bn, int c, float& mean
 // The same for the VEC consecutive columns c .. c+VEC-1 with every load issued before the first use:
 // called per column, each column's loads sit in their own conditional block and hipcc waits for one
 // column before it requests the next -- VEC dependent round trips in a kernel prologue.
-template <int VEC>
+template <int VEC, bool ST = false>
 __device__ __forceinline__ void bn_mean_rstd_v(const BNRef& bn, int c, float (&mean)[VEC], float (&rstd)[VEC]) {
     if (bn.use_running) {
         float rv[VEC];
@@ -116,7 +119,7 @@ __device__ __forceinline__ void bn_mean_rstd_v(const BNRef& bn, int c, float (&m
     } else {
         double s[VEC], q[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { s[j] = bn.sum[c + j]; q[j] = bn.sq[c + j]; }
+        for (int j = 0; j < VEC; ++j) { s[j] = ST ? stripe_sum(bn.sum, c + j, bn.ss) : bn.sum[c + j]; q[j] = ST ? stripe_sum(bn.sq, c + j, bn.ss) : bn.sq[c + j]; }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const double m = s[j] * (double)bn.inv_n, v = q[j] * (double)bn.inv_n - m * m;
@@ -126,9 +129,10 @@ __device__ __forceinline__ void bn_mean_rstd_v(const BNRef& bn, int c, float (&m
     }
 }
 
+template <bool ST = false>
 __device__ __forceinline__ void bn_update_running(const BNRef& bn, int c) {
-    double m = bn.sum[c] * (double)bn.inv_n;
-    double v = bn.sq[c] * (double)bn.inv_n - m * m;
+    double m = (ST ? stripe_sum(bn.sum, c, bn.ss) : bn.sum[c]) * (double)bn.inv_n;
+    double v = (ST ? stripe_sum(bn.sq, c, bn.ss) : bn.sq[c]) * (double)bn.inv_n - m * m;
     if (v < 0.0) v = 0.0;
     bn.run_mean[c] = 0.9f * bn.run_mean[c] + 0.1f * (float)m;
     bn.run_var[c] = 0.9f * bn.run_var[c] + 0.1f * (float)(v * (double)bn.unbias);

@@ -931,7 +931,9 @@ struct BnBwdProb {
 
 struct BnBwdProb3 { BnBwdProb p[3]; };
 
-template <int VEC, int G>
+// ST: striped reader (engine.hpp: the statistics / backward sums may sit in the site's NSTRIPE accumulator planes -- small batches,
+// whose GEMM epilogues add into them instead of leaving partial rows for k_stats_final)
+template <int VEC, int G, bool ST = false>
 __global__ void __launch_bounds__(256) k_bn_bwd(const BnBwdProb3 pp, int relu,
                                                 int N, int W, int rows_per_block) {
     __shared__ double lds[256 * (VEC == 4 ? 4 : 1)];
@@ -952,9 +954,10 @@ __global__ void __launch_bounds__(256) k_bn_bwd(const BnBwdProb3 pp, int relu,
             for (int j = 0; j < VEC; ++j) {
                 cs[j] = 0.0;
                 gs[j] = p.bn.gamma ? p.bn.gamma[cb + j] : 1.f;
-                ds[j] = p.dot_sum[cb + j]; dp[j] = p.dot_prod[cb + j];
+                ds[j] = ST ? stripe_sum(p.dot_sum, cb + j, p.bn.ss) : p.dot_sum[cb + j];
+                dp[j] = ST ? stripe_sum(p.dot_prod, cb + j, p.bn.ss) : p.dot_prod[cb + j];
             }
-            bn_mean_rstd_v<VEC>(p.bn, cb, mean, rstd);
+            bn_mean_rstd_v<VEC, ST>(p.bn, cb, mean, rstd);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 gs[j] *= rstd[j];
@@ -1100,10 +1103,13 @@ struct AttBwdArgs {
     float fnode, fedge;                       // 0 for without_node_attention / without_edge_attention (constant masks), else 1
 };
 
-template <int VEC, int G>
+// ST: striped reader of the four backward sums (a.dss: they may sit in the sites' NSTRIPE accumulator planes, engine.hpp) -- thread t
+// adds the planes of column t, the per-column means reach the lanes through LDS
+template <int VEC, int G, bool ST = false>
 __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, int N, int H, int rows_per_block) {
     warm_kernargs<sizeof(AttBwdArgs) + 16>();
     __shared__ double lds[4 * 256 * (VEC == 4 ? 4 : 1)];
+    __shared__ float mk_s[ST ? 4 : 1][ST ? 256 : 1];
     __shared__ double sc_lds[2][256 / G];
     constexpr int RPB = 256 / G;
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
@@ -1122,23 +1128,37 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
         const int cb = min(c, H - VEC);
         double d1c[VEC], d2c[VEC], d1o[VEC], d2o[VEC];
         float w0[VEC], w1[VEC], w2[VEC], w3[VEC], w4[VEC], w5[VEC];
+        StripeVal sq[4];
+        const int oc = min((int)threadIdx.x, H - 1);
+        if constexpr (ST) {
+            sq[0] = stripe_load(a.dsc, oc, a.dss); sq[1] = stripe_load(a.dpc, oc, a.dss);
+            sq[2] = stripe_load(a.dso, oc, a.dss); sq[3] = stripe_load(a.dpo, oc, a.dss);
+        }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             cs_b[j] = cs_n[j] = cs_p[j] = cs_q[j] = 0.0;
             gc[j] = a.bnc.gamma ? a.bnc.gamma[cb + j] : 1.f;
             go[j] = a.bno.gamma ? a.bno.gamma[cb + j] : 1.f;
-            d1c[j] = a.dsc[cb + j]; d2c[j] = a.dpc[cb + j]; d1o[j] = a.dso[cb + j]; d2o[j] = a.dpo[cb + j];
+            if constexpr (!ST) { d1c[j] = a.dsc[cb + j]; d2c[j] = a.dpc[cb + j]; d1o[j] = a.dso[cb + j]; d2o[j] = a.dpo[cb + j]; }
             w0[j] = a.Wn[cb + j]; w1[j] = a.Wn[H + cb + j];
             w2[j] = a.We[cb + j]; w3[j] = a.We[2 * H + cb + j]; w4[j] = a.We[H + cb + j]; w5[j] = a.We[3 * H + cb + j];
         }
         bn_mean_rstd_v<VEC>(a.bnc, cb, mc, rc);
         bn_mean_rstd_v<VEC>(a.bno, cb, mo, ro);
+        if constexpr (ST) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { stripe_pin(sq[q]); mk_s[q][threadIdx.x] = (float)(stripe_total(sq[q], a.dss) * (double)inv_n); }
+            __syncthreads();
+        }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const bool on = cok && c + j < H;
             gc[j] = on ? gc[j] * rc[j] : 0.f; go[j] = on ? go[j] * ro[j] : 0.f;
+            if constexpr (ST) { m1c[j] = mk_s[0][cb + j]; m2c[j] = mk_s[1][cb + j]; m1o[j] = mk_s[2][cb + j]; m2o[j] = mk_s[3][cb + j]; }
+            else {
             m1c[j] = (float)(d1c[j] * (double)inv_n); m2c[j] = (float)(d2c[j] * (double)inv_n);
             m1o[j] = (float)(d1o[j] * (double)inv_n); m2o[j] = (float)(d2o[j] * (double)inv_n);
+            }
             wn[j] = on ? w0[j] - w1[j] : 0.f; wp[j] = on ? w2[j] - w3[j] : 0.f; wq[j] = on ? w4[j] - w5[j] : 0.f;
         }
     }

@@ -242,8 +242,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int vecA, int vecB
         const int cnt = A_KC ? (ke - kb) : min(BM, M - m0);
         const int c0 = A_KC ? kb : m0;
         for (int t = threadIdx.x; t < cnt; t += 256) {
-            bn_scale_shift(pr.xa.bn, c0 + t, xsc[0][t], xsh[0][t]);
-            if (pr.xa.bn.update && by == 0 && split == 0 && (A_KC ? bx == 0 : true)) bn_update_running(pr.xa.bn, c0 + t);
+            bn_scale_shift<true>(pr.xa.bn, c0 + t, xsc[0][t], xsh[0][t]);
+            if (pr.xa.bn.update && by == 0 && split == 0 && (A_KC ? bx == 0 : true)) bn_update_running<true>(pr.xa.bn, c0 + t);
         }
         if (!A_KC) for (int t = cnt + threadIdx.x; t < BM; t += 256) { xsc[0][t] = 0.f; xsh[0][t] = 0.f; }
     }
@@ -251,8 +251,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int vecA, int vecB
         const int cnt = B_KC ? (ke - kb) : min(BN, N - n0);
         const int c0 = B_KC ? kb : n0;
         for (int t = threadIdx.x; t < cnt; t += 256) {
-            bn_scale_shift(pr.xb.bn, c0 + t, xsc[1][t], xsh[1][t]);
-            if (pr.xb.bn.update && bx == 0 && split == 0 && (B_KC ? by == 0 : true)) bn_update_running(pr.xb.bn, c0 + t);
+            bn_scale_shift<true>(pr.xb.bn, c0 + t, xsc[1][t], xsh[1][t]);
+            if (pr.xb.bn.update && bx == 0 && split == 0 && (B_KC ? by == 0 : true)) bn_update_running<true>(pr.xb.bn, c0 + t);
         }
         if (!B_KC) for (int t = cnt + threadIdx.x; t < BN; t += 256) { xsc[1][t] = 0.f; xsh[1][t] = 0.f; }
     }
@@ -324,7 +324,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a, int vecA, int vecB
             aux[r] = pr.aux[(size_t)row * N + col];
             ars[r] = rsp[(size_t)row * rstr];
         }
-        bn_mean_rstd(pr.aux_bn, col, amean, arstd);
+        bn_mean_rstd<true>(pr.aux_bn, col, amean, arstd);
 #pragma unroll
         for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(aux[r]), "+v"(ars[r]));
 #pragma unroll

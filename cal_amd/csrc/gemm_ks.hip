@@ -41,8 +41,8 @@ __global__ void __launch_bounds__(256) k_gemm_ks(const GemmArgs a) {
 
     if (XA > 0) {
         for (int t = threadIdx.x; t < K; t += 256) {
-            bn_scale_shift(pr.xa.bn, t, xsc[t], xsh[t]);
-            if (pr.xa.bn.update && blockIdx.x == 0 && blockIdx.y == 0) bn_update_running(pr.xa.bn, t);
+            bn_scale_shift<true>(pr.xa.bn, t, xsc[t], xsh[t]);
+            if (pr.xa.bn.update && blockIdx.x == 0 && blockIdx.y == 0) bn_update_running<true>(pr.xa.bn, t);
         }
         __syncthreads();
     }
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) k_gemm_ks(const GemmArgs a) {
                     float x = pr.aux[(size_t)grow * N + gcol + j];
                     if (pr.aux_rs) x *= pr.aux_rs[(size_t)grow * pr.aux_rs_stride];
                     float mean, rstd;
-                    bn_mean_rstd(pr.aux_bn, gcol + j, mean, rstd);
+                    bn_mean_rstd<true>(pr.aux_bn, gcol + j, mean, rstd);
                     s2[j] = val * (double)((x - mean) * rstd);
                 }
             }
