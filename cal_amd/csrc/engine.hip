@@ -749,6 +749,11 @@ bool striped_gat(const Ctx& c) {
     const int D = e->H / e->K;
     return (D == 32 || D == 64) && e->max_edges <= GG_E && e->max_edges <= GGB_E;
 }
+//   gin: a GINConv backbone whose layers run per graph both ways (k_ggin_fwd<1|2> / k_ggin_bwd<2|1>): the BatchNorm inside the layer
+bool striped_gin(const Ctx& c) {
+    const Engine* e = c.e;
+    return e->striped && c.training && e->gin && use_gc(c) && gc_small(c) && use_gcb(c) && e->max_edges <= GB_E && e->max_edges <= gc_edge_cap(64);
+}
 //   node: the node-level GCNConv chain of a SMALL batch (graphs beyond the per-graph kernels: configs[0], 230-250 nodes each) -- the
 //       sums that leave a GEMM epilogue (feature-layer statistics, every backward sum) go into the planes; their readers are the
 //       small-batch GEMMs' prologues (gemm.hip / gemm_ks.hip: striped readers), k_bn_bwd<.., ST> and k_att_bwd<.., ST>.  The
@@ -1014,7 +1019,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             GginFwdArgs ga;
             memset(&ga, 0, sizeof(ga));
             ga.x = hin; ga.W = e->P + e->o_conv_w[i - 1]; ga.bias = e->P + e->o_conv_b[i - 1]; ga.out = t1;
-            if (c.training) { ga.st_sum = graph_acc(c, bn_stsum(c, i), H); ga.st_sq = graph_acc(c, bn_stsq(c, i), H); }
+            if (c.training) { ga.st_sum = graph_acc(c, bn_stsum(c, i), H, striped_gin(c)); ga.st_sq = graph_acc(c, bn_stsq(c, i), H, striped_gin(c)); }
             {
                 ProfScope ps(st, 9, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
                 PROF_LAUNCH((k_ggin_fwd<1>), dim3(T, H / GC_N), dim3(512), 0, st, gd, e->gptr, e->eptr, ga, H, H, e->status);
@@ -1637,11 +1642,14 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             ga.slab = e->slabs + slab_off;
             fa.st[fa.nst++] = SlabTask{ga.slab, e->G + e->o_gin_w2[i - 1], H * H, T};
             slab_off += (size_t)T * H * H;
-            double* pp = parts_alloc(c, (size_t)T * nsl * 2 * H);
-            if (!pp) { set_error("engine: partial-row workspace exhausted"); return 2; }
-            ga.dot_parts = pp;
-            final_task(c, pp, T * nsl, 2 * H, H, bn_dsum(c, i));
-            final_task(c, pp + H, T * nsl, 2 * H, H, bn_dprod(c, i));
+            if (striped_gin(c)) { ga.dacc_sum = bn_dsum(c, i); ga.dacc_prod = bn_dprod(c, i); ga.dacc_ss = e->bn_plane; }
+            else {
+                double* pp = parts_alloc(c, (size_t)T * nsl * 2 * H);
+                if (!pp) { set_error("engine: partial-row workspace exhausted"); return 2; }
+                ga.dot_parts = pp;
+                final_task(c, pp, T * nsl, 2 * H, H, bn_dsum(c, i));
+                final_task(c, pp + H, T * nsl, 2 * H, H, bn_dprod(c, i));
+            }
             hipLaunchKernelGGL((k_ggin_bwd<2>), dim3(T, nsl), dim3(GB_NT), 0, st, gd, e->gptr, e->eptr, ga, N, H, H, e->status);
             CAL_CHECK_LAUNCH("k_ggin_bwd<2>"); STAGE();
             RC(flush_finals(c)); STAGE();

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(512, 2) k_ggin_fwd(const CSR g, const int* __r
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
     const bool want = PART == 1 && a.st_sum.on();
     if (rows <= 0) {
-        if (PART == 2 && a.bn.update && blockIdx.x == 0 && blockIdx.y == 0 && t < K) bn_update_running(a.bn, t);
+        if (PART == 2 && a.bn.update && blockIdx.x == 0 && blockIdx.y == 0 && t < K) { const BNRaw r0 = bn_raw_load_st(a.bn, t); bn_raw_update_running(a.bn, r0, t); }
         if (want && t < GC_N) { a.st_sum.add(n0 + t, 0.0); a.st_sq.add(n0 + t, 0.0); }
         return;
     }
@@ -82,13 +82,13 @@ __global__ void __launch_bounds__(512, 2) k_ggin_fwd(const CSR g, const int* __r
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int kh = w >> 2, ct = w & 1, r0 = (w & 3) >> 1;
     float bias = a.bias[n0 + ct * 32 + li];
-    BNRaw braw;
-    if (PART == 2) braw = bn_raw_load(a.bn, min(t, K - 1));
+    BNRawS braws;                                        // (striped reader, engine.hpp: PART 1 of the layer may add into the planes)
+    if (PART == 2) braws = bn_raws_load(a.bn, min(t, K - 1));
 #pragma unroll
     for (int u = 0; u < UA; ++u) ro_pin(va[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) ro_pin(vb[u]);
-    if (PART == 2) bn_raw_pin(braw);
+    if (PART == 2) bn_raws_pin(braws);
     if (PART == 1) {
 #pragma unroll
         for (int u = 0; u < CU; ++u) asm volatile("" : "+v"(nv[u]));
@@ -100,6 +100,7 @@ __global__ void __launch_bounds__(512, 2) k_ggin_fwd(const CSR g, const int* __r
     }
     asm volatile("" : "+v"(bias));
     if (PART == 2 && t < K) {
+        const BNRaw braw = bn_raws_sum(a.bn, braws);
         bn_raw_scale_shift(a.bn, braw, sc_s[t], sh_s[t]);
         if (a.bn.update && blockIdx.x == 0 && blockIdx.y == 0) bn_raw_update_running(a.bn, braw, t);
     }
@@ -238,6 +239,7 @@ struct GginBwdArgs {
     float* dxp0; float* dxp1; // [N,K] partial input gradients of output-column slice 0 / 1
     float* slab;             // [units][H*K] weight-gradient slabs, Linear layout [out][in]
     double* dot_parts;       // PART 2: [units * H/64][2K] partial rows of (s1, s2)
+    double* dacc_sum; double* dacc_prod; int dacc_ss;    // ... or (non-null) into the workgroup's accumulator plane (engine.hpp: stripe_sum)
     const float* t1;         // PART 1: [N,H] pre-BatchNorm activations
     const double* dot_sum; const double* dot_prod;   // PART 1: finalised s1, s2 [H]
 };
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(GB_NT) k_ggin_bwd(const CSR g, const int* __re
     const bool given = PART == 2 && a.dout != nullptr;
     if (rows <= 0 || rows > GB_T || ne > GB_E || ne < 0) {
         if (rows > 0 && t == 0) atomicOr(status, 8);
-        if (PART == 2) for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
+        if (PART == 2 && !a.dacc_sum) for (int i = t; i < 2 * K; i += GB_NT) parts[i] = 0.0;
         if (a.bias_parts && t < GC_N) a.bias_parts[(size_t)b * H + ns0 + t] = 0.0;
         for (int i = t; i < K * GC_N; i += GB_NT) slab[(size_t)(ns0 + i / K) * K + i % K] = 0.f;
         return;
@@ -334,23 +336,27 @@ __global__ void __launch_bounds__(GB_NT) k_ggin_bwd(const CSR g, const int* __re
 #pragma unroll
         for (int u = 0; u < 2; ++u) nv[u] = g.nbr[min(e0 + max(min(t + u * GB_NT, ne - 1), 0), slot_hi)];
     }
-    BNRaw braw = bn_raw_load(a.bn, PART == 2 ? min(t, K - 1) : ns0 + (t & (GC_N - 1)));
-    double ud1 = 0.0, ud2 = 0.0;
-    if (PART == 1) { ud1 = a.dot_sum[ns0 + (t & (GC_N - 1))]; ud2 = a.dot_prod[ns0 + (t & (GC_N - 1))]; }
-    bn_raw_pin(braw);
+    BNRawS braws = bn_raws_load(a.bn, PART == 2 ? min(t, K - 1) : ns0 + (t & (GC_N - 1)));      // (striped readers, engine.hpp)
+    StripeVal ud1s, ud2s;
+    if (PART == 1) { ud1s = stripe_load(a.dot_sum, ns0 + (t & (GC_N - 1)), a.bn.ss); ud2s = stripe_load(a.dot_prod, ns0 + (t & (GC_N - 1)), a.bn.ss); }
+    bn_raws_pin(braws);
     if (PART == 1) {
-        asm volatile("" : "+v"(ud1), "+v"(ud2), "+v"(pv), "+v"(pn), "+v"(nv[0]), "+v"(nv[1]));
+        stripe_pin(ud1s); stripe_pin(ud2s);
+        asm volatile("" : "+v"(pv), "+v"(pn), "+v"(nv[0]), "+v"(nv[1]));
         if (ne <= 0) { nv[0] = g0; nv[1] = g0; }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) ro_pin(vw[u]);
     if (PART == 2 && t < K) {
         float m1, r1;
+        const BNRaw braw = bn_raws_sum(a.bn, braws);
         bn_raw_mean_rstd(a.bn, braw, m1, r1);
         mean_s[t] = m1; rstd_s[t] = r1; gam_s[t] = braw.g; bet_s[t] = braw.b;
     }
     if (PART == 1 && t < GC_N) {
         float m1, r1;
+        const BNRaw braw = bn_raws_sum(a.bn, braws);
+        const double ud1 = stripe_total(ud1s, a.bn.ss), ud2 = stripe_total(ud2s, a.bn.ss);
         bn_raw_mean_rstd(a.bn, braw, m1, r1);
         um_s[t] = m1; ur_s[t] = r1; ug_s[t] = braw.g * r1;
         u1_s[t] = (float)(ud1 * (double)a.bn.inv_n);
@@ -489,7 +495,12 @@ __global__ void __launch_bounds__(GB_NT) k_ggin_bwd(const CSR g, const int* __re
             double s2 = ((double)f2[0] + (double)f2[1]) + ((double)f2[2] + (double)f2[3]);
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
-            if (lk == 0) { parts[k] = s1; parts[K + k] = s2; }
+            if (lk == 0) {
+                if (a.dacc_sum) {
+                    const size_t po = (size_t)stripe_of_block() * a.dacc_ss + k;
+                    atomicAdd(a.dacc_sum + po, s1); atomicAdd(a.dacc_prod + po, s2);
+                } else { parts[k] = s1; parts[K + k] = s2; }
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
