@@ -28,14 +28,15 @@ struct BNRef {
 
 // Striped fp64 accumulators (round 5).  A BatchNorm's column sums were one partial row per producer workgroup plus a finishing
 // launch (k_stats_final: 8 x 4.7 us of the 233 us headline step).  Where producers AND consumers are the per-graph kernels
-// (128-512 workgroups ending together) the producers now add their sums atomically into ONE OF NSTRIPE ROWS (row = workgroup %
+// (128-512 workgroups ending together), or the GEMM epilogues / row kernels of a small node-level batch, the producers now add
+// their sums atomically into ONE OF NSTRIPE ROWS (row = workgroup %
 // NSTRIPE; the rows -- "planes" of the whole BatchNorm-sum region -- are `ss` doubles apart in the arena and zeroed with it), and
 // the consumers add the NSTRIPE rows in one fixed order: a chain of 32-128 same-address atomics per column instead of 256-512
 // (scripts/micro/atomics64.hip, profiles/r5/micro_atomics64.txt: +1.5 / +2.1 us per producer / consumer pair at eight / four
 // rows against +5.0 us for partial rows + finishing kernel and +6.1 us for one row).  Producers that finish into a single row
 // (k_stats_final, plain atomics, plain stores) write plane 0 and leave the others zero, so a STRIPED reader (the *_st helpers
 // below) is right for either kind; the plain readers are right only for single-row sites -- the engine stripes a site only
-// when every kernel that reads it is a striped reader (engine.hip: Ctx::striped).  ss == 0 (no planes): the same value read
+// when every kernel that reads it is a striped reader (engine.hip: striped_co / striped_bb / striped_gat / striped_gin / striped_feat / striped_node).  ss == 0 (no planes): the same value read
 // NSTRIPE times and scaled back, exactly -- no branch in a kernel prologue (see bn_raw_load).
 constexpr int NSTRIPE = 4;
 __device__ __forceinline__ double stripe_sum(const double* __restrict__ p, int c, int ss) {
