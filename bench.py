@@ -36,6 +36,8 @@ WORKLOADS = {
     "spmotif_b0.9_causalgcn_h128_l3_bs128": dict(model="CausalGCN", data="spmotif", node_num=7, hidden=128, layers=3, batch=128, nfeat=10, ncls=4),
     # the reference's DEFAULT SPMotif shape (opts.py:18 node_num = 15, ~235-node graphs) at BASELINE.json configs[0]'s batch of 32
     "spmotif_b0.9_causalgcn_nodenum15_bs32": dict(model="CausalGCN", data="spmotif", node_num=15, hidden=128, layers=3, batch=32, nfeat=10, ncls=4),
+    # ... and the reference's defaults TOGETHER (opts.py:18,29: node_num 15 and batch_size 128, ~30 k node rows): what main_syn.py runs
+    "spmotif_b0.9_causalgcn_nodenum15_bs128": dict(model="CausalGCN", data="spmotif", node_num=15, hidden=128, layers=3, batch=128, nfeat=10, ncls=4),
     "spmotif_b0.9_causalgat_h128_l3_bs128": dict(model="CausalGAT", data="spmotif", node_num=7, hidden=128, layers=3, batch=128, nfeat=10, ncls=4),
     "spmotif_b0.9_causalgin_h128_l3_bs128": dict(model="CausalGIN", data="spmotif", node_num=7, hidden=128, layers=3, batch=128, nfeat=10, ncls=4),
     "mutaglike_causalgat_h128_l3_bs64": dict(model="CausalGAT", data="mutag", node_num=18, hidden=128, layers=3, batch=64, nfeat=109, ncls=2),

@@ -34,6 +34,7 @@
 #include "engine_gin.hpp"
 #include "engine_ggin.hpp"
 #include "engine_feat.hpp"
+#include "engine_gwide.hpp"
 
 namespace cal {
 
@@ -194,6 +195,7 @@ struct Engine {
     int ro_rows;             // 1: ... also for 129 .. 512 graphs, in row blocks (k_ro_step<true>); CAL_AMD_RO_ROWS=0: the GEMM chain there
     int striped;             // 1: the per-graph kernels exchange their BatchNorm sums through NSTRIPE accumulator planes (engine.hpp: stripe_sum)
                              // instead of partial rows + k_stats_final; CAL_AMD_STRIPED=0 keeps the finishing launches
+    int gwide;               // 1: graphs of 129 .. 256 nodes run the wide per-graph convolutions (engine_gwide.hpp); CAL_AMD_GWIDE=0: the node-level chain
     int ro_step;             // 1: training steps run the readout as one launch (k_ro_step); CAL_AMD_RO_STEP=0 keeps the four kernels
     float *dzl, *dyh1, *dy1, *dxh, *dpool, *dZco, *gn, *gself, *ddeg, *dl, *dzco, *dXhco, *dZ, *dzi, *dXh, *slabs;
     size_t slab_floats;
@@ -258,6 +260,7 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     { const char* v = getenv("CAL_AMD_RO_STEP"); e->ro_step = !(v && v[0] == '0'); }
     { const char* v = getenv("CAL_AMD_RO_ROWS"); e->ro_rows = !(v && v[0] == '0'); }
     { const char* v = getenv("CAL_AMD_STRIPED"); e->striped = !(v && v[0] == '0'); }
+    { const char* v = getenv("CAL_AMD_GWIDE"); e->gwide = !(v && v[0] == '0'); }
     {
         // k_ro_step's 3 * H / 16 workgroups (133 KB of LDS each: one per CU) meet at spin barriers: they must all be
         // resident.  A device (or CU mask / partition) with fewer compute units than that takes the four-kernel readout.
@@ -728,6 +731,12 @@ bool use_gc(const Ctx& c) {
     return e->max_nodes > 0 && e->max_nodes <= GC_T && e->max_edges <= GC_E && e->H % GC_N == 0 && e->H <= GC_K && c.B > 0;
 }
 bool gc_small(const Ctx& c) { return c.e->max_nodes <= 64 && c.e->max_edges <= gc_edge_cap(64); }
+// wide per-graph convolutions, both ways (engine_gwide.hpp): graphs of 129 .. 256 nodes (the reference's default SPMotif shape)
+bool use_gw(const Ctx& c) {
+    const Engine* e = c.e;
+    return e->gwide && e->max_nodes > GC_T && e->max_nodes <= GW_T && e->max_edges <= GW_E && e->H % GC_N == 0 && e->H <= GW_K && c.B > 0 &&
+           e->ntiles == 0 && e->K == 0 && !e->gin;
+}
 // per-graph fused backward (engine_gconv_bwd.hpp): 64-node graphs only
 bool use_gcb(const Ctx& c) { return use_gc(c) && gc_small(c) && c.T <= 128 * 4; }
 // Which BatchNorm sites of a step go through the accumulator planes (engine.hpp: stripe_sum): those whose producers are per-graph
@@ -776,7 +785,7 @@ Acc graph_acc(Ctx& c, double* dst, int cols, bool st = false) {
 // Launch the per-graph fused backward for nb branches: slabs (one per graph) and the BatchNorm-backward partial
 // rows are registered like those of the GEMM path.  gb[k].dot_parts / .slab are filled in here.
 int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, double** dsum, double** dprod,
-              FinishArgs& fa, size_t& slab_off, bool rs, bool st) {
+              FinishArgs& fa, size_t& slab_off, bool rs, bool st, const CSR* gs_wide = nullptr) {
     Engine* e = c.e;
     const int H = e->H, B = c.T, nsl = H / GC_N;         // (B: units of this launch -- tiles or graphs)
     for (int k = 0; k < nb; ++k) {
@@ -795,6 +804,18 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
         gb[k].dot_parts = p;
         final_task(c, p, B * nsl, 2 * H, H, dsum[k]);
         final_task(c, p + H, B * nsl, 2 * H, H, dprod[k]);
+    }
+    if (gs_wide) {
+        // graphs of up to 256 nodes (engine_gwide.hpp): CSR by SOURCE; the dX' and dW products of a (graph, slice) go to two
+        // workgroups when one each would leave half of the CUs without one
+        const int nsplit = (int64_t)B * nsl * nb * 2 <= e->num_cus ? 2 : 1;
+        const dim3 gridw(B, nsl * nsplit, nb);
+        const GconvBwdBranch2 b2{{gb[0], gb[nb - 1]}};
+        if (rs) PROF_LAUNCH((k_gw_bwd<true, 2>), gridw, dim3(GW_NT), 0, c.st, *gs_wide, e->gptr, e->eptr, b2, e->loop_w, c.N, H, H, nsplit, e->status);
+        else if (gb[0].dout) PROF_LAUNCH((k_gw_bwd<false, 0>), gridw, dim3(GW_NT), 0, c.st, *gs_wide, e->gptr, e->eptr, b2, e->loop_w, c.N, H, H, nsplit, e->status);
+        else PROF_LAUNCH((k_gw_bwd<false, 1>), gridw, dim3(GW_NT), 0, c.st, *gs_wide, e->gptr, e->eptr, b2, e->loop_w, c.N, H, H, nsplit, e->status);
+        CAL_CHECK_LAUNCH("k_gw_bwd");
+        return 0;
     }
     const dim3 grid(B, nsl, nb);
     // the two-branch launch: 2 x B x H/64 workgroups -- at 128 graphs twice the CUs; the 80 KB instantiation runs them as ONE round
@@ -1008,6 +1029,10 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     }
     // 4. backbone: h_i = relu(A_hat (BN_i(h_{i-1}) @ W_i) + b_i)   (model.py:93-95)
     const bool gc = use_gc(c);
+    const bool gw = use_gw(c);
+    const bool gw_st = gw && striped_node(c);            // the wide kernels' BatchNorm sums go through the accumulator planes (every reader is a striped reader)
+    // 32-column slices (two workgroups per CU) when 64-column slices would leave half of the CUs without a workgroup
+    auto gw_narrow = [&](int nb) { return (int64_t)T * (H / GC_N) * nb * 2 <= e->num_cus; };
     const bool gat = e->K > 0;
     for (int i = 1; i <= L; ++i) {
         // A training forward must leave what the backward of the SAME shape reads: the fused layer writes gt1 only, the
@@ -1110,6 +1135,22 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             }
             continue;
         }
+        if (gw) {        // GCNConv per graph of up to 256 nodes: MFMA product + sparse aggregation from LDS + statistics (engine_gwide.hpp)
+            GconvBranch gb;
+            memset(&gb, 0, sizeof(gb));
+            gb.x = e->h + (size_t)(i - 1) * NH; gb.W = e->P + e->o_conv_w[i - 1]; gb.bias = e->P + e->o_conv_b[i - 1];
+            gb.dis = e->dis_unit; gb.bn = bnref(c, i, N, 1); gb.out = e->h + (size_t)i * NH;
+            if (i == 1) gb.coef_out = e->coef; else gb.coef_in = e->coef;
+            if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H, gw_st); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H, gw_st); }
+            {
+                ProfScope ps(st, 2, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
+                if (gw_narrow(1)) PROF_LAUNCH((k_gw_fwd<false, 32>), dim3(T, H / 32, 1), dim3(GW_NT), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1, e->loop_w, H, H, e->status);
+                else PROF_LAUNCH((k_gw_fwd<false, 64>), dim3(T, H / GC_N, 1), dim3(GW_NT), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb, gb}}, 1, e->loop_w, H, H, e->status);
+            }
+            CAL_CHECK_LAUNCH("k_gw_fwd"); STAGE();
+            RC(flush_finals(c)); STAGE();
+            continue;
+        }
         if (gc) {        // GCNConv: GEMM + aggregation + statistics in one per-graph kernel
             GconvBranch gb;
             memset(&gb, 0, sizeof(gb));
@@ -1200,8 +1241,21 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
                                 e->loop_w, H, H, e->status);
         CAL_CHECK_LAUNCH("k_gconv_fwd(co)"); STAGE();
     }
+    if (gw) {        // 7-9 for graphs of up to 256 nodes (engine_gwide.hpp)
+        GconvBranch gb[2];
+        memset(gb, 0, sizeof(gb));
+        for (int k = 0; k < 2; ++k) {
+            gb[k].x = x; gb[k].W = e->P + (k ? e->o_ow : e->o_cw); gb[k].bias = e->P + (k ? e->o_ob : e->o_cb);
+            gb[k].ew = e->att + (size_t)k * E; gb[k].dis = e->dis_co + (size_t)k * N;
+            gb[k].rs = e->anode + k; gb[k].rs_stride = 2; gb[k].bn = bnref(c, L + 1 + k, N, 1);
+            gb[k].out = e->hco + (size_t)k * NH; gb[k].z = e->zco + (size_t)k * NH; gb[k].pooled = e->pooled + (size_t)k * B * H;
+        }
+        if (gw_narrow(2)) hipLaunchKernelGGL((k_gw_fwd<true, 32>), dim3(T, H / 32, 2), dim3(GW_NT), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1, e->loop_w, H, H, e->status);
+        else hipLaunchKernelGGL((k_gw_fwd<true, 64>), dim3(T, H / GC_N, 2), dim3(GW_NT), 0, st, gd, e->gptr, e->eptr, GconvBranch2{{gb[0], gb[1]}}, 1, e->loop_w, H, H, e->status);
+        CAL_CHECK_LAUNCH("k_gw_fwd(co)"); STAGE();
+    }
     // 7. z_k = BN_k(a_k * x) @ W_k for k in (context, objects)   (model.py:112-113)
-    if (!gc) {
+    if (!gc && !gw) {
         GemmArgs a = gemm_args(N, H, H, false, false, 0);
         for (int k = 0; k < 2; ++k) {
             a.p[k].A = x; a.p[k].B = e->P + (k ? e->o_ow : e->o_cw); a.p[k].C = e->zco + (size_t)k * NH;
@@ -1211,14 +1265,14 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
         RC(fwd_gemm(c, false, a, 2)); STAGE();
     }
     // 8. h_k = relu(A_hat_k z_k + b_k)
-    if (!gc) {
+    if (!gc && !gw) {
         SpmmBranch b0{e->zco, e->hco, e->P + e->o_cb, e->att, e->dis_co, Acc(), Acc(), nullptr, nullptr, nullptr};
         SpmmBranch b1{e->zco + NH, e->hco + NH, e->P + e->o_ob, e->att + E, e->dis_co + N, Acc(), Acc(), nullptr, nullptr, nullptr};
         RC(launch_espmm(st, gd, SpmmBranch2{{b0, b1}}, 2, 1, e->loop_w, N, H, spmm_rpb(H, false)));
         CAL_CHECK_LAUNCH("k_espmm(co)"); STAGE();
     }
     // 9. add-pool (model.py:115-116)
-    if (!gc) {
+    if (!gc && !gw) {
         RC(launch_pool2(c));
         STAGE();
     }
@@ -1440,8 +1494,10 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         hipLaunchKernelGGL(k_readout_bwd_tail, dim3(cdiv((int64_t)BH, 256)), dim3(256), 0, st, in[0], in[1], in[2], e->iperm, e->dpool, B, H, e->cat);
         CAL_CHECK_LAUNCH("k_readout_bwd_tail"); STAGE();
     }
-    const bool gcb = use_gcb(c);
-    const bool agb = gcb && T <= 256;           // per-graph attention backward (two workgroups per graph: one wave of the chip)
+    const bool gwb = use_gw(c);                 // wide per-graph backward (engine_gwide.hpp); its BatchNorm sums through the planes when the
+    const bool gw_st = gwb && striped_node(c);  // node-level readers of this batch (k_att_bwd, k_bn_bwd) are the striped instantiations
+    const bool gcb = use_gcb(c) || gwb;
+    const bool agb = gcb && !gwb && T <= 256;           // per-graph attention backward (two workgroups per graph: one wave of the chip)
     // P1. add-pool backward + ReLU of the causal/trivial convs: d(conv output)[v] = relu'(h_k[v]) * (gradient of the pooled row of v's
     // graph) is never stored -- the transposed aggregation below (P5) builds it per gathered row from the activation, and the bias
     // gradients are count x pooled-row gradient per graph (k_pool2 counted the positive rows).  Rounds 1-3 wrote and re-read the
@@ -1509,7 +1565,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             gb[k].gn_slot = agb ? 1 : 0;        // consumed by k_att_bwd_graph in slot order (else by k_normbwd_* in edge-id order)
             dst[k] = e->G + (k ? e->o_ow : e->o_cw); dsum[k] = bn_dsum(c, L + 1 + k); dprod[k] = bn_dprod(c, L + 1 + k);
         }
-        RC(gconv_bwd(c, gd, gb, 2, dst, dsum, dprod, fa, slab_off, true, striped_co(c))); STAGE();
+        RC(gconv_bwd(c, gd, gb, 2, dst, dsum, dprod, fa, slab_off, true, gwb ? gw_st : striped_co(c), gwb ? &gs : nullptr)); STAGE();
         RC(flush_finals(c)); STAGE();
         // the edge-weight gradients through the normalisation are part of the per-graph attention backward below; big
         // batches (a per-graph launch would be several waves of one-per-CU workgroups) keep the node- / edge-parallel kernels
@@ -1836,16 +1892,17 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             }
             float* dst[1] = {e->G + e->o_conv_w[i - 1]};
             double* dsum[1] = {bn_dsum(c, i)}; double* dprod[1] = {bn_dprod(c, i)};
-            { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false, striped_bb(c) && (i > 1 || (F <= FM_F && H <= FB_H)))); } STAGE();
+            { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false, gwb ? gw_st : striped_bb(c) && (i > 1 || (F <= FM_F && H <= FB_H)), gwb ? &gs : nullptr)); } STAGE();
             RC(flush_finals(c)); STAGE();
-            if (i == 1 && F <= FM_F && H <= FB_H) {
+            if (i == 1 && !gwb && F <= FM_F && H <= FB_H) {
                 // the feature layer's backward per graph, fed from this layer's partial dX' (no k_bn_bwd, no dZ round trip)
                 RC(feat_bwd(p0, H > GC_N ? dzi : nullptr, false)); STAGE();
             } else if (i == 1) {       // the feature layer below is a plain GEMM: materialise dZ for it
                 BnBwdProb p{p0, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i), Acc(), H > GC_N ? dzi : nullptr};
                 RC(with_g(H, [&](auto g) {
                     constexpr int G = decltype(g)::value;
-                    hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, BnBwdProb3{{p, p, p}}, 1, N, H, c.rpb_n);
+                    if (gw_st) hipLaunchKernelGGL((k_bn_bwd<4, G, true>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, BnBwdProb3{{p, p, p}}, 1, N, H, c.rpb_n);
+                    else hipLaunchKernelGGL((k_bn_bwd<4, G>), dim3(cdiv(N, c.rpb_n), 1), dim3(256), 0, st, BnBwdProb3{{p, p, p}}, 1, N, H, c.rpb_n);
                     return 0;
                 }));
                 CAL_CHECK_LAUNCH("k_bn_bwd"); STAGE();
