@@ -205,6 +205,7 @@ struct Engine {
     hipStream_t side; hipEvent_t ev_fork[24], ev_join[24];
     int *rowptr_dst, *nbr_dst, *eid_dst, *rowptr_src, *nbr_src, *eid_src, *row32, *col32, *work, *status, *gptr, *iperm, *eptr;
     float* wslot;               // [2][E] attention edge weights (context, objects) in CSR-by-destination slot order
+    float* coef_src;            // [E] unit-weight coefficients deg^-1/2 of the destination in CSR-by-SOURCE slot order (k_plan_graph, for the wide per-graph backward)
     float* coef;                // [3][E] edge coefficients dis_j * w_e in CSR-by-destination slot order: unit, context, objects
     int max_nodes, max_edges;   // per-graph bounds of the coming batches (0 = unknown): cal_engine_set_graph_bounds
     const int64_t *node_ptr, *edge_ptr;   // [B+1] device arrays of the coming batch (null = unknown): cal_engine_set_graph_ptrs
@@ -407,6 +408,7 @@ static size_t engine_layout(Engine* e, int64_t N, int64_t E, int64_t B, bool ass
     { int* tmp = nullptr; I32(tmp, 2 * B + 2); if (assign) e->perm_dev = (int64_t*)tmp; }
     I32(e->eptr, B + 1);
     F32(e->coef, 3 * E);
+    F32(e->coef_src, E);
     F32(e->wslot, 2 * E);
     if (e->gin) {
         const size_t Lg = L > 0 ? L : 1;
@@ -788,6 +790,9 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
               FinishArgs& fa, size_t& slab_off, bool rs, bool st, const CSR* gs_wide = nullptr) {
     Engine* e = c.e;
     const int H = e->H, B = c.T, nsl = H / GC_N;         // (B: units of this launch -- tiles or graphs)
+    // wide kernels: the dX' and dW products of a (graph, slice) go to two or four workgroups when one each would leave CUs without one
+    const int nsplit = !gs_wide ? 1 : (int64_t)B * nsl * nb * 4 <= e->num_cus ? 4 : (int64_t)B * nsl * nb * 2 <= e->num_cus ? 2 : 1;
+    const int np2 = nsplit == 4 ? 2 : 1;                 // workgroups per (graph, slice) that leave BatchNorm-backward partial rows
     for (int k = 0; k < nb; ++k) {
         gb[k].batch = c.batch; gb[k].tile_gptr = e->ntiles > 0 ? e->tile_gptr : nullptr;
         const size_t need = (size_t)B * H * H;
@@ -799,16 +804,14 @@ int gconv_bwd(Ctx& c, const CSR& gd, GconvBwdBranch* gb, int nb, float** dst, do
             gb[k].dacc_sum = dsum[k]; gb[k].dacc_prod = dprod[k]; gb[k].dacc_ss = e->bn_plane;
             continue;
         }
-        double* p = parts_alloc(c, (size_t)B * nsl * 2 * H);
+        double* p = parts_alloc(c, (size_t)B * nsl * np2 * 2 * H);
         if (!p) { set_error("engine: partial-row workspace exhausted"); return 2; }
         gb[k].dot_parts = p;
-        final_task(c, p, B * nsl, 2 * H, H, dsum[k]);
-        final_task(c, p + H, B * nsl, 2 * H, H, dprod[k]);
+        final_task(c, p, B * nsl * np2, 2 * H, H, dsum[k]);
+        final_task(c, p + H, B * nsl * np2, 2 * H, H, dprod[k]);
     }
     if (gs_wide) {
-        // graphs of up to 256 nodes (engine_gwide.hpp): CSR by SOURCE; the dX' and dW products of a (graph, slice) go to two
-        // workgroups when one each would leave half of the CUs without one
-        const int nsplit = (int64_t)B * nsl * nb * 2 <= e->num_cus ? 2 : 1;
+        // graphs of up to 256 nodes (engine_gwide.hpp): CSR by SOURCE
         const dim3 gridw(B, nsl * nsplit, nb);
         const GconvBwdBranch2 b2{{gb[0], gb[nb - 1]}};
         if (rs) PROF_LAUNCH((k_gw_bwd<true, 2>), gridw, dim3(GW_NT), 0, c.st, *gs_wide, e->gptr, e->eptr, b2, e->loop_w, c.N, H, H, nsplit, e->status);
@@ -973,10 +976,11 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     }
     // 1. GraphPlan
     if (fast_plan) {
-        auto kern = wide_plan ? k_plan_graph<GP_T2, GP_E2> : k_plan_graph<GP_T, GP_E>;
-        hipLaunchKernelGGL(kern, dim3(T), dim3(256), 0, st, edge_index, E, N, T, e->node_ptr, e->edge_ptr, batch, tgp, B, e->loop_w,
+        auto kern = wide_plan ? k_plan_graph<GP_T2, GP_E2, 1024> : k_plan_graph<GP_T, GP_E, 256>;
+        hipLaunchKernelGGL(kern, dim3(T), dim3(wide_plan ? 1024 : 256), 0, st, edge_index, E, N, T, e->node_ptr, e->edge_ptr, batch, tgp, B, e->loop_w,
                            e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src, e->row32, e->col32,
-                           e->gptr, e->eptr, e->dis_unit, e->status, plan_stats ? x0 : nullptr, F, bn_stsum(c, 0), bn_stsq(c, 0));
+                           e->gptr, e->eptr, e->dis_unit, e->status, plan_stats ? x0 : nullptr, F, bn_stsum(c, 0), bn_stsq(c, 0),
+                           use_gw(c) ? e->coef : nullptr, use_gw(c) ? e->coef_src : nullptr);
         CAL_CHECK_LAUNCH("k_plan_graph"); STAGE();
     } else if (big_plan) {
         int* scratch = e->work + 4 * ((size_t)e->capN + 1);
@@ -1030,7 +1034,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     // 4. backbone: h_i = relu(A_hat (BN_i(h_{i-1}) @ W_i) + b_i)   (model.py:93-95)
     const bool gc = use_gc(c);
     const bool gw = use_gw(c);
-    const bool gw_st = gw && striped_node(c);            // the wide kernels' BatchNorm sums go through the accumulator planes (every reader is a striped reader)
+    const bool gw_st = gw && e->striped && c.training;   // the wide kernels' BatchNorm sums go through the accumulator planes (every reader is a striped reader)
     // 32-column slices (two workgroups per CU) when 64-column slices would leave half of the CUs without a workgroup
     auto gw_narrow = [&](int nb) { return (int64_t)T * (H / GC_N) * nb * 2 <= e->num_cus; };
     const bool gat = e->K > 0;
@@ -1140,7 +1144,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
             memset(&gb, 0, sizeof(gb));
             gb.x = e->h + (size_t)(i - 1) * NH; gb.W = e->P + e->o_conv_w[i - 1]; gb.bias = e->P + e->o_conv_b[i - 1];
             gb.dis = e->dis_unit; gb.bn = bnref(c, i, N, 1); gb.out = e->h + (size_t)i * NH;
-            if (i == 1) gb.coef_out = e->coef; else gb.coef_in = e->coef;
+            if (i == 1 && !fast_plan) gb.coef_out = e->coef; else gb.coef_in = e->coef;      // (k_plan_graph writes the unit coefficients in slot order)
             if (c.training && i < L) { gb.st_sum = graph_acc(c, bn_stsum(c, i + 1), H, gw_st); gb.st_sq = graph_acc(c, bn_stsq(c, i + 1), H, gw_st); }
             {
                 ProfScope ps(st, 2, 2.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true);
@@ -1495,7 +1499,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         CAL_CHECK_LAUNCH("k_readout_bwd_tail"); STAGE();
     }
     const bool gwb = use_gw(c);                 // wide per-graph backward (engine_gwide.hpp); its BatchNorm sums through the planes when the
-    const bool gw_st = gwb && striped_node(c);  // node-level readers of this batch (k_att_bwd, k_bn_bwd) are the striped instantiations
+    const bool gw_st = gwb && e->striped && c.training;  // node-level readers of this batch (k_att_bwd, k_bn_bwd) are then the striped instantiations
     const bool gcb = use_gcb(c) || gwb;
     const bool agb = gcb && !gwb && T <= 256;           // per-graph attention backward (two workgroups per graph: one wave of the chip)
     // P1. add-pool backward + ReLU of the causal/trivial convs: d(conv output)[v] = relu'(h_k[v]) * (gradient of the pooled row of v's
@@ -1561,7 +1565,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             gb[k].ew = e->att + (size_t)k * E; gb[k].dis = e->dis_co + (size_t)k * N;
             gb[k].rs = e->anode + k; gb[k].rs_stride = 2; gb[k].bn = bnref(c, L + 1 + k, N, 0);
             gb[k].dxp0 = e->dXhco + (size_t)k * NH; gb[k].dxp1 = e->dzco + (size_t)k * NH;
-            gb[k].coef_in = e->coef + (size_t)(1 + k) * E;
+            gb[k].coef_in = gwb ? nullptr : e->coef + (size_t)(1 + k) * E;      // (the wide kernels walk the CSR by source: other slot order)
             gb[k].gn_slot = agb ? 1 : 0;        // consumed by k_att_bwd_graph in slot order (else by k_normbwd_* in edge-id order)
             dst[k] = e->G + (k ? e->o_ow : e->o_cw); dsum[k] = bn_dsum(c, L + 1 + k); dprod[k] = bn_dprod(c, L + 1 + k);
         }
@@ -1628,7 +1632,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         if (!aa.dWn.on() || !aa.dWe.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
         RC(with_g(H, [&](auto g) {
             constexpr int G = decltype(g)::value;
-            if (striped_node(c)) hipLaunchKernelGGL((k_att_bwd<4, G, true>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, aa, 1, N, H, c.rpb_n);
+            if (striped_node(c) || gw_st) hipLaunchKernelGGL((k_att_bwd<4, G, true>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, aa, 1, N, H, c.rpb_n);
             else hipLaunchKernelGGL((k_att_bwd<4, G>), dim3(cdiv(N, c.rpb_n)), dim3(256), 0, st, aa, 1, N, H, c.rpb_n);
             return 0;
         }));
@@ -1879,6 +1883,10 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             gb.x = hin; gb.W = e->P + e->o_conv_w[i - 1]; gb.dis = e->dis_unit; gb.bn = bnref(c, i, N, 0);
             gb.dxp0 = p0; gb.dxp1 = dzi;
             gb.coef_in = e->coef;               // written by the forward's first fused layer
+            if (gwb) {                          // CSR by source: the unit coefficients k_plan_graph left in that slot order, if it ran
+                const bool fastp = e->node_ptr && e->edge_ptr && e->max_nodes > 0 && e->max_nodes <= GP_T2 && e->max_edges <= GP_E2;
+                gb.coef_in = fastp ? e->coef_src : nullptr;
+            }
             if (i == L) gb.dout = e->dZ;
             else {
                 gb.dy0 = ((L - i - 1) & 1) ? e->z : e->dXh;

@@ -343,43 +343,46 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_fwd(const CSR g, const int* __r
 // ----------------------------------------------------------------------------------------------------------------------
 constexpr int GW_LDD = GC_N + 4;
 
-// P3 inner product for NCT column tiles: acc[c] += sum_i x'[i][k] dz[i][c * 32 + li], i < rowsP (steps of two rows: lk)
-template <int NCT>
+// P3 inner product for NCT column tiles: acc[c] += sum_i x'[i][k] dz[i][c * 32 + li], i < rowsP (steps of two rows: lk).  Batches of
+// 16 steps; the operands of batch b + 1 -- x from global memory, dz (and the row scales) from LDS -- are requested before the
+// MFMAs of batch b.
+template <int NCT, bool RS>
 __device__ __forceinline__ void gw_p3(const float* __restrict__ xk, int K, const float* rs_s, const float* dzp, int rowsP, int rows, int lk,
-                                      float sc, float sh, gc_f32x16 (&acc)[2]) {
-    float xg[2][16];
-    auto ld = [&](int sb, float (&dst)[16]) {
+                                      float sc, float sh, gc_f32x16 (&acc)[2], int sb0, int sb1) {
+    constexpr int BS = 16;
+    float xg[2][BS], bz[2][BS][NCT], rsv[2][RS ? BS : 1];
+    auto ld = [&](int sb, float (&x)[BS], float (&bzz)[BS][NCT], float (&r)[RS ? BS : 1]) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) dst[u] = xk[(size_t)min(2 * (sb * 16 + u) + lk, rows - 1) * K];
-    };
-    auto mul = [&](int sb, float (&src)[16]) {
-        float a[16], bz[16][NCT];
+        for (int u = 0; u < BS; ++u) x[u] = xk[(size_t)min(2 * (sb * BS + u) + lk, rows - 1) * K];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int i = 2 * (sb * 16 + u) + lk;
-            a[u] = rs_s[i];
+        for (int u = 0; u < BS; ++u) {
+            const int i = 2 * (sb * BS + u) + lk;
+            if (RS) r[u] = rs_s[i];
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) bz[u][c] = dzp[i * GW_LDD + 32 * c];
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const float av = fmaf(src[u] * a[u], sc, sh);
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz[u][c], acc[c], 0, 0, 0);
+            for (int c = 0; c < NCT; ++c) bzz[u][c] = dzp[i * GW_LDD + 32 * c];
         }
     };
-    const int nsb = rowsP >> 5;
-    ld(0, xg[0]);
-    for (int sb = 0; sb < nsb; sb += 2) {
-        if (sb + 1 < nsb) ld(sb + 1, xg[1]);
+    auto mul = [&](float (&x)[BS], float (&bzz)[BS][NCT], float (&r)[RS ? BS : 1]) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(xg[0][u]));
-        mul(sb, xg[0]);
+        for (int u = 0; u < BS; ++u) {
+            const float av = RS ? fmaf(x[u] * r[u], sc, sh) : fmaf(x[u], sc, sh);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bzz[u][c], acc[c], 0, 0, 0);
+        }
+    };
+    const int nsb = sb1;                                 // batches [sb0, sb1) of the graph's rowsP / 32
+    if (sb0 >= sb1) return;
+    ld(sb0, xg[0], bz[0], rsv[0]);
+    for (int sb = sb0; sb < nsb; sb += 2) {
+        if (sb + 1 < nsb) ld(sb + 1, xg[1], bz[1], rsv[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mul(xg[0], bz[0], rsv[0]);
+        __builtin_amdgcn_sched_barrier(0);
         if (sb + 1 < nsb) {
-            if (sb + 2 < nsb) ld(sb + 2, xg[0]);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) asm volatile("" : "+v"(xg[1][u]));
-            mul(sb + 1, xg[1]);
+            if (sb + 2 < nsb) ld(sb + 2, xg[0], bz[0], rsv[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(xg[1], bz[1], rsv[1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -406,12 +409,15 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_bwd(const CSR g, const int* __r
     warm_kernargs<sizeof(CSR) + 2 * sizeof(void*) + sizeof(GconvBwdBranch2) + 32>();
     const GconvBwdBranch& br = bb.b[blockIdx.z];
     const int b = blockIdx.x, sl = blockIdx.y / nsplit, part = blockIdx.y - sl * nsplit, ns0 = sl * GC_N, t = threadIdx.x;
-    const bool do_p2 = nsplit == 1 || part == 0, do_p3 = nsplit == 1 || part == 1, first = part == 0;
+    // nsplit 1: one workgroup does P2 and P3; 2: part 0 = P2, part 1 = P3; 4: parts 0 / 1 = P2 on row tiles 0-3 / 4-7, parts 2 / 3 = P3 on
+    // column tile 0 / 1 (the node range halved over its waves)
+    const int np2 = nsplit == 4 ? 2 : 1;
+    const bool do_p2 = nsplit == 1 || part < np2, do_p3 = nsplit == 1 || part >= np2, first = part == 0;
     const int g0 = gptr[b], rows = gptr[b + 1] - g0, e0 = eptr[b], ne = eptr[b + 1] - e0;
     const int pb = (POOL && br.iperm) ? br.iperm[b] : b;
     const int lane = t & 63, li = lane & 31, lk = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    double* parts = br.dot_parts + ((size_t)sl * gridDim.x + b) * (2 * K);
+    double* parts = br.dot_parts + (((size_t)sl * np2 + (do_p2 ? part : 0)) * gridDim.x + b) * (2 * K);
     float* slab = br.slab + (size_t)b * K * H;
     if (rows <= 0 || rows > GW_T || ne > GW_E || ne < 0) {
         // empty graph (or a violated bound, flagged): its partial row and its slab slice must still exist
@@ -424,7 +430,7 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_bwd(const CSR g, const int* __r
     const bool hasw = br.ew != nullptr;
     const int rowsP = (rows + 31) & ~31, R = rowsP >> 5;
     // which product this wave runs, and on which tiles
-    const bool p2w = do_p2 && (nsplit == 2 || w < 4), p3w = do_p3 && (nsplit == 2 || w >= 4);
+    const bool p2w = do_p2 && (nsplit >= 2 || w < 4), p3w = do_p3 && (nsplit >= 2 || w >= 4);
     const int wk = w & 3;                                // 32-wide tile of the K input columns
     const int kq = min(wk * 32 + li, K - 1);             // this lane's input column in P2's epilogue / P3
     // ---- every global load of the kernel, issued before the first wait ----------------------------------------------------
@@ -455,12 +461,16 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_bwd(const CSR g, const int* __r
     const float dv = br.dis[g0 + min(t, rows - 1)];
     const float rv = RS ? br.rs[(size_t)(g0 + min(t, rows - 1)) * br.rs_stride] : 1.f;
     int nv[SU], ev[SU];
+    float cin[SU];                                       // coefficients in this slot order from an earlier kernel (k_plan_graph), if any
     const int slot_hi = max(g.nnz - 1, 0);
+    const float* coefp = br.coef_in ? br.coef_in : br.dis;
+    const int coef_hi = br.coef_in ? slot_hi : 0;
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
         const int s = min(e0 + max(min(t + u * GW_NT, ne - 1), 0), slot_hi);
         nv[u] = g.nbr[s];
         ev[u] = g.eid[s];
+        cin[u] = coefp[min(s, coef_hi)];
     }
     const bool ulane = UP && t >= 256;
     BNRawS braws = UP ? bn_raws_load2(br.bn, min(t, K - 1), br.ubn, ns0 + (t & (GC_N - 1)), ulane) : bn_raws_load(br.bn, min(t, K - 1));
@@ -472,7 +482,7 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_bwd(const CSR g, const int* __r
     bn_raws_pin(braws);
     if (UP) { stripe_pin(ud1s); stripe_pin(ud2s); }
 #pragma unroll
-    for (int u = 0; u < SU; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]));
+    for (int u = 0; u < SU; ++u) asm volatile("" : "+v"(nv[u]), "+v"(ev[u]), "+v"(cin[u]));
 #pragma unroll
     for (int i = 0; i < 8; ++i) ro_pin(wb[i]);
     if (POOL) { asm volatile("" : "+v"(gv), "+v"(gv1)); gv += br.gp1 ? gv1 : 0.f; }
@@ -500,7 +510,10 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_bwd(const CSR g, const int* __r
     }
     // second round: coefficient of the out-edge i -> j: w_e * dis_j
     float cv[SU];
-    {
+    if (br.coef_in) {
+#pragma unroll
+        for (int u = 0; u < SU; ++u) cv[u] = cin[u];
+    } else {
         const float* ewp = hasw ? br.ew : br.dis;
 #pragma unroll
         for (int u = 0; u < SU; ++u) {
@@ -678,22 +691,28 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_bwd(const CSR g, const int* __r
     double* red = reinterpret_cast<double*>(Ds);         // [8][2][32]
     // ---- P2: partial dX' = dz[:, ns] W[:, ns]^T, row tile by row tile; the BatchNorm-backward sums ride on its epilogue -------------
     if (p2w && wk * 32 < K) {
-        const int rt0 = nsplit == 2 ? (w >> 2) * 4 : 0, rt1 = min(R, nsplit == 2 ? rt0 + 4 : 8);
+        const int rt0 = nsplit == 4 ? part * 4 + (w >> 2) * 2 : nsplit == 2 ? (w >> 2) * 4 : 0;
+        const int rt1 = min(R, nsplit == 4 ? rt0 + 2 : nsplit == 2 ? rt0 + 4 : 8);
         const float mean = mean_s[kq], rstd = rstd_s[kq];
         float* dxp = sl ? br.dxp1 : br.dxp0;
         const float* xk = br.x + (size_t)g0 * K + kq;
         float f1[4] = {0.f, 0.f, 0.f, 0.f}, f2[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int rt = rt0; rt < rt1; ++rt) {
-            float xh[16];                                // x of this lane's column at the tile's rows (L2: the forward read it last)
+        // operands of tile rt + 1 (dz rows from LDS, this lane's x column from L2) are requested before the MFMAs of tile rt
+        auto rd = [&](int rt, float4 (&av)[8], float (&xh)[16], float (&rr)[RS ? 16 : 1]) {
+            const float* ap = Dz + (rt * 32 + li) * GW_LDD + 4 * lk;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xh[r] = xk[(size_t)min(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk, rows - 1) * K];
+            for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const float4*>(ap + 8 * i);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                xh[r] = xk[(size_t)min(i, rows - 1) * K];
+                if (RS) rr[r] = rs_s[i];
+            }
+        };
+        auto tile = [&](int rt, float4 (&av)[8], float (&xh)[16], float (&rr)[RS ? 16 : 1]) {
             gc_f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            const float* ap = Dz + (rt * 32 + li) * GW_LDD + 4 * lk;
-            float4 av[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const float4*>(ap + 8 * i);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, wb[i].x, acc, 0, 0, 0);
@@ -701,15 +720,30 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_bwd(const CSR g, const int* __r
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, wb[i].z, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, wb[i].w, acc, 0, 0, 0);
             }
+            // (rows past the graph: their dz rows are zero, so is the product -- no mask; their x_hat is a clamped, finite read)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int i = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                const float v = i < rows ? acc[r] : 0.f;
-                const float xn = (xh[r] * rs_s[min(i, GW_T - 1)] - mean) * rstd;
-                f1[r & 3] += v;
-                f2[r & 3] = fmaf(v, xn, f2[r & 3]);
+                const float xs = RS ? xh[r] * rr[r] : xh[r];
+                const float xn = (xs - mean) * rstd;
+                f1[r & 3] += acc[r];
+                f2[r & 3] = fmaf(acc[r], xn, f2[r & 3]);
             }
             gc_store_tile(acc, dxp + (size_t)(g0 + rt * 32) * K + wk * 32, K, rows - rt * 32, li, lk);
+        };
+        float4 avA[8], avB[8];
+        float xhA[16], xhB[16], rrA[RS ? 16 : 1], rrB[RS ? 16 : 1];
+        if (rt0 < rt1) rd(rt0, avA, xhA, rrA);
+        for (int rt = rt0; rt < rt1; rt += 2) {
+            if (rt + 1 < rt1) rd(rt + 1, avB, xhB, rrB);
+            __builtin_amdgcn_sched_barrier(0);
+            tile(rt, avA, xhA, rrA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (rt + 1 < rt1) {
+                if (rt + 2 < rt1) rd(rt + 2, avA, xhA, rrA);
+                __builtin_amdgcn_sched_barrier(0);
+                tile(rt + 1, avB, xhB, rrB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         double s1 = ((double)f1[0] + (double)f1[1]) + ((double)f1[2] + (double)f1[3]);
         double s2 = ((double)f2[0] + (double)f2[1]) + ((double)f2[2] + (double)f2[3]);
@@ -717,6 +751,9 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_bwd(const CSR g, const int* __r
         s2 += __shfl_xor(s2, 32, 64);
         if (lk == 0) { red[(w * 2 + 0) * 32 + li] = s1; red[(w * 2 + 1) * 32 + li] = s2; }
     }
+    gc_f32x16 acc_p3;                                    // nsplit 4: this wave's half of the node range
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc_p3[i] = 0.f;
     // ---- P3: dW[:, ns] (this graph's slab) = x'^T dz[:, ns] ---------------------------------------------------------------------
     if (p3w && wk * 32 < K) {
         const float sc = rstd_s[kq] * gam_s[kq], sh = bet_s[kq] - mean_s[kq] * sc;
@@ -724,14 +761,36 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_bwd(const CSR g, const int* __r
         gc_f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-        if (nsplit == 2) {
+        const int nsb = rowsP >> 5;
+        if (nsplit == 4) {
+            // this workgroup's column tile; waves w and w + 4 share the k tile and halve the node range, combined through LDS below
+            const int ct = part - np2, hsb = (nsb + 1) >> 1;
+            gw_p3<1, RS>(xk, K, rs_s, Dz + ct * 32 + li, rowsP, rows, lk, sc, sh, acc, w < 4 ? 0 : hsb, w < 4 ? hsb : nsb);
+            acc_p3 = acc[0];
+        } else if (nsplit == 2) {
             const int ct = w >> 2;
-            gw_p3<1>(xk, K, rs_s, Dz + ct * 32 + li, rowsP, rows, lk, sc, sh, acc);
+            gw_p3<1, RS>(xk, K, rs_s, Dz + ct * 32 + li, rowsP, rows, lk, sc, sh, acc, 0, nsb);
             gc_store_tile(acc[0], slab + (size_t)(wk * 32) * H + ns0 + ct * 32, H, 32, li, lk);
         } else {
-            gw_p3<2>(xk, K, rs_s, Dz + li, rowsP, rows, lk, sc, sh, acc);
+            gw_p3<2, RS>(xk, K, rs_s, Dz + li, rowsP, rows, lk, sc, sh, acc, 0, nsb);
 #pragma unroll
             for (int q = 0; q < 2; ++q) gc_store_tile(acc[q], slab + (size_t)(wk * 32) * H + ns0 + q * 32, H, 32, li, lk);
+        }
+    }
+    if (nsplit == 4 && do_p3) {
+        // (P3-only workgroup: the P2 scratch is idle, every wave reaches this barrier)
+        float* sc3 = reinterpret_cast<float*>(Ds);       // [4 k tiles][16][64]
+        gc_f32x16 acc3;
+        const bool live = wk * 32 < K;
+        if (w >= 4 && live) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc3[((w - 4) * 16 + i) * 64 + lane] = acc_p3[i];
+        }
+        __syncthreads();
+        if (w < 4 && live) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc3[i] = acc_p3[i] + sc3[(w * 16 + i) * 64 + lane];
+            gc_store_tile(acc3, slab + (size_t)(wk * 32) * H + ns0 + (part - np2) * 32, H, 32, li, lk);
         }
     }
     if (!do_p2) { BLK_CLK(1); return; }
@@ -741,7 +800,7 @@ __global__ void __launch_bounds__(GW_NT, 2) k_gw_bwd(const CSR g, const int* __r
         // column t of the two sums: P2's wave(s) of k tile t / 32
         const int kt = t >> 5, l = t & 31;
         double s1 = red[(kt * 2 + 0) * 32 + l], s2 = red[(kt * 2 + 1) * 32 + l];
-        if (nsplit == 2) { s1 += red[((kt + 4) * 2 + 0) * 32 + l]; s2 += red[((kt + 4) * 2 + 1) * 32 + l]; }
+        if (nsplit >= 2) { s1 += red[((kt + 4) * 2 + 0) * 32 + l]; s2 += red[((kt + 4) * 2 + 1) * 32 + l]; }
         if (br.dacc_sum) {
             const size_t po = (size_t)stripe_of_block() * br.dacc_ss + t;
             atomicAdd(br.dacc_sum + po, s1); atomicAdd(br.dacc_prod + po, s2);

@@ -21,8 +21,8 @@ constexpr int GP_E = 1024;                // edges per graph
 constexpr int GP_T2 = 256;                // the wider instantiation of k_plan_graph (SPMotif at the reference's default
 constexpr int GP_E2 = 2048;               // node_num = 15: up to ~250 nodes per graph)
 
-template <int GT, int GE>
-__global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ ei, int64_t E, int N, int B,
+template <int GT, int GE, int NT = 256>      // NT threads: 1024 for the wide instantiation (8 edges per lane and 8 ranking passes of 256 lanes were 14 us at 240-node graphs)
+__global__ void __launch_bounds__(NT) k_plan_graph(const int64_t* __restrict__ ei, int64_t E, int N, int B,
                                                     const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr,
                                                     const int64_t* __restrict__ batch, const int64_t* __restrict__ tile_gptr,
                                                     int Bgraphs, float loop_w,
@@ -31,11 +31,15 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
                                                     int* __restrict__ row32, int* __restrict__ col32, int* __restrict__ gptr,
                                                     int* __restrict__ eptr, float* __restrict__ dis_unit, int* __restrict__ status,
                                                     const float* __restrict__ x0, int F, double* __restrict__ st_sum,
-                                                    double* __restrict__ st_sq) {
+                                                    double* __restrict__ st_sq, float* __restrict__ coef_dst, float* __restrict__ coef_src) {
+    // coef_dst / coef_src != null: the unit-weight edge coefficient deg^-1/2 of the slot's neighbour, in slot order of either view (the
+    // wide per-graph convolutions read them with their first loads instead of chasing nbr -> dis in a second round)
+    __shared__ float dis_l[GT];
     // x0 != null: also the column sums / sums of squares of the raw features (bn_feat's batch statistics, model.py:90;
     // F <= 64), pre-reduced per graph in LDS and added to the zeroed accumulators with F fp64 atomics per workgroup
     __shared__ double fs[2][64];
-    constexpr int EU = GE / 256;                         // edges per lane
+    constexpr int EU = GE / NT;                          // edges per lane
+    static_assert(GE % NT == 0 && GT <= NT && NT >= 256, "block shape");
     constexpr int SU = GT / 64;                          // scan elements per lane
     __shared__ int deg_in[GT], deg_out[GT], off_in[GT + 1], off_out[GT + 1], cur_in[GT], cur_out[GT];
     __shared__ short rl[GE], cl[GE];                     // local endpoints of the graph's edges (edge-id order)
@@ -61,7 +65,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     int64_t rv[EU], cv[EU];
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
-        const int64_t e = e0 + max(min(t + u * 256, m - 1), 0);
+        const int64_t e = e0 + max(min(t + u * NT, m - 1), 0);
         rv[u] = m > 0 ? ei[e] : 0;
         cv[u] = m > 0 ? ei[E + e] : 0;
     }
@@ -73,7 +77,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
         // lane t of the first (256 / F) F lanes walks the elements t, t + lanes, ..: its column (t % F) is fixed, so it sums
         // in registers (<= ~10 terms, fp32) and adds ONE pair of values to the LDS accumulators -- one fp64 LDS atomic per
         // element was 480 serialised updates per address at 240-node graphs (5 us of this kernel)
-        const int lanes = (256 / F) * F, tot = rows * F;
+        const int lanes = (NT / F) * F, tot = rows * F;
         float s1 = 0.f, s2 = 0.f;
         if (t < lanes) {
             for (int i0 = t; i0 < tot; i0 += 4 * lanes) {
@@ -95,7 +99,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     if (t < rows && (bv < tg0 || bv >= tg1 || (t > 0 && gid_s[t - 1] > gid_s[t]))) atomicOr(status, 2);
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
-        const int s = t + u * 256;
+        const int s = t + u * NT;
         if (s < m) {
             int r = (int)(rv[u] - g0), c = (int)(cv[u] - g0);
             const bool bad = r < 0 || r >= rows || c < 0 || c >= rows;
@@ -135,12 +139,14 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
         ptr_dst[g0 + t] = (int)e0 + off_in[t];
         ptr_src[g0 + t] = (int)e0 + off_out[t];
         const float d = (float)deg_out[t] + loop_w;
-        dis_unit[g0 + t] = d == 0.f ? 0.f : 1.0f / sqrtf(d);
+        const float dd = d == 0.f ? 0.f : 1.0f / sqrtf(d);
+        dis_unit[g0 + t] = dd;
+        dis_l[t] = dd;
     }
     // scatter into the rows (arbitrary order inside a row) ...
 #pragma unroll
     for (int u = 0; u < EU; ++u) {
-        const int s = t + u * 256;
+        const int s = t + u * NT;
         if (s < m) {
             const int r = rl[s], c = cl[s];
             const int p = off_in[c] + atomicAdd(&cur_in[c], 1);
@@ -152,7 +158,7 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
     __syncthreads();
     BLK_CLK(3);
     // ... then every slot moves to its rank by edge id inside its row
-    for (int p = t; p < 2 * m; p += 256) {
+    for (int p = t; p < 2 * m; p += NT) {
         const bool d = p < m;
         const int q = d ? p : p - m;
         const short* te = d ? te_d : te_s;
@@ -170,8 +176,8 @@ __global__ void __launch_bounds__(256) k_plan_graph(const int64_t* __restrict__ 
             for (int u = 0; u < 8; ++u) rank += (k + u < s1 && x[u] < s) ? 1 : 0;
         }
         const int64_t slot = e0 + s0 + rank;
-        if (d) { nbr_dst[slot] = g0 + tn[q]; eid_dst[slot] = (int)(e0 + s); }
-        else { nbr_src[slot] = g0 + tn[q]; eid_src[slot] = (int)(e0 + s); }
+        if (d) { nbr_dst[slot] = g0 + tn[q]; eid_dst[slot] = (int)(e0 + s); if (coef_dst) coef_dst[slot] = dis_l[tn[q]]; }
+        else { nbr_src[slot] = g0 + tn[q]; eid_src[slot] = (int)(e0 + s); if (coef_src) coef_src[slot] = dis_l[tn[q]]; }
     }
     BLK_CLK(1);
 }
