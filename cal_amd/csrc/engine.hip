@@ -49,6 +49,8 @@ struct FinishArgs {
     float* stats;            // fused readout: stats[0] = wc*stats[1] + wo*stats[2] + wco*stats[3]
     float wc, wo, wco;
     float* tick;             // Adam step counter to advance (the update follows in the same step) or null
+    float* ticked;           // Adam step counter the step's FIRST kernel has already advanced (k_zero_f64), or null: taken back here when the
+                             // step is flagged -- whether the update rides in this kernel (adam.on) or follows as k_adam (range overflow)
     unsigned long long* perm_ctr;   // counter of the in-step permutation draw to advance (k_zero_f64's rank-sort workgroups only read it), or null
     // Adam inside this kernel (single-process steps, mode bit 4 without bit 8): every gradient element is updated by the
     // thread that finishes it, the ranges no task writes (gradients other kernels stored directly) by `nar` extra tasks
@@ -72,7 +74,8 @@ __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __re
     const bool flagged = fa.status && (fa.status[0] | fa.status[1]) != 0;     // every earlier kernel of the step has finished: uniform
     // a gated step applies no update, so it must not count as one either: the step's first kernel has already advanced the
     // Adam step counter (bias correction) -- take that back (advisor, round 4: the counter drifted by the frozen steps)
-    if (A.on && flagged && blockIdx.x == 0 && threadIdx.x == 0) A.step[0] -= 1.f;
+    // (advisor, round 5: keyed on adam.on the fallback to a separate k_adam -- adam.on = 0, counter already advanced -- kept counting)
+    if (fa.ticked && flagged && blockIdx.x == 0 && threadIdx.x == 0) fa.ticked[0] -= 1.f;
     if (A.on && flagged) A.on = 0;
     if (A.on) { adam_t = A.step[0]; adam_lr = A.lr[0]; }      // the step's first kernel has already advanced the counter
     while (task + 1 < ntask && (int)blockIdx.x >= fa.blk0[task + 1]) ++task;
@@ -1376,6 +1379,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     FinishArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.tick = (c.tick_in_finish && !c.adam_in_finish) ? e->step : nullptr;      // (adam_in_finish: k_zero_f64 did it)
+    fa.ticked = c.adam_in_finish ? e->step : nullptr;
     fa.perm_ctr = c.draw_perm ? e->perm_ctr : nullptr;
     fa.status = e->status;
     fa.host_status = e->host_status;
@@ -1999,7 +2003,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         a.p[0].aux = x0; a.p[0].has_aux = 1; a.p[0].aux_bn = bnref(c, 0, N, 0);
         a.p[0].dot_sum = bn_dsum(c, 0); a.p[0].dot_prod = bn_dprod(c, 0);
         {   // bn_feat's sums are only needed by the commit: keep the partial rows, no finalise launch
-            const int P0 = use_ks(N) ? gemm_ks_row_tiles(N) : gemm_row_tiles(N, F, H);
+            const int P0 = use_ks(N) ? gemm_ks_row_tiles(N) : gemm_row_tiles(N, F, H, false);
             if ((size_t)P0 * F * 2 > 4096) {
                 d_bn0.p = parts_alloc(c, (size_t)P0 * 2 * F); d_bn0.P = P0; d_bn0.stride = 2 * F;
                 a.p[0].parts = d_bn0.p;
@@ -2215,6 +2219,16 @@ CAL_EXPORT int cal_engine_set_tiles(void* h, const int64_t* tile_gptr, int64_t n
     Engine* e = (Engine*)h;
     CAL_REQUIRE(e != nullptr && ntiles >= 0 && (ntiles == 0 || tile_gptr != nullptr), "bad arguments");
     e->tile_gptr = ntiles > 0 ? tile_gptr : nullptr; e->ntiles = (int)ntiles;
+    return 0;
+}
+// Deterministic mode (atomic-free, bit-reproducible reductions): on = 1 turns the striped fp64 accumulators
+// (engine.hpp: stripe_sum -- order-dependent in the last bits) off for this engine: every BatchNorm sum is then a partial row per
+// workgroup, added in a fixed order by k_stats_final (what CAL_AMD_STRIPED=0 selects process-wide).  Same results to ~1e-16
+// relative, bit-identical from run to run; a few finishing launches per step slower.  Call before the first step is captured.
+CAL_EXPORT int cal_engine_set_deterministic(void* h, int on) {
+    Engine* e = (Engine*)h;
+    CAL_REQUIRE(e != nullptr, "bad arguments");
+    e->striped = on ? 0 : 1;
     return 0;
 }
 CAL_EXPORT int cal_engine_debug_stop(int k) { g_stop_after = k; return 0; }

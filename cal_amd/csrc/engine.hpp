@@ -261,7 +261,7 @@ int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStre
 int launch_gemm_dual(const GemmArgs& ax, int nbx, const GemmArgs& aw, int nbw, hipStream_t stream);
 int splitk_for(int64_t M, int64_t N, int64_t K, int nbatch);
 void gemm_set_split(GemmArgs& a, int S);
-int gemm_row_tiles(int M, int N, int K);
+int gemm_row_tiles(int M, int N, int K, bool hasC = true);
 // throughput variant (gemm_big.hip): 128x128 tiles for node-level products with >= 16k rows; 1 launched, 0 n/a, < 0 error
 bool gemm_big_rows(int M, int K);
 bool gemm_big_grad(int M, int N, int K);

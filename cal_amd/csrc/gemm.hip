@@ -425,7 +425,9 @@ __global__ void k_splitk_reduce(const float* __restrict__ part, float* __restric
 }
 
 // row tiles of a node-level GEMM (= partial statistic rows its epilogue writes): 128-row tiles on the throughput kernel
-int gemm_row_tiles(int M, int N, int K) { return gemm_wres_rows(M, N, K) ? gemm_wres_parts() : gemm_big_rows(M, K) ? cdiv(M, 128) : cdiv(M, BM); }
+// hasC = false: a statistics-only launch (C == nullptr: the dot sums of bn_feat's backward) -- the weight-resident kernel does not take
+// those (launch_gemm_wres), so its partial rows must not be sized for it (advisor, round 5: such a step failed with -2 at F, H in {128, 256})
+int gemm_row_tiles(int M, int N, int K, bool hasC) { return (hasC && gemm_wres_rows(M, N, K)) ? gemm_wres_parts() : gemm_big_rows(M, K) ? cdiv(M, 128) : cdiv(M, BM); }
 
 template <bool A_KC, bool B_KC, int XA, int XB>
 static void launch_one(const GemmArgs& a, dim3 grid, int vecA, int vecB, hipStream_t stream) {
@@ -487,7 +489,7 @@ int launch_gemm(bool transA, bool transB, const GemmArgs& a, int nbatch, hipStre
     if (int r = launch_gemm_wres(transA, transB, a, nbatch, stream)) return r < 0 ? 2 : 0;
     if (!transA && gemm_wres_rows(a.M, a.N, a.K))
         for (int b = 0; b < nbatch; ++b)
-            if (a.p[b].parts) { set_error("launch_gemm: statistics rows were sized for the weight-resident kernel, which cannot take this launch"); return 2; }
+            if (a.p[b].parts && a.p[b].C) { set_error("launch_gemm: statistics rows were sized for the weight-resident kernel, which cannot take this launch"); return 2; }
     if (int r = launch_gemm_big(transA, transB, a, nbatch, stream)) return r < 0 ? 2 : 0;
     if (!transA && gemm_big_rows(a.M, a.K))
         for (int b = 0; b < nbatch; ++b)

@@ -431,7 +431,7 @@ int launch_gemm_wres(bool transA, bool transB, const GemmArgs& a, int nbatch, hi
         for (int b = 0; b < nbatch; ++b) hasC = hasC && a.p[b].C != nullptr;
         if (!wres_aligned(a, nbatch) || xa < 0 || epi < 0 || !fits || !hasC) {
             for (int b = 0; b < nbatch; ++b)
-                if (a.p[b].parts) { set_error("launch_gemm_wres: a statistics GEMM sized for the weight-resident kernel cannot take this launch"); return -2; }
+                if (a.p[b].parts && a.p[b].C) { set_error("launch_gemm_wres: a statistics GEMM sized for the weight-resident kernel cannot take this launch"); return -2; }      // (C == nullptr: sized by gemm_row_tiles(.., hasC = false) for the tile kernels)
             return 0;
         }
         if (a.K == 256) { if (transB) wres_launch_xa<true, 8>(xa, epi, a, nbatch, stream); else wres_launch_xa<false, 8>(xa, epi, a, nbatch, stream); }

@@ -401,17 +401,18 @@ def _graph_sig(g):
             0 if y is None else (y.data_ptr(), y._version))
 
 
-def _unchanged(dataset, sigs) -> bool:
+def _unchanged(dataset, sigs, full: bool = True) -> bool:
     """Has the list (or a graph in it) changed since ``sigs`` was taken?  A replaced element, an edited label / feature / edge
-    list or a transform applied in place all show.  Lists of up to 512 graphs are checked completely; longer ones at ~512
-    positions whose phase rotates from call to call (~1.4 us per graph: a full pass over the reference's 5 596-graph training
-    split every epoch would cost as much as its first twenty steps) -- an edit of ONE graph of a long list is then seen within
-    a few loaders at the latest, a transform over the whole list at once.  The reference's loader re-reads its dataset every
-    batch (train_causal.py:13-15); ``clear_collate_cache()`` forces a rebuild."""
+    list or a transform applied in place all show.  ``full`` (every NEW DataLoader over a cached list): all graphs are compared
+    (~1.4 us each: 8 ms for the reference's 5 596-graph training split, once per loader).  ``full=False`` (a loader re-validating
+    its cache at the start of each further epoch): lists of more than 512 graphs are sampled at ~512 positions whose phase rotates
+    from call to call -- a transform over the whole list shows at once, an edit of ONE graph within a few epochs (advisor, round 5:
+    the sampled check used to be the only one, so a new loader could serve stale batches).  The reference's loader re-reads its
+    dataset every batch (train_causal.py:13-15); ``clear_collate_cache()`` forces a rebuild."""
     n = len(dataset)
     if n != len(sigs):
         return False
-    if n <= 512:
+    if full or n <= 512:
         idx = range(n)
     else:
         step = n // 509
@@ -425,13 +426,13 @@ def clear_collate_cache():
     del _CONCATS[:]
 
 
-def _concat_of(dataset):
+def _concat_of(dataset, full: bool = True):
     """One ``_HostConcat`` per dataset list, kept across DataLoader objects (loops that build a new loader every epoch over the
     same list would pay the concatenation -- ~30 ms for 5 000 graphs -- sixteen steps apart); rebuilt when the list or a graph
     in it has changed since (``_unchanged``)."""
     for i, (ds, sigs, hc) in enumerate(_CONCATS):
         if ds is dataset:
-            if _unchanged(dataset, sigs):
+            if _unchanged(dataset, sigs, full):
                 return hc
             del _CONCATS[i]
             break
@@ -488,6 +489,8 @@ class DataLoader:
     def __iter__(self) -> Iterable[Batch]:
         idx = self._indices()
         self.epoch += 1
+        if self._concat is not None:         # a further epoch of this loader: the cached concatenation is re-validated (sampled)
+            self._concat = _concat_of(self.dataset, full=False)
         for s in range(0, len(idx), self.batch_size):
             chunk = idx[s:s + self.batch_size]
             if self.drop_last and len(chunk) < self.batch_size:

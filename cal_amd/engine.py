@@ -121,7 +121,12 @@ def _layout_of(batch, B: int) -> dict:
 
 class StepEngine:
     def __init__(self, model, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, flat=None):
+                 weight_decay: float = 0.0, flat=None, deterministic: Optional[bool] = None):
+        """``deterministic``: every cross-row sum (BatchNorm statistics, their backward sums) is added in a fixed order -- steps are
+        bit-reproducible from run to run and across identical data-parallel replicas.  The default path adds those sums with fp64
+        atomics into four accumulator rows (order-dependent in the last bits, ~1e-16 relative; a few launches per step faster).
+        ``None`` follows ``torch.are_deterministic_algorithms_enabled()``; the environment variable CAL_AMD_STRIPED=0 selects
+        the same mode process-wide."""
         if not supported(model):
             raise ValueError("StepEngine covers CausalGCN / CausalGAT / CausalGIN (hidden % 4 == 0, <= 256, <= 6 layers, <= 64 classes)")
         p0 = next(model.parameters())
@@ -142,6 +147,12 @@ class StepEngine:
         if not h:
             raise _lib.CalError("cal_engine_create failed: " + _lib.lib().cal_last_error().decode())
         self._h = ctypes.c_void_p(h)
+        if deterministic is None:
+            deterministic = torch.are_deterministic_algorithms_enabled()
+        self.deterministic = bool(deterministic)
+        if self.deterministic:
+            _lib.call("cal_engine_set_deterministic", self._h, 1)
+        _loss_flag(self.device)              # (the fused loss's label flag exists before any step is captured)
         # model variants: cat readout (2H-wide co head), the two ablation flags (model.py:65-69,99-107)
         _lib.call("cal_engine_set_options", self._h, int(a.cat_or_add == "cat"),
                   int(bool(getattr(model, "without_node_attention", False))),
@@ -285,6 +296,9 @@ class StepEngine:
                 cb()                           # (optim.Binding: the flagged steps were not applied -- re-read the device step counter)
             msgs = [m for bit, m in self._STATUS_BITS if word & bit] or ["unknown status bits"]
             raise _lib.CalError("cal_amd engine: invalid batch (status 0x%x): %s" % (word, "; ".join(msgs)))
+        # the fused causal loss of statement-by-statement loops flags labels outside [0, C) in a word of its own (advisor, round 5:
+        # only train_causal's epoch read it; every caller of check_status -- trainer read-backs, evaluation -- now does)
+        check_loss_labels()
 
     def buffer(self, name: str, numel: int, dtype=torch.float32) -> torch.Tensor:
         off = _lib.query("cal_engine_buffer_offset", self._h, name.encode())

@@ -98,9 +98,10 @@ class _CausalBase(torch.nn.Module):
             object.__setattr__(self, "_engine", eng)
         return eng
 
-    def forward(self, data, eval_random=True, perm=None):
+    def forward(self, data, eval_random=True, perm=None, _objects_raw=False):
         x = data.x if data.x is not None else data.feat
-        eng = self._engine_for(x)
+        # (_objects_raw: CausalGIN's train_type = "irm" also returns the objects head's raw logits -- operator-level path)
+        eng = None if _objects_raw else self._engine_for(x)
         if eng is not None:
             from .engine import engine_forward_autograd
             if perm is None:
@@ -135,7 +136,7 @@ class _CausalBase(torch.nn.Module):
         xo = ops.add_pool(xo, plan)
 
         xc_logis = self.context_readout_layer(xc)
-        xo_logis = self.objects_readout_layer(xo)
+        xo_logis = self.objects_readout_layer(xo, "irm" if _objects_raw else "base")
         xco_logis = self.random_readout_layer(xc, xo, eval_random=eval_random, perm=perm)
         return xc_logis, xo_logis, xco_logis
 
@@ -146,11 +147,14 @@ class _CausalBase(torch.nn.Module):
         x = ops.linear(x, self.fc2_c.weight, self.fc2_c.bias)
         return F.log_softmax(x, dim=-1)
 
-    def objects_readout_layer(self, x):
+    def objects_readout_layer(self, x, train_type="base"):
+        """model.py:136-143; CausalGIN's variant (model.py:281-292) also hands back the raw logits for train_type = "irm"."""
         x = self.fc1_bn_o(x)
         x = ops.linear(x, self.fc1_o.weight, self.fc1_o.bias, relu=True)     # Linear + ReLU on the MFMA GEMM
         x = self.fc2_bn_o(x)
         x = ops.linear(x, self.fc2_o.weight, self.fc2_o.bias)
+        if train_type == "irm":
+            return x, F.log_softmax(x, dim=-1)
         return F.log_softmax(x, dim=-1)
 
     def intervention_list(self, num, eval_random):
@@ -288,3 +292,12 @@ class CausalGIN(_CausalBase):
         for conv in self.convs:                                   # model.py:244-245
             x = conv(x, edge_index, plan=plan)
         return x
+
+    def forward(self, data, eval_random=True, train_type="base", perm=None):
+        """model.py:234-264: ``forward(data, eval_random=True, train_type="base")``.  ``train_type="irm"`` makes the objects
+        head return ``(raw logits, log-probs)`` instead of the log-probs (model.py:281-292) -- dead in the reference's own loops
+        (train_causal.py:177,212 never pass it) but part of the module surface; that variant runs on the operator-level path,
+        where the raw logits are differentiable."""
+        if torch.is_tensor(train_type):                               # (a caller of the base-class order: forward(data, eval_random, perm))
+            perm, train_type = train_type, "base"
+        return super().forward(data, eval_random, perm=perm, _objects_raw=(train_type == "irm"))

@@ -115,7 +115,8 @@ class CausalTrainer:
                  use_graph: bool = True, world_size: int = 1, rebuild_plan: bool = True,
                  use_engine: Optional[bool] = None, device_perm: bool = True,
                  force_exchange: bool = False, graph_exchange: Optional[bool] = None,
-                 p2p_exchange: Optional[bool] = None):
+                 p2p_exchange: Optional[bool] = None, deterministic: Optional[bool] = None):
+        """``deterministic``: fixed-order BatchNorm sums -- bit-reproducible steps (``StepEngine(deterministic=...)``)."""
         from . import engine as eng_mod
         self.model, self.args = model, args
         self.use_graph = use_graph
@@ -129,7 +130,7 @@ class CausalTrainer:
         model.use_engine = False        # the trainer drives the engine itself; the module path stays op-level
         if use_engine:
             self.engine = eng_mod.StepEngine(model, lr=lr, weight_decay=weight_decay,
-                                             flat=(self.flat_p, self.flat_g))
+                                             flat=(self.flat_p, self.flat_g), deterministic=deterministic)
             self.engine.wc, self.engine.wo, self.engine.wco = float(args.c), float(args.o), float(args.co)
             self.lr = self.engine.lr
             self.opt = None

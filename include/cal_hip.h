@@ -246,6 +246,9 @@ CAL_API int cal_engine_set_graph_bounds(void* engine, int64_t max_nodes, int64_t
  * per-graph bounds this selects the one-kernel per-graph CSR build; violations are flagged in the status word */
 CAL_API int cal_engine_set_graph_ptrs(void* engine, const int64_t* node_ptr, const int64_t* edge_ptr);
 /* profiling aid: make cal_engine_step return after its k-th launch site (0 = run everything) */
+/* Deterministic mode of one engine: every BatchNorm sum as fixed-order partial rows (no fp64 atomics): bit-reproducible steps.
+ * No reference counterpart (torch.use_deterministic_algorithms is the closest notion); SURVEY.md section 7 "determinism". */
+CAL_API int cal_engine_set_deterministic(void* engine, int on);
 CAL_API int cal_engine_debug_stop(int k);
 /* name of launch site k (1-based) of the latest untruncated cal_engine_step; "" past the end */
 CAL_API const char* cal_engine_stage_name(int k);

@@ -693,3 +693,107 @@ def test_striped_batchnorm_sums_match_the_finishing_launches(name, monkeypatch):
         scale = max(1.0, s0[2][k].abs().max().item())
         assert (s1[2][k] - s0[2][k]).abs().max().item() <= 2e-5 * scale, k
     assert s0[3] and all(torch.allclose(s1[3][k], s0[3][k], rtol=1e-6, atol=1e-7) for k in s0[3])
+
+
+def _stage_names():
+    from cal_amd import _lib
+    h = _lib.lib()
+    names, k = [], 1
+    while True:
+        nm = h.cal_engine_stage_name(k)
+        nm = nm.decode() if isinstance(nm, bytes) else nm
+        if not nm:
+            return names
+        names.append(nm)
+        k += 1
+
+
+@pytest.mark.parametrize("nb,hidden,layers", [(32, 128, 3), (6, 64, 2), (1 + 256 // 4 // 2, 128, 1)])
+def test_config1_shape_takes_the_wide_per_graph_kernels(nb, hidden, layers):
+    """The reference's DEFAULT graph size (opts.py:18 node_num = 15 -> 225-247 nodes, utils.py:62-63) runs the wide per-graph
+    convolutions both ways (engine_gwide.hpp: k_gw_fwd / k_gw_bwd; gcn_conv.py:72-104, model.py:93-95,112-113) -- asserted by
+    launch-site name -- and matches the oracle: logits 1e-4, loss, every gradient.  The three batch sizes cover the launch shapes:
+    32-column slices + two / four workgroups per (graph, slice) in the backward (few graphs), 64-column slices and one workgroup."""
+    from cal_amd.data import Batch
+    gs = _config1_graphs(nb)
+    b, bd = Batch.from_data_list(gs), Batch.from_data_list(gs).to(DEV)
+    assert 128 < bd.max_nodes <= 256
+    torch.manual_seed(11)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=hidden, layers=layers)
+    g = torch.Generator().manual_seed(3)
+    for k in list(sd):                               # non-trivial biases / BatchNorm weights
+        if k.endswith(".bias") or ("bn" in k and k.endswith(".weight")):
+            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=g)
+    m, eng = _engine("CausalGCN", {k: v.clone() for k, v in sd.items()}, _args(hidden=hidden, layers=layers))
+    perm = torch.randperm(nb)
+    tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=layers)
+    loss, lc, lo, lco, logits = tr.step(b.feat, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
+    names = _stage_names()
+    assert names.count("k_gw_fwd(co)") == 1 and "k_gw_bwd" in names and "k_gw_fwd" in names, names
+    assert "k_espmm" not in names and "k_pool2" not in names
+    lp = eng.buffer("logp", 3 * nb * 4).view(3, nb, 4).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    eng.check_status()
+    for k, p in m.named_parameters():
+        gref = tr.sd[k].grad
+        if gref is not None:
+            assert torch.allclose(p.grad.cpu(), gref, atol=2e-4, rtol=4e-3), k
+
+
+def test_config1_shape_wide_kernels_with_fixed_order_sums(monkeypatch):
+    """The same step with CAL_AMD_STRIPED=0 (BatchNorm sums as partial rows + k_stats_final: the deterministic mode) and with
+    the wide kernels off (CAL_AMD_GWIDE=0: the node-level chain) gives the same logits / loss to 1e-5."""
+    from cal_amd.data import Batch
+    gs = _config1_graphs(16)
+    bd = Batch.from_data_list(gs).to(DEV)
+    perm = torch.randperm(16).to(DEV)
+    out = {}
+    for tag, env in (("wide", {}), ("fixed", {"CAL_AMD_STRIPED": "0"}), ("node", {"CAL_AMD_GWIDE": "0"})):
+        for k in ("CAL_AMD_STRIPED", "CAL_AMD_GWIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(11)
+        sd = O.init_state("CausalGCN", 10, 4, hidden=128, layers=3)
+        m, eng = _engine("CausalGCN", sd, _args())
+        stats = eng.train_step(bd, perm, adam=False).cpu()
+        names = _stage_names()
+        assert ("k_gw_fwd" in names) == (tag != "node"), (tag, names)
+        if tag == "fixed":
+            assert names.count("k_stats_final") >= 6, names          # every BatchNorm site finishes its partial rows
+        out[tag] = (stats[:4].clone(), eng.buffer("logp", 3 * 16 * 4).cpu().clone(),
+                    {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None})
+        eng.check_status()
+    for tag in ("fixed", "node"):
+        assert torch.allclose(out[tag][0], out["wide"][0], atol=1e-5)
+        assert (out[tag][1] - out["wide"][1]).abs().max().item() < 1e-5
+        for k, g in out["wide"][2].items():
+            assert torch.allclose(out[tag][2][k], g, atol=2e-4, rtol=4e-3), (tag, k)
+
+
+def test_wide_feature_matrix_big_batch_backward_takes_the_tile_kernels():
+    """Advisor (round 5, medium): with F and H both in {128, 256} and >= 16384 node rows, the statistics-only GEMM of bn_feat's
+    backward (C == nullptr, section S of engine_backward) was sized for the weight-resident kernel, which refuses launches without
+    C -> the step failed with -2.  The partial rows are now sized for the tile kernels (gemm_row_tiles(.., hasC = false))."""
+    from tests.helpers import random_graph_batch
+    b = random_graph_batch(num_graphs=60, n_lo=280, n_hi=300, p=0.012, feat=128, seed=7)
+    assert b.x.size(0) >= 16384
+    bd = random_graph_batch(num_graphs=60, n_lo=280, n_hi=300, p=0.012, feat=128, seed=7).to(DEV)
+    torch.manual_seed(4)
+    sd = O.init_state("CausalGCN", 128, 4, hidden=128, layers=1)
+    m, eng = _engine("CausalGCN", {k: v.clone() for k, v in sd.items()}, _args(hidden=128, layers=1), nfeat=128)
+    perm = torch.randperm(60)
+    tr = O.CpuTrainer("CausalGCN", {k: v.clone() for k, v in sd.items()}, 4, lr=1e-3, layers=1)
+    loss, lc, lo, lco, logits = tr.step(b.x, b.edge_index, b.batch, b.y, perm=perm)
+    stats = eng.train_step(bd, perm.to(DEV), adam=True).cpu().numpy()
+    eng.check_status()
+    lp = eng.buffer("logp", 3 * 60 * 4).view(3, 60, 4).cpu()
+    for r, t in zip(logits, lp):
+        assert (r.detach() - t).abs().max().item() < LOGIT_TOL
+    assert np.allclose(stats[:4], [loss.item(), lc.item(), lo.item(), lco.item()], atol=1e-4)
+    for k in ("bn_feat.weight", "bn_feat.bias", "conv_feat.weight"):
+        p = dict(m.named_parameters())[k]
+        assert torch.allclose(p.grad.cpu(), tr.sd[k].grad, atol=2e-4, rtol=4e-3), k

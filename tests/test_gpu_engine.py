@@ -23,13 +23,13 @@ def _args(**kw):
     return argparse.Namespace(**d)
 
 
-def _engine(sd, args, nfeat=10, ncls=4, lr=1e-3):
+def _engine(sd, args, nfeat=10, ncls=4, lr=1e-3, **kw):
     from cal_amd import model as M
     from cal_amd.engine import StepEngine
     m = M.CausalGCN(nfeat, ncls, args)
     m.load_state_dict(sd)
     m = m.to(DEV).train()
-    return m, StepEngine(m, lr=lr)
+    return m, StepEngine(m, lr=lr, **kw)
 
 
 def _close(a, b, atol, rtol):
@@ -185,13 +185,35 @@ def test_properties_at_full_size():
     assert torch.allclose(an.sum(1), torch.ones(N, device=DEV), atol=1e-6)
     for t in out1:
         assert torch.allclose(t.exp().sum(1), torch.ones(128, device=DEV), atol=1e-5)
-    # deterministic: partial-row reductions have a fixed order (hot-column atomics only touch fp64)
+    # run to run: the default path adds the BatchNorm sums with fp64 atomics into four accumulator rows (order-dependent in the
+    # last bits of a double): equal to 1e-6 ...
     state = {k: v.clone() for k, v in m.state_dict().items()}
     m.load_state_dict(sd)
     out2 = eng.forward(bd, perm, training=True)
     for u, v in zip(out1, out2):
         assert torch.allclose(u, v, atol=1e-6)
     m.load_state_dict(state)
+
+
+def test_deterministic_engine_is_bit_reproducible():
+    """``StepEngine(deterministic=True)`` / ``CausalTrainer(deterministic=True)`` (atomic-free, deterministic
+    reductions): every cross-row sum is a fixed-order sum of partial rows -- two runs of three training steps from the same
+    state give the same BITS (log-probs, loss statistics, every parameter after Adam), and the same as the default path to 1e-5."""
+    b, bd = _config2_batch()
+    torch.manual_seed(1)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=128, layers=3)
+    perm = torch.randperm(128, device=DEV)
+    runs = []
+    for det in (True, True, False):
+        m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(), deterministic=det)
+        assert eng.deterministic == det
+        stats = [eng.train_step(bd, perm, adam=True).clone() for _ in range(3)]
+        runs.append((eng.buffer("logp", 3 * 128 * 4).clone(), torch.stack(stats), eng.flat_p.detach().clone()))
+        eng.check_status()
+    for u, v in zip(runs[0], runs[1]):
+        assert torch.equal(u, v)                                   # bit for bit
+    for u, v in zip(runs[0], runs[2]):
+        assert torch.allclose(u, v, atol=1e-5, rtol=1e-5)          # the striped accumulators: same values to rounding
 
 
 def _ragged_batch(seed, nfeat, sizes):

@@ -186,3 +186,26 @@ def test_random_shape_sweep_cases_on_the_host_library(seed, name, kw, case):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import fuzz_host
     assert fuzz_host.run(case, seed, name, kw) == []
+
+
+def test_causalgin_forward_keeps_the_reference_signature_with_train_type():
+    """model.py:234,281-292: ``CausalGIN.forward(data, eval_random=True, train_type="base")``; ``"irm"`` makes the objects head
+    return (raw logits, log-probs).  Dead in the reference's loops, but a caller passing it must not get a TypeError."""
+    from cal_amd import model as M
+    ids = list(range(6))
+    torch.manual_seed(8)
+    m = M.CausalGIN(10, 4, _args()).eval()
+    perm = torch.arange(len(ids))
+    with torch.no_grad():
+        base = m(ref_batch(ids), True, "base", perm=perm)
+        c, (raw, o), co = m(ref_batch(ids), eval_random=True, train_type="irm", perm=perm)
+        old = m(ref_batch(ids), True, perm)                      # the base-class argument order still works
+    assert torch.allclose(o, torch.log_softmax(raw, dim=-1), atol=1e-6)
+    for r, t in zip(base, (c, o, co)):
+        assert torch.allclose(r, t, atol=1e-6)
+    for r, t in zip(base, old):
+        assert torch.allclose(r, t, atol=1e-6)
+    m.train()
+    c, (raw, o), co = m(ref_batch(ids), True, "irm", perm=perm)
+    raw.square().mean().backward()                               # the raw logits are differentiable (an IRM penalty needs that)
+    assert m.fc2_o.weight.grad is not None and m.fc2_o.weight.grad.abs().sum().item() > 0
