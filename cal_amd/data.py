@@ -16,6 +16,7 @@ the device ``GraphPlan`` (CSR structures) the HIP kernels consume.
 """
 from __future__ import annotations
 
+import operator
 import random as _random
 from typing import Iterable, List, Optional, Sequence
 
@@ -391,34 +392,67 @@ _CONCATS = []        # [(dataset list, per-graph signatures, _HostConcat)]: the 
 
 
 _FP_PHASE = [0]
+_VERSION_OF = operator.attrgetter("_version")
 
 
-def _graph_sig(g):
-    """Identity and in-place version of a graph's tensors (torch bumps ``_version`` on every in-place write)."""
-    x = g.x if getattr(g, "x", None) is not None else getattr(g, "feat", None)
-    ei, y = getattr(g, "edge_index", None), getattr(g, "y", None)
-    return (id(g), 0 if x is None else (x.data_ptr(), x._version), 0 if ei is None else (ei.data_ptr(), ei._version),
-            0 if y is None else (y.data_ptr(), y._version))
+_NO_TENSOR = torch.zeros(0)          # stands in for a missing attribute (its version counter never moves)
 
 
-def _unchanged(dataset, sigs, full: bool = True) -> bool:
-    """Has the list (or a graph in it) changed since ``sigs`` was taken?  A replaced element, an edited label / feature / edge
-    list or a transform applied in place all show.  ``full`` (every NEW DataLoader over a cached list): all graphs are compared
-    (~1.4 us each: 8 ms for the reference's 5 596-graph training split, once per loader).  ``full=False`` (a loader re-validating
-    its cache at the start of each further epoch): lists of more than 512 graphs are sampled at ~512 positions whose phase rotates
-    from call to call -- a transform over the whole list shows at once, an edit of ONE graph within a few epochs (advisor, round 5:
-    the sampled check used to be the only one, so a new loader could serve stale batches).  The reference's loader re-reads its
-    dataset every batch (train_causal.py:13-15); ``clear_collate_cache()`` forces a rebuild."""
+def _graph_refs(dataset, idx=None):
+    """(graphs, tensors): the graph OBJECTS at ``idx`` (all when None) and, three per graph, the tensor objects a collate reads
+    from them (features, edge_index, y).  The cache keeps these references, so "is it still the same tensor" is an identity
+    test on live objects (an address or ``data_ptr`` can be recycled by a replacement; a held object cannot)."""
+    graphs = list(dataset) if idx is None else [dataset[i] for i in idx]
+    tens = []
+    add = tens.append
+    for g in graphs:
+        d = getattr(g, "__dict__", None) or {}
+        x = d.get("x")
+        if x is None:
+            x = d.get("feat")
+        ei, y = d.get("edge_index"), d.get("y")
+        add(x if isinstance(x, torch.Tensor) else _NO_TENSOR)
+        add(ei if isinstance(ei, torch.Tensor) else _NO_TENSOR)
+        add(y if isinstance(y, torch.Tensor) else _NO_TENSOR)
+    return graphs, tens
+
+
+def _version_sum(tens) -> int:
+    """Sum of the in-place version counters (torch bumps ``_version`` on every in-place write; the counters only grow, so an
+    equal sum over the same objects means every one of them is unchanged)."""
+    return sum(map(_VERSION_OF, tens))
+
+
+def _graph_sig(dataset):
+    graphs, tens = _graph_refs(dataset)
+    vers = list(map(_VERSION_OF, tens))
+    return (graphs, tens, sum(vers), vers)
+
+
+def _unchanged(dataset, sig, full: bool = True) -> bool:
+    """Has the list (or a graph in it) changed since ``sig`` was taken?  A replaced element, a re-assigned or edited label /
+    feature / edge list and a transform applied in place all show: the graph and tensor OBJECTS are compared by identity, their
+    in-place version counters by sum.  ``full`` (every NEW DataLoader over a cached list): all graphs, ~0.7 us each -- 4 ms for
+    the reference's 5 596-graph training split, once per loader (round 5 compared a tuple of addresses and versions per graph:
+    1.8-4 us each, 0.23 ms per step of a loop that builds a loader per 16-batch epoch, more than the step itself).
+    ``full=False`` (a loader re-validating its cache at the start of each further epoch): lists of more than 512 graphs are
+    sampled at ~512 positions whose phase rotates from call to call -- a transform over the whole list shows at once, an edit of
+    ONE graph within a few epochs.  The reference's loader re-reads its dataset every batch (train_causal.py:13-15);
+    ``clear_collate_cache()`` forces a rebuild."""
+    graphs, tens, vsum, vers = sig
     n = len(dataset)
-    if n != len(sigs):
+    if n != len(graphs):
         return False
     if full or n <= 512:
-        idx = range(n)
-    else:
-        step = n // 509
-        _FP_PHASE[0] = (_FP_PHASE[0] + 1) % step
-        idx = list(range(_FP_PHASE[0], n, step)) + [0, n // 2, n - 1]
-    return all(sigs[i] == _graph_sig(dataset[i]) for i in idx)
+        g_now, t_now = _graph_refs(dataset)
+        return all(map(operator.is_, g_now, graphs)) and all(map(operator.is_, t_now, tens)) and _version_sum(t_now) == vsum
+    step = n // 509
+    _FP_PHASE[0] = (_FP_PHASE[0] + 1) % step
+    idx = list(range(_FP_PHASE[0], n, step)) + [0, n // 2, n - 1]
+    g_now, t_now = _graph_refs(dataset, idx)
+    t_then = [tens[3 * i + k] for i in idx for k in range(3)]
+    return (all(map(operator.is_, g_now, [graphs[i] for i in idx])) and all(map(operator.is_, t_now, t_then))
+            and _version_sum(t_now) == sum(vers[3 * i] + vers[3 * i + 1] + vers[3 * i + 2] for i in idx))
 
 
 def clear_collate_cache():
@@ -437,7 +471,7 @@ def _concat_of(dataset, full: bool = True):
             del _CONCATS[i]
             break
     hc = _HostConcat(dataset)
-    _CONCATS.append((dataset, [_graph_sig(g) for g in dataset], hc))
+    _CONCATS.append((dataset, _graph_sig(dataset), hc))
     del _CONCATS[:-2]
     return hc
 

@@ -101,3 +101,48 @@ def test_host_loader_pinned_ring_on_the_gpu_box():
             assert torch.equal(getattr(b, name).cpu(), getattr(ref, name)), (k, name)
     assert k == 24
     assert torch.equal(keep_ei, want_ei) and torch.equal(keep_y, want_y)
+
+
+def test_host_collated_steps_keep_up_with_device_collated_ones():
+    """Round-5 review item 5: bench.py's end_to_end.host_collate leg had fallen from 308 k to 71 k graphs/s.  The loss was not
+    in the step: a full garbage collection (~80 ms) inside a 60-step region and a per-graph cache validation for every new
+    loader object.  The loop itself -- DataLoader (vectorised collate into the pinned ring) -> Batch.to -> eager
+    CausalTrainer.step -- must stay within 1.5 x of the same loop fed by the on-device collate, at the headline shape
+    (measured 0.35 vs 0.25 ms per step).  Best of three regions each, gc off inside them, one loader per leg."""
+    import gc
+    import time
+    from cal_amd import model as M, spmotif
+    from cal_amd.data import DataLoader
+    from cal_amd.device_data import DeviceDataset, DeviceLoader
+    from cal_amd.trainer import CausalTrainer
+    args = argparse.Namespace(layers=3, hidden=128, with_random=True, without_node_attention=False,
+                              without_edge_attention=False, fc_num="222", cat_or_add="add", c=0.5, o=1.0, co=0.5)
+    gs = spmotif.train_mix(16 * 128, bias=0.9, node_num=7, seed=11)
+    per_step = {}
+    for kind in ("device", "host"):
+        torch.manual_seed(1)
+        model = M.CausalGCN(10, 4, args).cuda()
+        tr = CausalTrainer(model, args, lr=1e-3, use_graph=False)
+        gen = torch.Generator().manual_seed(3)
+        loader = (DeviceLoader(DeviceDataset(gs), 128, shuffle=True, generator=gen) if kind == "device"
+                  else DataLoader(gs, 128, shuffle=True, generator=gen))
+        for b in loader:                                   # warm-up epoch
+            tr.step(b.to(DEV))
+        torch.cuda.synchronize()
+        best = float("inf")
+        gc.collect()
+        gc.disable()
+        try:
+            for _ in range(3):
+                t0, n = time.perf_counter(), 0
+                for _epoch in range(4):
+                    for b in loader:
+                        tr.step(b.to(DEV))
+                        n += 1
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t0) / n)
+        finally:
+            gc.enable()
+        tr.check_status()
+        per_step[kind] = best
+    assert per_step["host"] <= 1.5 * per_step["device"], per_step
