@@ -59,6 +59,8 @@ struct FinishArgs {
     AdamArgs adam;
     AdamRange ar[MAX_ADAM_RANGES];
     int nar;
+    double* bn0z; int bn0z_n;   // bn_feat's statistics range of the fp64 arena: zeroed HERE for the next step (engine_plan.hpp: PlanFold)
+    int* dirty;              // the device word of that invariant, cleared here
     int* host_status;        // host-mapped mirror of status[0] | status[1], written by this kernel (cal_engine_peek_status), or null
     const int* status;       // the engine's status words: while any bit is up (this step's or a sticky earlier one) the gradients are
                              // not trusted and NO parameter / moment is updated (check_status raises and clears them)
@@ -84,6 +86,10 @@ __global__ void __launch_bounds__(256) k_finish(const FinishArgs fa, float* __re
         fa.stats[0] = fa.wc * fa.stats[1] + fa.wo * fa.stats[2] + fa.wco * fa.stats[3];
     if (fa.tick && !flagged && blockIdx.x == 0 && threadIdx.x == 0) fa.tick[0] += 1.f;      // (the k_adam that follows skips a flagged step too)
     if (fa.perm_ctr && blockIdx.x == 0 && threadIdx.x == 0) fa.perm_ctr[0] += 1;
+    if (fa.bn0z && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < fa.bn0z_n; i += 256) fa.bn0z[i] = 0.0;
+        if (threadIdx.x == 0) *fa.dirty = 0;
+    }
     if (fa.host_status && fa.status && blockIdx.x == 0 && threadIdx.x == 0)
         __hip_atomic_store(fa.host_status, fa.status[0] | fa.status[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // Both task kinds are pure reductions over S slabs / P partial rows: the loops keep 8 loads in flight
@@ -198,6 +204,9 @@ struct Engine {
     int ro_rows;             // 1: ... also for 129 .. 512 graphs, in row blocks (k_ro_step<true>); CAL_AMD_RO_ROWS=0: the GEMM chain there
     int striped;             // 1: the per-graph kernels exchange their BatchNorm sums through NSTRIPE accumulator planes (engine.hpp: stripe_sum)
                              // instead of partial rows + k_stats_final; CAL_AMD_STRIPED=0 keeps the finishing launches
+    int fold_zero;           // 1: forward + backward steps on the per-graph plan have no k_zero_f64 launch (PlanFold); CAL_AMD_FOLD_ZERO=0: always the launch
+    int bn0_dirty_host;      // host twin of the device word status[3]: a training forward has been enqueued since the last k_finish
+    int gw_cols;             // CAL_AMD_GW_COLS (experiment): 32 / 64 forces the wide forward kernels' slice width, 0 = by occupancy
     int gwide;               // 1: graphs of 129 .. 256 nodes run the wide per-graph convolutions (engine_gwide.hpp); CAL_AMD_GWIDE=0: the node-level chain
     int ro_step;             // 1: training steps run the readout as one launch (k_ro_step); CAL_AMD_RO_STEP=0 keeps the four kernels
     float *dzl, *dyh1, *dy1, *dxh, *dpool, *dZco, *gn, *gself, *ddeg, *dl, *dzco, *dXhco, *dZ, *dzi, *dXh, *slabs;
@@ -265,6 +274,9 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     { const char* v = getenv("CAL_AMD_RO_ROWS"); e->ro_rows = !(v && v[0] == '0'); }
     { const char* v = getenv("CAL_AMD_STRIPED"); e->striped = !(v && v[0] == '0'); }
     { const char* v = getenv("CAL_AMD_GWIDE"); e->gwide = !(v && v[0] == '0'); }
+    { const char* v = getenv("CAL_AMD_GW_COLS"); e->gw_cols = v ? atoi(v) : 0; }
+    { const char* v = getenv("CAL_AMD_FOLD_ZERO"); e->fold_zero = !(v && v[0] == '0'); }
+    e->bn0_dirty_host = 1;                            // 32 / 64 (experiment): forward slice width forced
     {
         // k_ro_step's 3 * H / 16 workgroups (133 KB of LDS each: one per CU) meet at spin barriers: they must all be
         // resident.  A device (or CU mask / partition) with fewer compute units than that takes the four-kernel readout.
@@ -453,6 +465,7 @@ CAL_EXPORT int cal_engine_set_workspace(void* h, void* ws, int64_t bytes, int64_
     size_t need = engine_layout(e, capN, capE, capB, true);
     CAL_REQUIRE((int64_t)need <= bytes, "workspace too small");
     e->ws_bytes = bytes;
+    e->bn0_dirty_host = 1;          // nothing is known about the new arena: the next step zeroes all of it (k_zero_f64)
     return 0;
 }
 
@@ -969,21 +982,36 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     // ... and for graphs of up to 8192 nodes (config 5): one 1024-thread workgroup per graph, rows ranked from a global scratch
     const bool big_plan = !fast_plan && e->node_ptr && e->edge_ptr && B > 0 && e->ntiles == 0 && e->max_nodes > 0 && e->max_nodes <= GPB_T;
     const bool plan_stats = (fast_plan || big_plan) && c.training && F <= 64;      // bn_feat's statistics ride in the plan kernel
-    // 0. zero the fp64 arena and the GraphPlan counters (one kernel, not memset nodes)
-    {
+    // 0. zero the fp64 arena and the GraphPlan counters (one kernel, not memset nodes) -- or, for a forward + backward step on
+    //    the per-graph plan, nothing: those duties ride in k_plan_graph (engine_plan.hpp: PlanFold) and bn_feat's statistics
+    //    range was zeroed by the previous step's k_finish
+    const bool fold = e->fold_zero && fast_plan && c.training && c.want_grad && !e->bn0_dirty_host && g_stop_after == 0;
+    if (c.training) e->bn0_dirty_host = 1;          // (cleared where k_finish is enqueued)
+    if (!fold) {
         const int64_t ni = (fast_plan || big_plan) ? 0 : 4 * ((int64_t)N + 1);
         hipLaunchKernelGGL(k_zero_f64, dim3(cdiv(std::max<int64_t>(e->arena_n, ni), 256) + (c.draw_perm ? cdiv(B, ZP_EPB) : 0)), dim3(256), 0, st,
                            e->arena, (int64_t)e->arena_n, e->work, ni, e->status, (e->K > 0 && c.training) ? e->gat_ctr : nullptr,
-                           c.draw_perm ? e->perm_dev : nullptr, B, e->perm_seed, e->perm_ctr, c.adam_in_finish ? e->step : nullptr);
+                           c.draw_perm ? e->perm_dev : nullptr, B, e->perm_seed, e->perm_ctr, c.adam_in_finish ? e->step : nullptr,
+                           c.training ? e->status + 3 : nullptr);
         CAL_CHECK_LAUNCH("k_zero_f64"); STAGE();
     }
     // 1. GraphPlan
     if (fast_plan) {
         auto kern = wide_plan ? k_plan_graph<GP_T2, GP_E2, 1024> : k_plan_graph<GP_T, GP_E, 256>;
-        hipLaunchKernelGGL(kern, dim3(T), dim3(wide_plan ? 1024 : 256), 0, st, edge_index, E, N, T, e->node_ptr, e->edge_ptr, batch, tgp, B, e->loop_w,
+        const int nt = wide_plan ? 1024 : 256;
+        PlanFold pf;
+        memset(&pf, 0, sizeof(pf));
+        if (fold) {
+            const int wp0 = (e->bn[0].width + 3) / 4 * 4;
+            pf.on = 1; pf.arena = e->arena; pf.n = e->arena_n; pf.skip_lo = e->bn[0].arena; pf.skip_hi = e->bn[0].arena + 2 * wp0;
+            pf.gat_tick = e->K > 0 ? e->gat_ctr : nullptr; pf.adam_step = c.adam_in_finish ? e->step : nullptr;
+            pf.perm = c.draw_perm ? e->perm_dev : nullptr; pf.permB = B; pf.seed = e->perm_seed; pf.perm_ctr = e->perm_ctr;
+            pf.dirty = e->status + 3;
+        }
+        hipLaunchKernelGGL(kern, dim3(T + ((fold && c.draw_perm) ? cdiv(B, nt / 4) : 0)), dim3(nt), 0, st, edge_index, E, N, T, e->node_ptr, e->edge_ptr, batch, tgp, B, e->loop_w,
                            e->rowptr_dst, e->nbr_dst, e->eid_dst, e->rowptr_src, e->nbr_src, e->eid_src, e->row32, e->col32,
                            e->gptr, e->eptr, e->dis_unit, e->status, plan_stats ? x0 : nullptr, F, bn_stsum(c, 0), bn_stsq(c, 0),
-                           use_gw(c) ? e->coef : nullptr, use_gw(c) ? e->coef_src : nullptr);
+                           use_gw(c) ? e->coef : nullptr, use_gw(c) ? e->coef_src : nullptr, pf);
         CAL_CHECK_LAUNCH("k_plan_graph"); STAGE();
     } else if (big_plan) {
         int* scratch = e->work + 4 * ((size_t)e->capN + 1);
@@ -1039,7 +1067,7 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     const bool gw = use_gw(c);
     const bool gw_st = gw && e->striped && c.training;   // the wide kernels' BatchNorm sums go through the accumulator planes (every reader is a striped reader)
     // 32-column slices (two workgroups per CU) when 64-column slices would leave half of the CUs without a workgroup
-    auto gw_narrow = [&](int nb) { return (int64_t)T * (H / GC_N) * nb * 2 <= e->num_cus; };
+    auto gw_narrow = [&](int nb) { return e->gw_cols ? e->gw_cols == 32 : (int64_t)T * (H / GC_N) * nb * 2 <= e->num_cus; };
     const bool gat = e->K > 0;
     for (int i = 1; i <= L; ++i) {
         // A training forward must leave what the backward of the SAME shape reads: the fused layer writes gt1 only, the
@@ -1383,6 +1411,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
     fa.perm_ctr = c.draw_perm ? e->perm_ctr : nullptr;
     fa.status = e->status;
     fa.host_status = e->host_status;
+    { const int wp0 = (e->bn[0].width + 3) / 4 * 4; fa.bn0z = e->arena + e->bn[0].arena; fa.bn0z_n = 2 * wp0; fa.dirty = e->status + 3; }
     size_t slab_off = 0;
     auto commit_p = [&](const double* src, int P, int stride, int dst, int n, float scale) {
         if (fa.nct < MAX_COMMITS) fa.ct[fa.nct] = CommitTask{src, P, stride, dst, n, scale};
@@ -2083,6 +2112,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         hipLaunchKernelGGL(k_finish, dim3(nblk), dim3(256), 0, st, fa, e->G);
     }
     CAL_CHECK_LAUNCH("k_finish"); STAGE();
+    e->bn0_dirty_host = 0;          // bn_feat's statistics range is clean again behind this launch (PlanFold)
     return 0;
 }
 

@@ -133,7 +133,9 @@ constexpr int ZP_EPB = 64;                 // elements ranked per workgroup
 __global__ void __launch_bounds__(256) k_zero_f64(double* __restrict__ a, int64_t n, int* __restrict__ ints, int64_t ni,
                                                   int* __restrict__ status, unsigned long long* __restrict__ tick,
                                                   int64_t* __restrict__ perm, int B, unsigned long long seed,
-                                                  unsigned long long* __restrict__ counter, float* __restrict__ adam_step) {
+                                                  unsigned long long* __restrict__ counter, float* __restrict__ adam_step,
+                                                  int* __restrict__ dirty) {
+    // dirty != null (a training forward): bn_feat's statistics range is about to be used; only a k_finish cleans it (PlanFold)
     __shared__ unsigned long long key[ZP_CAP];
     const int pblocks = perm ? (B + ZP_EPB - 1) / ZP_EPB : 0;
     if (perm && (int)blockIdx.x >= (int)gridDim.x - pblocks) {
@@ -146,6 +148,7 @@ __global__ void __launch_bounds__(256) k_zero_f64(double* __restrict__ a, int64_
     if (i == 0 && status) { status[1] |= status[0]; status[0] = 0; }
     if (i == 0 && tick) *tick += 1;
     if (i == 0 && adam_step) adam_step[0] += 1.f;       // the step ends with Adam inside k_finish, which reads the counter
+    if (i == 0 && dirty) *dirty = 1;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -21,6 +21,25 @@ constexpr int GP_E = 1024;                // edges per graph
 constexpr int GP_T2 = 256;                // the wider instantiation of k_plan_graph (SPMotif at the reference's default
 constexpr int GP_E2 = 2048;               // node_num = 15: up to ~250 nodes per graph)
 
+// The step's FIRST-kernel duties riding in k_plan_graph (round 6; they were a launch of their own, k_zero_f64: 4.9 us of the
+// 224 us headline step).  Taken by steps that END WITH k_finish in the same call (forward + backward), on the per-graph plan:
+//   * every workgroup zeroes its share of the fp64 arena EXCEPT bn_feat's statistics [skip_lo, skip_hi) -- this kernel adds the
+//     raw features' column sums there while other workgroups are still zeroing, so that range is zeroed by the PREVIOUS step's
+//     last kernel instead (k_finish: nothing reads it there) and is clean at entry by invariant;
+//   * thread 0 of workgroup 0 advances the attention-dropout counter and the Adam step counter;
+//   * the workgroups behind the B planning ones rank-sort the in-step permutation draw (randperm_slice, NT / 4 elements each).
+// `dirty` is the device word of that invariant: the stand-alone k_zero_f64 of a training forward raises it (the range is about to
+// be used and nothing in that call cleans it), k_finish clears it.  A captured folded step replayed behind such an orphan forward
+// would add onto stale sums: it flags status bit 512 instead and updates nothing (the host-side twin of the word keeps EAGER
+// steps off the fold in that state, so only a graph replay can meet it).
+struct PlanFold {
+    double* arena; int64_t n; int skip_lo, skip_hi;
+    unsigned long long* gat_tick; float* adam_step;
+    int64_t* perm; int permB; unsigned long long seed; const unsigned long long* perm_ctr;
+    const int* dirty;
+    int on;
+};
+
 template <int GT, int GE, int NT = 256>      // NT threads: 1024 for the wide instantiation (8 edges per lane and 8 ranking passes of 256 lanes were 14 us at 240-node graphs)
 __global__ void __launch_bounds__(NT) k_plan_graph(const int64_t* __restrict__ ei, int64_t E, int N, int B,
                                                     const int64_t* __restrict__ node_ptr, const int64_t* __restrict__ edge_ptr,
@@ -31,7 +50,23 @@ __global__ void __launch_bounds__(NT) k_plan_graph(const int64_t* __restrict__ e
                                                     int* __restrict__ row32, int* __restrict__ col32, int* __restrict__ gptr,
                                                     int* __restrict__ eptr, float* __restrict__ dis_unit, int* __restrict__ status,
                                                     const float* __restrict__ x0, int F, double* __restrict__ st_sum,
-                                                    double* __restrict__ st_sq, float* __restrict__ coef_dst, float* __restrict__ coef_src) {
+                                                    double* __restrict__ st_sq, float* __restrict__ coef_dst, float* __restrict__ coef_src,
+                                                    const PlanFold pf) {
+    if (pf.on) {
+        if ((int)blockIdx.x >= B) {                      // permutation draw (blocks B ..)
+            __shared__ unsigned long long pkey[1024];
+            randperm_slice<NT>(pf.perm, pf.permB, pf.seed, pf.perm_ctr, pkey, (int)blockIdx.x - B);
+            return;
+        }
+        const int64_t per = (pf.n + B - 1) / B, lo = (int64_t)blockIdx.x * per, hi = lo + per < pf.n ? lo + per : pf.n;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += NT)
+            if (i < pf.skip_lo || i >= pf.skip_hi) pf.arena[i] = 0.0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (pf.gat_tick) *pf.gat_tick += 1;
+            if (pf.adam_step) pf.adam_step[0] += 1.f;
+            if (*pf.dirty) atomicOr(status, 512);
+        }
+    }
     // coef_dst / coef_src != null: the unit-weight edge coefficient deg^-1/2 of the slot's neighbour, in slot order of either view (the
     // wide per-graph convolutions read them with their first loads instead of chasing nbr -> dis in a second round)
     __shared__ float dis_l[GT];

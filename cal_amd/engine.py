@@ -273,7 +273,9 @@ class StepEngine:
                     (32, "edge_index has self loops although the batch declared no_self_loops"),
                     (64, "the peer-memory gradient exchange timed out waiting for another rank"),
                     (256, "the one-launch readout timed out at an in-kernel barrier (its workgroups were not co-resident: "
-                          "another process is holding CUs; CAL_AMD_RO_STEP=0 runs the readout as separate launches)"))
+                          "another process is holding CUs; CAL_AMD_RO_STEP=0 runs the readout as separate launches)"),
+                    (512, "a captured train step was replayed behind a training-mode forward that had no backward (the step's "
+                          "BatchNorm accumulators were not clean: nothing was updated; the next step runs normally)"))
 
     def peek_status(self) -> int:
         """The status words as the latest COMPLETED training step left them (host-mapped mirror written by the step's last

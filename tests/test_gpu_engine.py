@@ -687,3 +687,87 @@ def test_row_blocked_readout_tracks_the_fp64_step(nb, monkeypatch):
     assert fuzz_engine.run(case, 4100 + nb) == []
     monkeypatch.setenv("CAL_AMD_RO_ROWS", "0")
     assert fuzz_engine.run(case, 4100 + nb) == []
+
+
+def _stage_names():
+    from cal_amd import _lib
+    h = _lib.lib()
+    names, k = [], 1
+    while True:
+        nm = h.cal_engine_stage_name(k)
+        nm = nm.decode() if isinstance(nm, bytes) else nm
+        if not nm:
+            return names
+        names.append(nm)
+        k += 1
+
+
+def test_first_kernel_duties_ride_in_the_plan_kernel(monkeypatch):
+    """Round 6: forward + backward steps on the per-graph plan have no k_zero_f64 launch -- k_plan_graph zeroes the fp64 arena
+    (all but bn_feat's statistics, which the previous step's k_finish zeroed), advances the counters and draws the in-step
+    permutation (engine_plan.hpp: PlanFold).  Three deterministic steps with the fold and with CAL_AMD_FOLD_ZERO=0 give the same
+    BITS; the first step of an engine (nothing known about its arena) and a step behind a training forward without backward
+    keep the launch; a captured folded step replayed behind such an orphan forward flags status bit 512 and updates nothing."""
+    from cal_amd import _lib
+    b, bd = _config2_batch()
+    torch.manual_seed(1)
+    sd = O.init_state("CausalGCN", 10, 4, hidden=128, layers=3)
+    perm = torch.randperm(128, device=DEV)
+    runs = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("CAL_AMD_FOLD_ZERO", fold)
+        m, eng = _engine({k: v.clone() for k, v in sd.items()}, _args(), deterministic=True)
+        stats, names = [], []
+        for _ in range(3):
+            stats.append(eng.train_step(bd, perm, adam=True).clone())
+            names.append(_stage_names())
+        eng.check_status()
+        assert "k_zero_f64" in names[0]                                   # first step: the arena is unknown
+        assert ("k_zero_f64" in names[1]) == (fold == "0") and ("k_zero_f64" in names[2]) == (fold == "0")
+        assert len(names[1]) == len(names[0]) - (1 if fold == "1" else 0)
+        runs.append((torch.stack(stats), eng.flat_p.detach().clone(), m.bn_feat.running_mean.clone(), m.bn_feat.running_var.clone()))
+        if fold == "1":
+            # the in-step permutation draw inside the plan kernel: the same permutation as the stand-alone launch draws
+            ctr = torch.zeros(1, dtype=torch.int64, device=DEV)
+            eng.set_perm_rng(1234, ctr)
+            eng.train_step(bd, None, adam=True, draw_perm=True)
+            assert "k_zero_f64" not in _stage_names()
+            drawn = eng.drawn_perm(128).clone()
+            assert sorted(drawn.tolist()) == list(range(128)) and int(ctr.item()) == 1
+            ref = torch.empty(128, dtype=torch.int64, device=DEV)
+            ctr2 = torch.zeros(1, dtype=torch.int64, device=DEV)
+            from cal_amd.plan import _p, _stream
+            _lib.call("cal_randperm", _p(ref), 128, 1234, _p(ctr2), _stream())
+            assert torch.equal(drawn, ref)
+            # an orphan training forward: the next EAGER step takes the launch again and is still right
+            eng.forward(bd, perm, training=True)
+            eng.train_step(bd, perm, adam=True)
+            assert "k_zero_f64" in _stage_names()
+            eng.train_step(bd, perm, adam=True)
+            assert "k_zero_f64" not in _stage_names()
+            eng.check_status()
+            # ... a captured folded step replayed behind one is refused loudly, and the step after it is fine
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                eng.train_step(bd, perm, adam=True)
+            torch.cuda.current_stream().wait_stream(s)
+            with torch.cuda.graph(g):
+                eng.train_step(bd, perm, adam=True)
+            g.replay()
+            torch.cuda.synchronize()
+            eng.check_status()
+            before = eng.flat_p.detach().clone()
+            eng.forward(bd, perm, training=True)
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(eng.flat_p.detach(), before)
+            with pytest.raises(_lib.CalError, match="0x200"):
+                eng.check_status()
+            g.replay()
+            torch.cuda.synchronize()
+            eng.check_status()
+            assert not torch.equal(eng.flat_p.detach(), before)
+    for u, v in zip(runs[0], runs[1]):
+        assert torch.equal(u, v)
