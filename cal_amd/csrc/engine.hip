@@ -479,11 +479,12 @@ CAL_EXPORT int64_t cal_engine_buffer_offset(void* h, const char* name) {
         {"dxh", e->dxh}, {"dpool", e->dpool}, {"dZco", e->dZco}, {"gn", e->gn}, {"gself", e->gself}, {"ddeg", e->ddeg},
         {"dl", e->dl}, {"dzco", e->dzco}, {"dXhco", e->dXhco}, {"dZ", e->dZ}, {"dzi", e->dzi}, {"dXh", e->dXh},
         {"arena", e->arena}, {"gptr", e->gptr}, {"status", e->status}, {"eptr", e->eptr},
+        {"gt1", e->gin ? e->gt1 : nullptr}, {"gy", e->gin ? e->gy : nullptr},
         {"rowptr_dst", e->rowptr_dst}, {"nbr_dst", e->nbr_dst}, {"eid_dst", e->eid_dst},
         {"rowptr_src", e->rowptr_src}, {"nbr_src", e->nbr_src}, {"eid_src", e->eid_src}, {"perm", e->perm_dev}, {"ones", e->ones},
     };
     for (auto& t : tab)
-        if (!strcmp(t.n, name)) return ((char*)t.p - e->ws) / 4;
+        if (!strcmp(t.n, name)) return t.p ? ((char*)t.p - e->ws) / 4 : -1;
     return -1;
 }
 
@@ -515,7 +516,7 @@ BNRef bnref(const Ctx& c, int k, int rows, int update) {
     const int wp = (b.width + 3) / 4 * 4;
     r.sum = e->arena + b.arena; r.sq = e->arena + b.arena + wp;
     r.gamma = e->P + b.gamma; r.beta = e->P + b.beta;
-    r.inv_n = 1.0f / (float)rows; r.eps = 1e-5f;
+    r.inv_n = 1.0 / (double)rows; r.eps = 1e-5f;
     r.run_mean = b.rm; r.run_var = b.rv; r.nbt = b.nbt;
     r.unbias = rows > 1 ? (float)rows / (float)(rows - 1) : 1.f;
     r.update = (update && c.training) ? 1 : 0;

@@ -13,7 +13,9 @@ struct BNRef {
     const double* sq;      // [W]
     const float* gamma;    // [W] (null -> 1)
     const float* beta;     // [W] (null -> 0)
-    float inv_n;           // 1 / rows
+    double inv_n;          // 1 / rows, in DOUBLE: as a float, 1 / 3 is off by 3e-8 and var = q / n - (s / n)^2 inherits 3e-8 * mean^2 --
+                           // 1e-4 of the variance of a pooled column with mean / sigma = 60 in a batch of 3 graphs (round 6: the
+                           // one report of the random-shape sweep the ReLU masks did not explain, tests/tools/fuzz_engine.py)
     float eps;
     // running statistics (updated by exactly one consumer block when update != 0; momentum 0.1,
     // unbiased variance, num_batches_tracked += 1)

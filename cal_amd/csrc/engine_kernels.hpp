@@ -1145,7 +1145,7 @@ __global__ void __launch_bounds__(256) k_att_bwd(const AttBwdArgs a, int relu, i
     const int grp = threadIdx.x / G, l = threadIdx.x % G;
     const int rbeg = blockIdx.x * rows_per_block, rend = min(N, rbeg + rows_per_block);
     using V = Vec<VEC>;
-    const float inv_n = a.bnc.inv_n;
+    const double inv_n = a.bnc.inv_n;
     double sdl = 0.0, ssp = 0.0;
     // the kernel supports one column chunk per lane (H <= G*VEC), enforced by the host
     const int c = l * VEC;
