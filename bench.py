@@ -311,6 +311,13 @@ def engine_roofline(trainer, batches, workload, iters=20):
         "dual": ("k_gemm_dual", "k_gemm_dual (one grid) / k_wres<NT, dot sums> + k_tn (two launches, timed as one class): dX = dZ W^T with the BN-backward sums "
                                 "+ dW = BN(h)^T dZ over node ranges (backbone layers, backward)", "k_gemm_dual"),
     }
+    if WORKLOADS.get(workload, {}).get("node_num") == 15:
+        # graphs of 129-256 nodes (the reference's default SPMotif shape): the same two classes are the WIDE per-graph kernels
+        mfma["gconv"] = ("k_gconv_fwd", "k_gw_fwd (engine_gwide.hpp): per-graph fused GCNConv for 129-256-node graphs -- BN + [n,H]x[H,64|32] MFMA product "
+                                        "with the node operand straight from global memory + SPARSE aggregation from the LDS-resident z slice + "
+                                        "bias/ReLU/BN statistics (backbone layers, forward)", "k_gw_fwd")
+        mfma["gconv_bwd"] = ("k_gconv_bwd", "k_gw_bwd (engine_gwide.hpp): its backward -- sparse transposed aggregation from LDS, dX' = dz W^T (BN-backward sums) "
+                                            "and dW = x'^T dz on MFMA, split over two workgroups per (graph, slice) (backbone layers, backward)", "k_gw_bwd")
     # primary roofline = the MFMA kernel class that takes the most time per step
     best = None
     for key in mfma:

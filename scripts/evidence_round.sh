@@ -10,7 +10,7 @@ for w in spmotif_b0.9_causalgcn_h128_l3_bs128 ba5000_causalgcn_h256_l3_bs32 ba50
     bash scripts/pmc_mfma_util.sh $w $tag > /dev/null 2>&1
     bash scripts/pmc_issue.sh $w $tag > /dev/null 2>&1
 done
-for w in ba5000_causalgcn_h256_l3_bs32 ba5000_causalgat_h256_l3_bs32 spmotif_b0.9_causalgcn_h128_l3_bs128 spmotif_b0.9_causalgcn_nodenum15_bs32 mutaglike_causalgat_h128_l3_bs64 nci1like_causalgcn_h128_l3_bs512; do
+for w in ba5000_causalgcn_h256_l3_bs32 ba5000_causalgat_h256_l3_bs32 spmotif_b0.9_causalgcn_h128_l3_bs128 spmotif_b0.9_causalgcn_nodenum15_bs32 spmotif_b0.9_causalgcn_nodenum15_bs128 mutaglike_causalgat_h128_l3_bs64 nci1like_causalgcn_h128_l3_bs512; do
     bash scripts/trace_step.sh $w $tag/traces > /dev/null 2>&1
 done
 for v in 0 1; do

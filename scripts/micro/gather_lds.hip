@@ -212,6 +212,88 @@ __global__ void __launch_bounds__(256) k_v1b(const int* __restrict__ ptr, const 
     if (NTMODE >= 1) { vf4 t; t.x = acc.x; t.y = acc.y; t.z = acc.z; t.w = acc.w; __builtin_nontemporal_store(t, (vf4*)(out + (size_t)i * H + c)); }
     else *(float4*)(out + (size_t)i * H + c) = acc;
 }
+
+// V1d (round 6): R rows per wave IN FLIGHT TOGETHER -- the loads of every stage (extents, slots, first NB0 gathers of each row) are issued for
+// all R rows before any is used, so a wave's three dependent round trips carry R rows; rows of more than NB0 slots finish in V1b's loop.
+// (V1b keeps one row per wave in flight: 8 waves x 4 SIMDs = 32 rows per CU, each a chain of ~3 round trips -- rows in flight, not bytes,
+//  bound the kernel: the column-halves variant moves 1.18 x the algorithmic bytes instead of 1.52 x and is SLOWER.)
+template <int R, int NB0>
+__global__ void __launch_bounds__(256) k_v1d(const int* __restrict__ ptr, const int* __restrict__ nbr, const float* __restrict__ cs,
+                                             const float* __restrict__ dis, const float* __restrict__ h, float* __restrict__ out, int N, int nnz) {
+    const int per = gridDim.x >> 3;
+    const int bxr = (int)blockIdx.x < 8 * per ? (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, c = lane * 4;
+    const int i0 = __builtin_amdgcn_readfirstlane((bxr * 4 + (int)(threadIdx.x >> 6)) * R);
+    if (i0 >= N) return;
+    int p0[R], cnt[R], jl[R];
+    float di[R], cl[R];
+    float4 hs[R], acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int ir = min(i0 + r, N - 1);
+        p0[r] = ptr[ir]; cnt[r] = ptr[ir + 1];
+        di[r] = dis[ir];
+        hs[r] = *(const float4*)(h + (size_t)ir * H + c);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        cnt[r] -= p0[r];
+        const int s = min(p0[r] + min(lane, max(cnt[r] - 1, 0)), nnz - 1);
+        jl[r] = nbr[s];
+        const float cv = cs[s];
+        cl[r] = lane < cnt[r] ? cv : 0.f;
+        acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    {
+        float4 v[R][NB0];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int u = 0; u < NB0; ++u) {
+                const int j = __builtin_amdgcn_readlane(jl[r], u);
+                v[r][u] = *(const float4*)(h + (size_t)j * H + c);
+            }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int u = 0; u < NB0; ++u) {
+                const float cf = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cl[r]), u));
+                acc[r].x = fmaf(cf, v[r][u].x, acc[r].x); acc[r].y = fmaf(cf, v[r][u].y, acc[r].y);
+                acc[r].z = fmaf(cf, v[r][u].z, acc[r].z); acc[r].w = fmaf(cf, v[r][u].w, acc[r].w);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (cnt[r] > NB0) {                           // (wave-uniform) the rest of the row, V1b's loop
+            int jr = jl[r]; float cr = cl[r];
+            for (int base = 0; base < cnt[r]; base += 64) {
+                if (base) {
+                    const int s = p0[r] + min(base + lane, cnt[r] - 1);
+                    jr = nbr[s]; cr = cs[s];
+                }
+                const int n = min(64, cnt[r] - base);
+                int q = base ? 0 : NB0;
+                for (; q + 8 <= n; q += 8) v1_batch<8>(acc[r], h, jr, cr, q, c);
+                switch (n - q) {
+                    case 7: v1_batch<7>(acc[r], h, jr, cr, q, c); break;
+                    case 6: v1_batch<6>(acc[r], h, jr, cr, q, c); break;
+                    case 5: v1_batch<5>(acc[r], h, jr, cr, q, c); break;
+                    case 4: v1_batch<4>(acc[r], h, jr, cr, q, c); break;
+                    case 3: v1_batch<3>(acc[r], h, jr, cr, q, c); break;
+                    case 2: v1_batch<2>(acc[r], h, jr, cr, q, c); break;
+                    case 1: v1_batch<1>(acc[r], h, jr, cr, q, c); break;
+                    default: break;
+                }
+            }
+        }
+        if (i0 + r < N) {
+            float4 a = acc[r];
+            a.x = fmaf(di[r], hs[r].x, a.x); a.y = fmaf(di[r], hs[r].y, a.y); a.z = fmaf(di[r], hs[r].z, a.z); a.w = fmaf(di[r], hs[r].w, a.w);
+            a.x *= di[r]; a.y *= di[r]; a.z *= di[r]; a.w *= di[r];
+            *(float4*)(out + (size_t)(i0 + r) * H + c) = a;
+        }
+    }
+}
 // V1c: persistent waves (grid = CUs x 8 workgroups), every wave walks rows i, i + stride, ...; the NEXT row's pointers and slots
 // are requested before the current row's gathers are consumed (software pipeline over rows)
 __global__ void __launch_bounds__(256) k_v1c(const int* __restrict__ ptr, const int* __restrict__ nbr, const float* __restrict__ cs,
@@ -548,6 +630,20 @@ int main(int argc, char** argv) {
         us = timeit([&] { hipLaunchKernelGGL(k_v1c, dim3(wgs), dim3(256), 0, 0, d_ptr, d_nbr, d_cs, d_dis, d_h, d_out, N, 0); });
         char nm[96]; snprintf(nm, sizeof nm, "V1c persistent waves (%d wgs), next row prefetched", wgs);
         report(nm, us); check("v1c", d_out);
+    }
+    // ---- V1d: R rows per wave in flight together
+    {
+        auto run = [&](auto kern, int R, const char* nm) {
+            CK(hipMemset(d_out, 0, (size_t)N * H * 4));
+            const int grid = (N + 4 * R - 1) / (4 * R);
+            float t = timeit([&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d_ptr, d_nbr, d_cs, d_dis, d_h, d_out, N, (int)G.E); });
+            report(nm, t); check("v1d", d_out);
+        };
+        run(k_v1d<2, 4>, 2, "V1d 2 rows per wave together, first 4 slots each");
+        run(k_v1d<2, 8>, 2, "V1d 2 rows per wave together, first 8 slots each");
+        run(k_v1d<4, 4>, 4, "V1d 4 rows per wave together, first 4 slots each");
+        run(k_v1d<4, 2>, 4, "V1d 4 rows per wave together, first 2 slots each");
+        run(k_v1d<1, 4>, 1, "V1d 1 row per wave, first 4 slots unconditional");
     }
     // ---- V1h: column halves in L2-sized windows
     for (int win : {5000, 2500, 10000}) {

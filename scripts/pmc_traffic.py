@@ -12,6 +12,8 @@ fetch, write, workload = json.load(open(sys.argv[1])), json.load(open(sys.argv[2
 # and the two-branch launches); "by_kernel" below lists every kernel of the pass by its full template name as well.
 classes = {
     "k_gconv_fwd": "k_gconv_fwd<false", "k_gconv_fwd_co": "k_gconv_fwd<true", "k_gconv_bwd": "k_gconv_bwd<false, 1",
+    "k_gw_fwd": "k_gw_fwd<false", "k_gw_fwd_co": "k_gw_fwd<true", "k_gw_bwd": "k_gw_bwd<false, 1", "k_gw_bwd_top": "k_gw_bwd<false, 0",
+    "k_gw_bwd_co": "k_gw_bwd<true, 2", "k_ro_step": "k_ro_step", "k_plan_graph": "k_plan_graph",
     "k_gconv_bwd_top": "k_gconv_bwd<false, 0", "k_gconv_bwd_co": "k_gconv_bwd<true, 2", "k_att_fwd_graph": "k_att_fwd_graph",
     "k_ggin_fwd": "k_ggin_fwd<1>", "k_ggin_bwd": "k_ggin_bwd<1>", "k_feat_bwd": "k_feat_bwd",
     "k_att_bwd_graph": "k_att_bwd_graph", "k_finish": "k_finish", "k_espmm_all": "k_espmm", "k_gemm_backbone": "k_gemm<",
