@@ -30,7 +30,7 @@ constexpr int GW_K = 128;                 // reduction width (= hidden)
 // node + coefficient) and handed to the group's 16 lanes by v_mov_b32_dpp row_newbcast:c -- a register move, no LDS round trip and
 // no scalar traffic per slot; a row of more than 16 slots reloads the chunk.  (First version, round 6: one row per wave, one lane
 // per column, slots by v_readlane: ~1000 cycles per row -- every 4-slot batch, the chunk preload and the self-loop term were
-// LDS round trips of their own -- 12-17 us of a 29 us kernel at 240-node graphs, in-kernel clocks.)
+// LDS round trips of their own -- 12-17 us of a 29 us kernel at 240-node graphs; profiles/r6/micro_gw_phases.txt.)
 template <int S> __device__ __forceinline__ int gw_bcast(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + S, 0xF, 0xF, true); }      // row_newbcast:S
 template <int S> __device__ __forceinline__ float gw_bcast(float v) { return __int_as_float(gw_bcast<S>(__float_as_int(v))); }
 template <int VW> __device__ __forceinline__ void gw_ld(const float* p, float (&v)[VW]) {
