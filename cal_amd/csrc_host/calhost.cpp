@@ -488,18 +488,30 @@ HOST_EXPORT int cal_collate_host(const float* X, const int64_t* EI, int64_t Etot
                                  const int64_t* edge_ptr, const int64_t* Y, const int64_t* idx, int64_t B, float* xo,
                                  int64_t* eio, int64_t Eout, int64_t* batcho, int64_t* yo) {
     HOST_REQUIRE(X && EI && node_ptr && edge_ptr && Y && idx && xo && eio && batcho && yo && B >= 0 && F > 0, "bad arguments");
-    int64_t nodes = 0, edges = 0;
+    // offsets of every member graph first (serial, B additions), then the copies -- 128 scattered graphs of a 10 MB dataset are
+    // ~0.7 MB of cache-missing reads: 120 us on one core, the largest piece of a host-collated step (0.34 ms against 0.22 ms on
+    // the GPU) -- over a few threads (a fixed small team: the work is 100 us, the caller's loop runs it every 0.3 ms)
+    std::vector<int64_t> noff((size_t)B + 1), eoff((size_t)B + 1);
+    noff[0] = 0; eoff[0] = 0;
+    for (int64_t b = 0; b < B; ++b) {
+        const int64_t g = idx[b];
+        const int64_t nn = node_ptr[g + 1] - node_ptr[g], ne = edge_ptr[g + 1] - edge_ptr[g];
+        HOST_REQUIRE(nn >= 0 && ne >= 0 && eoff[b] + ne <= Eout, "offsets out of range");
+        noff[b + 1] = noff[b] + nn; eoff[b + 1] = eoff[b] + ne;
+    }
+    const int64_t edges = eoff[B];
+    const int team = B >= 32 ? 4 : 1;
+#pragma omp parallel for schedule(static) num_threads(team) if (team > 1)
     for (int64_t b = 0; b < B; ++b) {
         const int64_t g = idx[b];
         const int64_t nb = node_ptr[g], nn = node_ptr[g + 1] - nb, eb = edge_ptr[g], ne = edge_ptr[g + 1] - eb;
-        HOST_REQUIRE(nn >= 0 && ne >= 0 && edges + ne <= Eout, "offsets out of range");
+        const int64_t nodes = noff[b], e0 = eoff[b];
         std::copy(X + nb * F, X + (nb + nn) * F, xo + nodes * F);
         const int64_t* src = EI + eb;
         const int64_t* dst = EI + Etot + eb;
-        for (int64_t k = 0; k < ne; ++k) { eio[edges + k] = src[k] + nodes; eio[Eout + edges + k] = dst[k] + nodes; }
+        for (int64_t k = 0; k < ne; ++k) { eio[e0 + k] = src[k] + nodes; eio[Eout + e0 + k] = dst[k] + nodes; }
         std::fill(batcho + nodes, batcho + nodes + nn, b);
         yo[b] = Y[g];
-        nodes += nn; edges += ne;
     }
     HOST_REQUIRE(edges == Eout, "edge count mismatch");
     return 0;

@@ -227,6 +227,10 @@ class Batch(Data):
         return self
 
 
+# every attribute Batch.__init__ sets, at its default (the host collate fills instances without calling it)
+_BATCH_DEFAULTS = dict(Batch().__dict__)
+
+
 class _StageSlot:
     """One pinned (float, int64) buffer pair of the host loader's ring.  It is handed to a new batch only when the batch that
     last used it is gone or has been moved to the device; the ring is walked round-robin, so the copy that last read a slot
@@ -340,11 +344,16 @@ class _HostConcat:
         views = [("x" if self.feat_is_x else "feat", "f", 0, N * F, (N, F)), ("edge_index", "i", 0, 2 * E, (2, E)),
                  ("batch", "i", o_b, o_y, (N,)), ("y", "i", o_y, o_p, (B,)), ("ptr", "i", o_p, o_e, (B + 1,)),
                  ("edge_ptr", "i", o_e, o_t, (B + 1,))]
-        b = Batch()
-        b.num_graphs = B
-        b.max_nodes = int(n.max()) if B else 0
-        b.max_edges = int(e.max()) if B else 0
-        b.no_self_loops = self.no_self_loops
+        # (the object is filled through its __dict__ in one go and the int64 views come from ONE split: Batch() + a slice and a view
+        #  per attribute were 75 us of a 250 us collate, a third of what the GPU needs for the whole step)
+        b = Batch.__new__(Batch)
+        d = b.__dict__
+        d.update(_BATCH_DEFAULTS)
+        d["num_graphs"] = B
+        d["max_nodes"] = int(n.max()) if B else 0
+        d["max_edges"] = int(e.max()) if B else 0
+        d["no_self_loops"] = self.no_self_loops
+        sizes = [2 * E, N, B, B + 1, B + 1]
         if T1:
             fi = np.asarray(first, dtype=np.int64)
             tn, te = noff[fi], eoff[fi]
@@ -353,9 +362,14 @@ class _HostConcat:
             ia[o_t + 2 * T1:o_t + 3 * T1] = te
             views += [("tile_ptr", "i", o_t, o_t + T1, (T1,)), ("tile_node_ptr", "i", o_t + T1, o_t + 2 * T1, (T1,)),
                       ("tile_edge_ptr", "i", o_t + 2 * T1, o_t + 3 * T1, (T1,))]
-            b.tile_max_nodes, b.tile_max_edges = int((tn[1:] - tn[:-1]).max()), int((te[1:] - te[:-1]).max())
-        for name, kind, a, c, shape in views:
-            setattr(b, name, (fbuf if kind == "f" else ibuf)[a:c].view(shape))
+            d["tile_max_nodes"], d["tile_max_edges"] = int((tn[1:] - tn[:-1]).max()), int((te[1:] - te[:-1]).max())
+            sizes += [T1, T1, T1]
+        parts = ibuf.split(sizes)
+        d["x" if self.feat_is_x else "feat"] = fbuf.view(N, F)
+        d["edge_index"] = parts[0].view(2, E)
+        d["batch"], d["y"], d["ptr"], d["edge_ptr"] = parts[1], parts[2], parts[3], parts[4]
+        if T1:
+            d["tile_ptr"], d["tile_node_ptr"], d["tile_edge_ptr"] = parts[5], parts[6], parts[7]
         b._staged = (fbuf, ibuf, views, slot)
         if slot is not None:
             slot.owner = weakref.ref(b)
