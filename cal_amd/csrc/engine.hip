@@ -1682,18 +1682,22 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         fb.dy0 = p0; fb.dy1 = p1; fb.y = e->h;
         if (!nobn) { fb.ubn = bnref(c, 1, N, 0); fb.udot_sum = bn_dsum(c, 1); fb.udot_prod = bn_dprod(c, 1); }
         fb.x0 = x0; fb.W = e->P + e->o_feat_w; fb.bn0 = bnref(c, 0, N, 0);
-        const size_t need = (size_t)T * F * H;
+        // units: the graphs (tiles) of the per-graph kernels -- or, behind the wide convolutions (129-256-node graphs), uniform chunks
+        // of FB_T rows: the layer is row-wise, the chunks need not be graphs (k_feat_bwd with a null unit table)
+        const bool chunks = gwb;
+        const int U = chunks ? cdiv(N, FB_T) : T;
+        const size_t need = (size_t)U * F * H;
         if (slab_off + need > e->slab_floats || fa.nst >= MAX_SLABS) { set_error("engine: slab workspace exhausted"); return 2; }
         fb.slab = e->slabs + slab_off;
-        fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, T};
+        fa.st[fa.nst++] = SlabTask{e->slabs + slab_off, e->G + e->o_feat_w, F * H, U};
         slab_off += need;
-        d_bn0.p = parts_alloc(c, (size_t)T * 2 * F); d_bn0.P = T; d_bn0.stride = 2 * F;
+        d_bn0.p = parts_alloc(c, (size_t)U * 2 * F); d_bn0.P = U; d_bn0.stride = 2 * F;
         if (!d_bn0.p) { set_error("engine: partial-row workspace exhausted"); return 2; }
         fb.parts = d_bn0.p;
-        const dim3 grid(T), blk(GB_NT);
+        const dim3 grid(U), blk(GB_NT);
         if (F <= FB_F && !nobn) {
             // few features (SPMotif: F = 10): the FMA-loop kernel is 1.7 us shorter than one MFMA tile behind three barriers
-            hipLaunchKernelGGL(k_feat_bwd, grid, blk, 0, st, e->gptr, fb, H, F, e->status);
+            hipLaunchKernelGGL(k_feat_bwd, grid, blk, 0, st, chunks ? (const int*)nullptr : (const int*)e->gptr, fb, H, F, e->status, N);
         } else if (F <= 64) {
             hipLaunchKernelGGL((k_feat_bwd_mma<8, true>), grid, blk, 0, st, e->gptr, fb, H, F, e->status);
         } else {
@@ -1936,8 +1940,9 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
             double* dsum[1] = {bn_dsum(c, i)}; double* dprod[1] = {bn_dprod(c, i)};
             { ProfScope ps(st, 4, 4.0 * N * H * H + 2.0 * (double)(c.E + N) * H, true); RC(gconv_bwd(c, gd, &gb, 1, dst, dsum, dprod, fa, slab_off, false, gwb ? gw_st : striped_bb(c) && (i > 1 || (F <= FM_F && H <= FB_H)), gwb ? &gs : nullptr)); } STAGE();
             RC(flush_finals(c)); STAGE();
-            if (i == 1 && !gwb && F <= FM_F && H <= FB_H) {
+            if (i == 1 && (gwb ? F <= FB_F : F <= FM_F) && H <= FB_H) {
                 // the feature layer's backward per graph, fed from this layer's partial dX' (no k_bn_bwd, no dZ round trip)
+                // (wide graphs: the same FMA kernel over uniform 64-row chunks, F <= 64 -- round 6; it replaces k_bn_bwd + the dual GEMM + a finishing launch)
                 RC(feat_bwd(p0, H > GC_N ? dzi : nullptr, false)); STAGE();
             } else if (i == 1) {       // the feature layer below is a plain GEMM: materialise dZ for it
                 BnBwdProb p{p0, hin, e->dZ, bnref(c, i, N, 0), bn_dsum(c, i), bn_dprod(c, i), Acc(), H > GC_N ? dzi : nullptr};

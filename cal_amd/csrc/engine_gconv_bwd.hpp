@@ -560,8 +560,11 @@ struct FeatBwdArgs {
     float* slab;                             // [B][F,H]
     double* parts;                           // [B][2F]: (sum dX0, sum dX0 * x0_hat)
 };
+// gptr == null (round 6: graphs of 129-256 nodes behind the wide convolutions, engine_gwide.hpp): the units are uniform chunks of FB_T
+// ROWS of the batch, b * FB_T .. -- nothing here looks at the graph structure (dW_feat and the two BatchNorm_0 sums are sums over
+// rows), so a 240-node graph is simply four units with a slab and a partial row each.
 __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr, const FeatBwdArgs a, int H, int F,
-                                                  int* __restrict__ status) {
+                                                  int* __restrict__ status, int N) {
     __shared__ __attribute__((aligned(16))) float Dz[FB_T * (FB_H + 4)];     // dZ rows [j][n]
     __shared__ float Xn[FB_T * FB_F];                    // x0_hat rows [j][f] (normalised, no affine)
     __shared__ __attribute__((aligned(16))) float Ws[FB_F * (FB_H + 4)];     // W_feat [f][n]
@@ -571,7 +574,7 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
     BLK_CLK(0);
     warm_kernargs<sizeof(FeatBwdArgs) + 32>();
     const int b = blockIdx.x, t = threadIdx.x, LDZ = FB_H + 4;
-    const int g0 = gptr[b], rows = gptr[b + 1] - g0;
+    const int g0 = gptr ? gptr[b] : b * FB_T, rows = gptr ? gptr[b + 1] - g0 : min(FB_T, N - g0);
     float* slab = a.slab + (size_t)b * F * H;
     double* parts = a.parts + (size_t)b * 2 * F;
     if (rows <= 0 || rows > FB_T) {

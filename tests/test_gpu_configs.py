@@ -732,6 +732,8 @@ def test_config1_shape_takes_the_wide_per_graph_kernels(nb, hidden, layers):
     names = _stage_names()
     assert names.count("k_gw_fwd(co)") == 1 and "k_gw_bwd" in names and "k_gw_fwd" in names, names
     assert "k_espmm" not in names and "k_pool2" not in names
+    # the feature layer's backward per graph in row chunks (k_feat_bwd<WIDE>): no dual GEMM / BatchNorm-backward launch below layer 1
+    assert "k_feat_bwd" in names and "k_bn_bwd" not in names, names
     lp = eng.buffer("logp", 3 * nb * 4).view(3, nb, 4).cpu()
     for r, t in zip(logits, lp):
         assert (r.detach() - t).abs().max().item() < LOGIT_TOL
