@@ -204,6 +204,7 @@ struct Engine {
     int ro_rows;             // 1: ... also for 129 .. 512 graphs, in row blocks (k_ro_step<true>); CAL_AMD_RO_ROWS=0: the GEMM chain there
     int striped;             // 1: the per-graph kernels exchange their BatchNorm sums through NSTRIPE accumulator planes (engine.hpp: stripe_sum)
                              // instead of partial rows + k_stats_final; CAL_AMD_STRIPED=0 keeps the finishing launches
+    int rpb_div;             // rows per workgroup of the node-level row kernels = max(32, N / rpb_div); CAL_AMD_RPB_DIV (experiment); 0 = by size
     int fold_zero;           // 1: forward + backward steps on the per-graph plan have no k_zero_f64 launch (PlanFold); CAL_AMD_FOLD_ZERO=0: always the launch
     int bn0_dirty_host;      // host twin of the device word status[3]: a training forward has been enqueued since the last k_finish
     int gw_cols;             // CAL_AMD_GW_COLS (experiment): 32 / 64 forces the wide forward kernels' slice width, 0 = by occupancy
@@ -276,6 +277,7 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     { const char* v = getenv("CAL_AMD_GWIDE"); e->gwide = !(v && v[0] == '0'); }
     { const char* v = getenv("CAL_AMD_GW_COLS"); e->gw_cols = v ? atoi(v) : 0; }
     { const char* v = getenv("CAL_AMD_FOLD_ZERO"); e->fold_zero = !(v && v[0] == '0'); }
+    { const char* v = getenv("CAL_AMD_RPB_DIV"); e->rpb_div = v ? std::max(1, atoi(v)) : 0; }
     e->bn0_dirty_host = 1;                            // 32 / 64 (experiment): forward slice width forced
     {
         // k_ro_step's 3 * H / 16 workgroups (133 KB of LDS each: one per CU) meet at spin barriers: they must all be
@@ -1697,7 +1699,8 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         const dim3 grid(U), blk(GB_NT);
         if (F <= FB_F && !nobn) {
             // few features (SPMotif: F = 10): the FMA-loop kernel is 1.7 us shorter than one MFMA tile behind three barriers
-            hipLaunchKernelGGL(k_feat_bwd, grid, blk, 0, st, chunks ? (const int*)nullptr : (const int*)e->gptr, fb, H, F, e->status, N);
+            if (F <= 16) hipLaunchKernelGGL(k_feat_bwd<16>, grid, blk, 0, st, chunks ? (const int*)nullptr : (const int*)e->gptr, fb, H, F, e->status, N);
+            else hipLaunchKernelGGL(k_feat_bwd<FB_F>, grid, blk, 0, st, chunks ? (const int*)nullptr : (const int*)e->gptr, fb, H, F, e->status, N);
         } else if (F <= 64) {
             hipLaunchKernelGGL((k_feat_bwd_mma<8, true>), grid, blk, 0, st, e->gptr, fb, H, F, e->status);
         } else {
@@ -2147,7 +2150,8 @@ CAL_EXPORT int cal_engine_step(void* h, const float* x0, const int64_t* edge_ind
                                    e->max_edges <= gc_edge_cap(64)),
                 "cal_engine_set_tiles needs the per-graph kernels: hidden in {64, 128}, the tiles' offsets (cal_engine_set_graph_ptrs) and bounds <= 64 nodes / 1024 edges");
     c.training = (mode & 1) ? 1 : 0;
-    c.rpb_n = std::max(32, cdiv(N, 1024));
+    // (16 k - 64 k rows: 512 workgroups -- a workgroup's prologue / column-sum epilogue over 32 rows was a third of k_att_bwd at 30 k rows)
+    c.rpb_n = std::max(32, cdiv(N, e->rpb_div ? e->rpb_div : (N >= 16384 && N <= 65536 ? 512 : 1024)));
     c.rpb_b = std::max(32, cdiv(B, 64));
     c.parts_off = 0;
     c.fin.nt = 0;
@@ -2200,7 +2204,8 @@ CAL_EXPORT int cal_engine_backward_from(void* h, const float* x0, const int64_t*
     c.T = e->ntiles > 0 ? e->ntiles : (int)B;
     c.batch = batch;
     c.training = 1;
-    c.rpb_n = std::max(32, cdiv(N, 1024));
+    // (16 k - 64 k rows: 512 workgroups -- a workgroup's prologue / column-sum epilogue over 32 rows was a third of k_att_bwd at 30 k rows)
+    c.rpb_n = std::max(32, cdiv(N, e->rpb_div ? e->rpb_div : (N >= 16384 && N <= 65536 ? 512 : 1024)));
     c.rpb_b = std::max(32, cdiv(B, 64));
     c.parts_off = 0; c.fin.nt = 0; c.nfork = 0;
     c.y = nullptr; c.perm = nullptr; c.wc = c.wo = c.wco = 0.f; c.want_grad = 1;

@@ -563,14 +563,17 @@ struct FeatBwdArgs {
 // gptr == null (round 6: graphs of 129-256 nodes behind the wide convolutions, engine_gwide.hpp): the units are uniform chunks of FB_T
 // ROWS of the batch, b * FB_T .. -- nothing here looks at the graph structure (dW_feat and the two BatchNorm_0 sums are sums over
 // rows), so a 240-node graph is simply four units with a slab and a partial row each.
+// FMAX: the LDS arrays' feature capacity (16: 46 KB, three workgroups per CU -- SPMotif's F = 10 over 470 row chunks was two rounds
+// of one workgroup per CU at 100 KB; 64: any F <= FB_F)
+template <int FMAX>
 __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr, const FeatBwdArgs a, int H, int F,
                                                   int* __restrict__ status, int N) {
     __shared__ __attribute__((aligned(16))) float Dz[FB_T * (FB_H + 4)];     // dZ rows [j][n]
-    __shared__ float Xn[FB_T * FB_F];                    // x0_hat rows [j][f] (normalised, no affine)
-    __shared__ __attribute__((aligned(16))) float Ws[FB_F * (FB_H + 4)];     // W_feat [f][n]
+    __shared__ float Xn[FB_T * FMAX];                    // x0_hat rows [j][f] (normalised, no affine)
+    __shared__ __attribute__((aligned(16))) float Ws[FMAX * (FB_H + 4)];     // W_feat [f][n]
     __shared__ float um_s[FB_H], ur_s[FB_H], ug_s[FB_H], u1_s[FB_H], u2_s[FB_H];
-    __shared__ float m0_s[FB_F], r0_s[FB_F], g0_s[FB_F], b0_s[FB_F];
-    __shared__ float dX0[FB_T * FB_F];
+    __shared__ float m0_s[FMAX], r0_s[FMAX], g0_s[FMAX], b0_s[FMAX];
+    __shared__ float dX0[FB_T * FMAX];
     BLK_CLK(0);
     warm_kernargs<sizeof(FeatBwdArgs) + 32>();
     const int b = blockIdx.x, t = threadIdx.x, LDZ = FB_H + 4;
@@ -653,7 +656,7 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = t + u * GB_NT;
-            if (i < rows * F) { const int f = i % F; Xn[(i / F) * FB_F + f] = (xr[u] - m0_s[f]) * r0_s[f]; }
+            if (i < rows * F) { const int f = i % F; Xn[(i / F) * FMAX + f] = (xr[u] - m0_s[f]) * r0_s[f]; }
         }
     }
     __syncthreads();
@@ -665,7 +668,7 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
         for (int j = 0; j < rows; ++j) {
-            const float xv = fmaf(Xn[j * FB_F + f], gam, bet);
+            const float xv = fmaf(Xn[j * FMAX + f], gam, bet);
             const float4 d = *reinterpret_cast<const float4*>(Dz + j * LDZ + n);
             acc.x = fmaf(xv, d.x, acc.x); acc.y = fmaf(xv, d.y, acc.y); acc.z = fmaf(xv, d.z, acc.z); acc.w = fmaf(xv, d.w, acc.w);
         }
@@ -695,7 +698,7 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
             for (int k = 0; k < FB_H / 16; ++k) p = dot4(dz[k], wv[k], p);
             p += __shfl_xor(p, 1, 64);
             p += __shfl_xor(p, 2, 64);
-            if (qn == 0 && j < rows) dX0[j * FB_F + f] = p;
+            if (qn == 0 && j < rows) dX0[j * FMAX + f] = p;
         }
     }
     __syncthreads();
@@ -708,7 +711,7 @@ __global__ void __launch_bounds__(GB_NT) k_feat_bwd(const int* __restrict__ gptr
 #pragma unroll
         for (int u = 0; u < FB_T / 8; ++u) {
             const int j = min(p + 8 * u, rows - 1);
-            dv[u] = dX0[j * FB_F + fc]; xv[u] = Xn[j * FB_F + fc];
+            dv[u] = dX0[j * FMAX + fc]; xv[u] = Xn[j * FMAX + fc];
         }
 #pragma unroll
         for (int u = 0; u < FB_T / 8; ++u) {
