@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "cal_hip.h"
@@ -500,7 +501,8 @@ HOST_EXPORT int cal_collate_host(const float* X, const int64_t* EI, int64_t Etot
         noff[b + 1] = noff[b] + nn; eoff[b + 1] = eoff[b] + ne;
     }
     const int64_t edges = eoff[B];
-    const int team = B >= 32 ? 4 : 1;
+    static const int team_max = [] { const char* v = getenv("CAL_HOST_COLLATE_THREADS"); const int n = v ? atoi(v) : 4; return n < 1 ? 1 : n; }();
+    const int team = B >= 32 ? team_max : 1;
 #pragma omp parallel for schedule(static) num_threads(team) if (team > 1)
     for (int64_t b = 0; b < B; ++b) {
         const int64_t g = idx[b];
