@@ -35,6 +35,7 @@
 #include "engine_ggin.hpp"
 #include "engine_feat.hpp"
 #include "engine_gwide.hpp"
+#include "engine_attwide.hpp"
 
 namespace cal {
 
@@ -204,6 +205,7 @@ struct Engine {
     int ro_rows;             // 1: ... also for 129 .. 512 graphs, in row blocks (k_ro_step<true>); CAL_AMD_RO_ROWS=0: the GEMM chain there
     int striped;             // 1: the per-graph kernels exchange their BatchNorm sums through NSTRIPE accumulator planes (engine.hpp: stripe_sum)
                              // instead of partial rows + k_stats_final; CAL_AMD_STRIPED=0 keeps the finishing launches
+    int attwide;             // 1: the attention block of 129-256-node graphs per graph (engine_attwide.hpp); CAL_AMD_ATTWIDE=0: the node-level kernels
     int rpb_div;             // rows per workgroup of the node-level row kernels = max(32, N / rpb_div); CAL_AMD_RPB_DIV (experiment); 0 = by size
     int fold_zero;           // 1: forward + backward steps on the per-graph plan have no k_zero_f64 launch (PlanFold); CAL_AMD_FOLD_ZERO=0: always the launch
     int bn0_dirty_host;      // host twin of the device word status[3]: a training forward has been enqueued since the last k_finish
@@ -277,6 +279,7 @@ CAL_EXPORT void* cal_engine_create(int64_t F, int64_t H, int64_t C, int64_t L) {
     { const char* v = getenv("CAL_AMD_GWIDE"); e->gwide = !(v && v[0] == '0'); }
     { const char* v = getenv("CAL_AMD_GW_COLS"); e->gw_cols = v ? atoi(v) : 0; }
     { const char* v = getenv("CAL_AMD_FOLD_ZERO"); e->fold_zero = !(v && v[0] == '0'); }
+    { const char* v = getenv("CAL_AMD_ATTWIDE"); e->attwide = !(v && v[0] == '0'); }
     { const char* v = getenv("CAL_AMD_RPB_DIV"); e->rpb_div = v ? std::max(1, atoi(v)) : 0; }
     e->bn0_dirty_host = 1;                            // 32 / 64 (experiment): forward slice width forced
     {
@@ -758,6 +761,12 @@ bool use_gw(const Ctx& c) {
     return e->gwide && e->max_nodes > GC_T && e->max_nodes <= GW_T && e->max_edges <= GW_E && e->H % GC_N == 0 && e->H <= GW_K && c.B > 0 &&
            e->ntiles == 0 && e->K == 0 && !e->gin;
 }
+// the attention block between the backbone and the causal convolutions per graph for the wide shapes (engine_attwide.hpp): needs the
+// per-graph plan's facts (a graph's edges are one run of edge_index columns, no self loops: slot ranges = edge ranges)
+bool use_aw(const Ctx& c) {
+    const Engine* e = c.e;
+    return use_gw(c) && e->attwide && e->node_ptr && e->edge_ptr && e->max_nodes <= AW_T && e->max_edges <= AW_E && e->H <= 256 && c.T <= 512;
+}
 // per-graph fused backward (engine_gconv_bwd.hpp): 64-node graphs only
 bool use_gcb(const Ctx& c) { return use_gc(c) && gc_small(c) && c.T <= 128 * 4; }
 // Which BatchNorm sites of a step go through the accumulator planes (engine.hpp: stripe_sum): those whose producers are per-graph
@@ -1224,8 +1233,25 @@ int engine_forward(Ctx& c, const float* x0, const int64_t* edge_index, const int
     }
     const float* x = e->h + (size_t)L * NH;
     // 5+6 per graph: node attention, edge softmax and weighted degrees in one kernel (4 rows per lane group)
-    const bool att_graph = att_graph_fwd(c);
-    if (att_graph) {
+    // (forward: only when the launch has enough workgroups -- 32 graphs on 256 CUs lose to the node-parallel pair, 19.3 vs 12.6 us;
+    //  128 graphs win, 20.5 vs 24.0 us with their finishing launch.  The backward per graph wins at both: 22.8 vs 28.1, 30.8 vs 47.7 us)
+    const bool att_wide = use_aw(c) && 3 * T >= e->num_cus;
+    if (att_wide) {          // graphs of 129-256 nodes: the same kernel in four row passes, four slots per lane (engine_attwide.hpp)
+        const bool sw = gw_st;
+        const Acc a0 = graph_acc(c, bn_stsum(c, L + 1), H, sw), a1 = graph_acc(c, bn_stsq(c, L + 1), H, sw);
+        const Acc a2 = graph_acc(c, bn_stsum(c, L + 2), H, sw), a3 = graph_acc(c, bn_stsq(c, L + 2), H, sw);
+        RC(with_g(H, [&](auto g) {
+            constexpr int G = decltype(g)::value;
+            hipLaunchKernelGGL((k_att_fwd_wide<4, G>), dim3(T), dim3(512), 0, st, e->gptr, gs, x, e->P + e->o_natt_w, e->P + e->o_natt_b,
+                               e->P + e->o_eatt_w, e->P + e->o_eatt_b, e->anode, e->pq, e->att, e->dis_co, e->dis_co + N, a0, a1, a2, a3,
+                               e->loop_w, H, E, e->status, e->no_node_att ? 0.f : 1.f, e->no_edge_att ? 0.f : 1.f, e->eptr);
+            return 0;
+        }));
+        CAL_CHECK_LAUNCH("k_att_fwd_wide"); STAGE();
+        RC(flush_finals(c)); STAGE();
+    }
+    const bool att_graph = att_wide || att_graph_fwd(c);
+    if (att_graph && !att_wide) {
         const bool sco = striped_co(c);
         const Acc a0 = graph_acc(c, bn_stsum(c, L + 1), H, sco), a1 = graph_acc(c, bn_stsq(c, L + 1), H, sco);
         const Acc a2 = graph_acc(c, bn_stsum(c, L + 2), H, sco), a3 = graph_acc(c, bn_stsq(c, L + 2), H, sco);
@@ -1428,8 +1454,9 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         d.p = parts_alloc(c, (size_t)PN * cols); d.P = PN; d.stride = cols;
         return d.p ? Acc(nullptr, d.p, cols) : Acc();
     };
-    const int ag_split = 2;                                        // workgroups per graph of k_att_bwd_graph
-    auto deferred_g = [&](int cols, Deferred& d) -> Acc {          // one partial row per workgroup of k_att_bwd_graph
+    const bool awb = use_aw(c);                                    // ... of k_att_bwd_wide (129-256-node graphs): two while 2 T workgroups fit the chip
+    const int ag_split = awb ? ((int64_t)2 * T <= e->num_cus ? 2 : 1) : 2;       // workgroups per graph of k_att_bwd_graph
+    auto deferred_g = [&](int cols, Deferred& d) -> Acc {          // one partial row per workgroup of k_att_bwd_graph / k_att_bwd_wide
         d.p = parts_alloc(c, (size_t)ag_split * T * cols); d.P = ag_split * T; d.stride = cols;
         return d.p ? Acc(nullptr, d.p, cols) : Acc();
     };
@@ -1609,7 +1636,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         RC(flush_finals(c)); STAGE();
         // the edge-weight gradients through the normalisation are part of the per-graph attention backward below; big
         // batches (a per-graph launch would be several waves of one-per-CU workgroups) keep the node- / edge-parallel kernels
-        if (!agb) {
+        if (!agb && !awb) {
             const bool two = H > GC_N;
             RC(norm_bwd(two ? e->gn + 2 * (size_t)E : nullptr, two ? e->gself + 2 * (size_t)N : nullptr));
         }
@@ -1647,7 +1674,22 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         aa.Wn = e->P + e->o_natt_w; aa.We = e->P + e->o_eatt_w; aa.dl = e->dl;
         aa.fnode = e->no_node_att ? 0.f : 1.f; aa.fedge = e->no_edge_att ? 0.f : 1.f;
         aa.gs = gs; aa.gd = gd; aa.dZ = e->dZ;
-        if (agb) {       // per graph: d deg, d edge logits and the row pass in one kernel (engine_attbwd.hpp)
+        if (awb) {       // per graph of up to 256 nodes: the same with a sparse edge phase (engine_attwide.hpp); inputs in edge-id order
+            aa.dbias = L > 0 ? deferred_g(H, d_convb[L - 1]) : Acc();
+            aa.dWn = deferred_g(H + 4, d_dwn); aa.dWe = deferred_g(2 * H + 4, d_dwe);
+            if (!aa.dWn.on() || !aa.dWe.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }
+            AttBwdWideArgs ag;
+            ag.a = aa; ag.gptr = e->gptr; ag.eptr = e->eptr; ag.row32 = e->row32; ag.col32 = e->col32; ag.att = e->att; ag.dis = e->dis_co;
+            ag.gn = e->gn; ag.gn2 = two ? e->gn + 2 * (size_t)E : nullptr;
+            ag.gself = e->gself; ag.gself2 = two ? e->gself + 2 * (size_t)N : nullptr;
+            ag.loop_w = e->loop_w; ag.E = E; ag.N = N; ag.status = e->status;
+            RC(with_g(H, [&](auto g) {
+                constexpr int G = decltype(g)::value;
+                hipLaunchKernelGGL((k_att_bwd_wide<4, G>), dim3(ag_split * T), dim3(512), 0, st, ag, 1, H, ag_split);
+                return 0;
+            }));
+            CAL_CHECK_LAUNCH("k_att_bwd_wide"); STAGE();
+        } else if (agb) {       // per graph: d deg, d edge logits and the row pass in one kernel (engine_attbwd.hpp)
             aa.dbias = L > 0 ? deferred_g(H, d_convb[L - 1]) : Acc();
             aa.dWn = deferred_g(H + 4, d_dwn); aa.dWe = deferred_g(2 * H + 4, d_dwe);
             if (!aa.dWn.on() || !aa.dWe.on()) { set_error("engine: partial-row workspace exhausted"); return 2; }

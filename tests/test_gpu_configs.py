@@ -708,7 +708,7 @@ def _stage_names():
         k += 1
 
 
-@pytest.mark.parametrize("nb,hidden,layers", [(32, 128, 3), (6, 64, 2), (1 + 256 // 4 // 2, 128, 1)])
+@pytest.mark.parametrize("nb,hidden,layers", [(32, 128, 3), (6, 64, 2), (1 + 256 // 4 // 2, 128, 1), (90, 64, 1)])
 def test_config1_shape_takes_the_wide_per_graph_kernels(nb, hidden, layers):
     """The reference's DEFAULT graph size (opts.py:18 node_num = 15 -> 225-247 nodes, utils.py:62-63) runs the wide per-graph
     convolutions both ways (engine_gwide.hpp: k_gw_fwd / k_gw_bwd; gcn_conv.py:72-104, model.py:93-95,112-113) -- asserted by
@@ -734,6 +734,13 @@ def test_config1_shape_takes_the_wide_per_graph_kernels(nb, hidden, layers):
     assert "k_espmm" not in names and "k_pool2" not in names
     # the feature layer's backward per graph in row chunks (k_feat_bwd<WIDE>): no dual GEMM / BatchNorm-backward launch below layer 1
     assert "k_feat_bwd" in names and "k_bn_bwd" not in names, names
+    # ... and the attention block per graph both ways (engine_attwide.hpp): no node- / edge-parallel launches between the convolutions
+    # (the forward one only when the launch has enough workgroups, 3 T >= CUs: 90 graphs here; below that the node-parallel pair)
+    assert "k_att_bwd_wide" in names and not {"k_normbwd_node2", "k_normbwd_edge", "k_att_bwd"} & set(names), names
+    if 3 * nb >= 256:
+        assert "k_att_fwd_wide" in names and not {"k_node_att_fwd", "k_edge_att_deg"} & set(names), names
+    else:
+        assert "k_node_att_fwd" in names and "k_att_fwd_wide" not in names, names
     lp = eng.buffer("logp", 3 * nb * 4).view(3, nb, 4).cpu()
     for r, t in zip(logits, lp):
         assert (r.detach() - t).abs().max().item() < LOGIT_TOL
