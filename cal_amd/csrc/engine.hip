@@ -1455,7 +1455,7 @@ int engine_backward(Ctx& c, const float* x0, const int64_t* batch) {
         return d.p ? Acc(nullptr, d.p, cols) : Acc();
     };
     const bool awb = use_aw(c);                                    // ... of k_att_bwd_wide (129-256-node graphs): two while 2 T workgroups fit the chip
-    const int ag_split = awb ? ((int64_t)2 * T <= e->num_cus ? 2 : 1) : 2;       // workgroups per graph of k_att_bwd_graph
+    const int ag_split = awb ? std::max(1, std::min(8, e->num_cus / std::max(T, 1))) : 2;       // workgroups per graph of k_att_bwd_graph
     auto deferred_g = [&](int cols, Deferred& d) -> Acc {          // one partial row per workgroup of k_att_bwd_graph / k_att_bwd_wide
         d.p = parts_alloc(c, (size_t)ag_split * T * cols); d.P = ag_split * T; d.stride = cols;
         return d.p ? Acc(nullptr, d.p, cols) : Acc();

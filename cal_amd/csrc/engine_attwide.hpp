@@ -11,7 +11,8 @@
 // then the row phase of k_att_bwd_graph unchanged.  Replaces k_normbwd_node2 -> k_normbwd_edge -> k_att_bwd (three node- / edge-
 // parallel launches with ddeg / dl through HBM: 48 us of the 500 us step at 30 k rows).  Inputs in EDGE-ID order (att, gn as the
 // wide convolution backward leaves them): one round of loads, no slot-order twins.
-//   grid (nsplit B), 512 threads; nsplit = 2: both workgroups of a graph run the edge phase, each takes half of the rows.
+//   grid (nsplit B), 512 threads: the nsplit workgroups of a graph all run the (cheap) edge phase, each takes 1 / nsplit of the rows
+//   (nsplit = CUs / graphs, at most 8: 32 graphs of 235 nodes -> one row-loop iteration per workgroup).
 // Sums are added in a fixed order (slots of a row strided over 8 lanes, DPP sums): bit-reproducible.
 #pragma once
 #include "engine_attbwd.hpp"
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(512) k_att_bwd_wide(const AttBwdWideArgs ga, i
     __shared__ float bnk_s[8][G * VEC];
     __shared__ int ps_s[AW_T + 1], pd_s[AW_T + 1];
     __shared__ float dis_c_s[AW_T], dis_o_s[AW_T], dd_c_s[AW_T], dd_o_s[AW_T], spv_s[AW_T], sqv_s[AW_T], gs_c_s[AW_T], gs_o_s[AW_T];
-    const int b = nsplit == 2 ? blockIdx.x >> 1 : blockIdx.x, half = nsplit == 2 ? blockIdx.x & 1 : 0, t = threadIdx.x, grp = t / G, l = t % G;
+    const int b = (int)blockIdx.x / nsplit, half = (int)blockIdx.x - b * nsplit, t = threadIdx.x, grp = t / G, l = t % G;     // half: this workgroup's part of the rows
     const int g0 = ga.gptr[b], rows = ga.gptr[b + 1] - g0, e0 = ga.eptr[b], ne = ga.eptr[b + 1] - e0;
     const int64_t E = ga.E;
     const int N = ga.N;
@@ -112,8 +113,8 @@ __global__ void __launch_bounds__(512) k_att_bwd_wide(const AttBwdWideArgs ga, i
                 hc2[u] = V::ld(dxhc2 + v * H + cc); ho2[u] = V::ld(dxho2 + v * H + cc);
             }
         };
-        const int hrows = (rows + 1) >> 1;
-        const int rbeg = half * hrows, rend = nsplit == 2 ? min(rows, rbeg + hrows) : rows;      // this workgroup's rows
+        const int hrows = (rows + nsplit - 1) / nsplit;
+        const int rbeg = half * hrows, rend = min(rows, rbeg + hrows);      // this workgroup's rows
         load_rows(rbeg + grp);
         // pins: nothing above may sink below this point
 #pragma unroll
